@@ -1,0 +1,174 @@
+"""bench.py — env-steps/sec of the batched ORCA step (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one transition of EVERY env of the batch (4096 envs x 5 humans per GPU, ORCA humans + holonomic
+ORCA robot, in-kernel auto-reset): `--steps K` executes exactly K such batched steps per rank after W warm-up
+steps, in fused launches of `--chunk` steps each.  value = total env transitions of all ranks / wall time.
+
+    python bench.py                                        # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W             # N GPUs, one rank per GPU (RCCL)
+
+Multi-GPU: the env axis is sharded (weak scaling: 4096 envs per GPU, global env ids offset by rank, no
+collective on the step path); the only exchange is one all-gather (RCCL) of the per-rank episode summaries
+at the end, inside the timed region.  The JSON line also carries `roofline` (algorithmic bytes of the
+dominant kernel over its HIP-event duration) and, at N=1, `cpu_baseline` (the CPU oracle timed on this
+host's cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_env_step(H):
+    """72 B per agent (read pos/vel/goal/radius/v_pref, write pos/vel) + 26 B per env."""
+    return 72 * (H + 1) + 26
+
+
+def cpu_baseline(envs, humans, target_seconds=12.0):
+    """The CPU oracle (oracle/crowd_oracle.cpp: same workload, same auto-reset rollout) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    import crowd_oracle
+
+    def run(threads, steps):
+        crowd_oracle.CrowdOracle.set_threads(threads)
+        o = crowd_oracle.CrowdOracle(num_envs=envs, num_humans=humans, robot_policy=1, robot_visible=1)
+        o.reset(2000 + np.arange(envs))
+        z = lambda dt: np.zeros(envs, dtype=dt)  # noqa: E731
+        t0 = time.perf_counter()
+        total, _ = o.rollout(steps, 2000, 2 ** 32 - 2000, 4, z(np.int32), z(np.int32), z(np.float64))
+        return total, time.perf_counter() - t0
+
+    cores = crowd_oracle.CrowdOracle.max_threads()
+    n, dt = run(cores, 4)  # calibration
+    steps = max(4, min(2000, int(target_seconds * 0.6 / max(dt / 4, 1e-6))))
+    n_all, dt_all = run(cores, steps)
+    steps1 = max(2, int(steps / max(cores, 1) * 0.6))
+    n_one, dt_one = run(1, steps1)
+    crowd_oracle.CrowdOracle.set_threads(cores)
+    return {
+        'value': n_all / dt_all, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+        'sample': '%d envs x %d humans x %d steps, auto-reset, OpenMP over envs (oracle/crowd_oracle.cpp, '
+                  'float32 RVO2 restatement; upstream Python-RVO2 is not installable offline)' % (envs, humans, steps),
+        'single_core_value': n_one / dt_one,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
+    ap.add_argument('--humans', type=int, default=5)
+    ap.add_argument('--chunk', type=int, default=100, help='steps fused into one kernel launch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import crowdnav_amd
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    B, H = args.envs, args.humans
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
+                                       robot_visible=1, device=local_rank)
+    # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
+    bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, episode_limit=-1, record_capacity=4,
+                             env_offset=rank * B, env_stride=world * B)
+
+    def run(n_steps, events=None):
+        left = n_steps
+        while left > 0:
+            n = min(args.chunk, left)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            eng.rollout(n)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, n))
+            left -= n
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    before = int(bufs['transitions'].item())
+    events = []
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, events)
+    # shard boundary: per-rank episode summary (finished episodes, their mean discounted return) to all ranks
+    cnt = bufs['ep_count'].sum().to(torch.float64)
+    k = torch.clamp(bufs['ep_count'], max=bufs['ep_return'].shape[1])
+    mask = torch.arange(bufs['ep_return'].shape[1], device=k.device)[None, :] < k[:, None]
+    summary = torch.stack([cnt, (bufs['ep_return'] * mask).sum(), mask.sum().to(torch.float64)])
+    if world > 1:
+        gathered = [torch.empty_like(summary) for _ in range(world)]
+        dist.all_gather(gathered, summary)
+        summary = torch.stack(gathered).sum(0)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    transitions = int(bufs['transitions'].item()) - before
+    assert transitions == B * args.steps, (transitions, B * args.steps)
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total = transitions * world
+
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    launches = len(events)
+    avg_launch_s = kernel_ms / 1e3 / launches
+    bytes_per_launch = algorithmic_bytes_per_env_step(H) * B * (args.steps / launches)
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+    out = {
+        'metric': 'env-steps/sec (whole node), 4096 envs x 5 humans, ORCA step',
+        'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 ORCA solve + f64 env step', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: %d batched envs x %d humans per GPU, ORCA humans + holonomic '
+                               'ORCA robot (visible), circle_crossing, in-kernel auto-reset' % (B, H),
+                   'envs_per_gpu': B, 'humans': H, 'steps_per_launch': args.chunk,
+                   'parallelism': 'env-axis shards x%d, all-gather of episode summaries at the end' % world},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'cn::rollout_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
+                     'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
+        'episodes_finished': int(summary[0].item()),
+        'mean_recorded_return': float(summary[1].item() / max(summary[2].item(), 1.0)),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(B, H)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,107 @@
+"""ctypes binding of libcrowdnav_amd.so (include/crowdnav_amd.h).
+
+The shared library is the product: there is no CPU fallback.  If it has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C crowdnav_amd/csrc`) importing this
+module raises, and creating an engine without a visible gfx950 device raises CrowdNavAmdError.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
+ABI_VERSION = 1
+
+CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
+NOTHING, DANGER, REACH_GOAL, COLLISION, TIMEOUT = range(5)
+ROBOT_EXTERNAL, ROBOT_ORCA = 0, 1
+CIRCLE_CROSSING, SQUARE_CROSSING = 0, 1
+
+
+class CrowdNavAmdError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__('libcrowdnav_amd: %s (status %d)' % (message, status))
+        self.status = status
+
+
+class CnConfig(C.Structure):
+    """struct cn_config (include/crowdnav_amd.h)."""
+    _fields_ = [
+        ('num_envs', C.c_int32), ('num_humans', C.c_int32),
+        ('time_step', C.c_double), ('time_limit', C.c_double),
+        ('success_reward', C.c_double), ('collision_penalty', C.c_double),
+        ('discomfort_dist', C.c_double), ('discomfort_penalty_factor', C.c_double),
+        ('robot_visible', C.c_int32), ('robot_policy', C.c_int32),
+        ('robot_safety_space', C.c_double), ('human_safety_space', C.c_double),
+        ('neighbor_dist', C.c_double),
+        ('max_neighbors', C.c_int32), ('scenario_rule', C.c_int32),
+        ('time_horizon', C.c_double), ('time_horizon_obst', C.c_double),
+        ('circle_radius', C.c_double), ('square_width', C.c_double),
+        ('human_radius', C.c_double), ('human_v_pref', C.c_double),
+        ('robot_radius', C.c_double), ('robot_v_pref', C.c_double),
+        ('randomize_attributes', C.c_int32), ('device', C.c_int32),
+    ]
+
+
+class CnRolloutIo(C.Structure):
+    """struct cn_rollout_io (include/crowdnav_amd.h)."""
+    _fields_ = [
+        ('seed_base', C.c_uint32), ('seed_mod', C.c_uint32),
+        ('episode_limit', C.c_int64), ('env_offset', C.c_int64), ('env_stride', C.c_int64),
+        ('record_capacity', C.c_int32),
+        ('ep_outcome', C.c_void_p), ('ep_steps', C.c_void_p), ('ep_return', C.c_void_p),
+        ('ep_time', C.c_void_p), ('ep_danger', C.c_void_p), ('ep_danger_dmin_sum', C.c_void_p),
+        ('ep_count', C.c_void_p), ('cur_steps', C.c_void_p), ('cur_return', C.c_void_p),
+        ('cur_danger', C.c_void_p), ('cur_danger_dmin_sum', C.c_void_p),
+        ('active', C.c_void_p), ('transitions', C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/crowdnav_amd.h declares
+_P = C.c_void_p
+SYMBOLS = {
+    'cn_last_error': (C.c_char_p, []),
+    'cn_abi_version': (C.c_int, []),
+    'cn_create': (C.c_int, [C.POINTER(CnConfig), C.POINTER(_P)]),
+    'cn_destroy': (C.c_int, [_P]),
+    'cn_set_stream': (C.c_int, [_P, _P]),
+    'cn_sync': (C.c_int, [_P]),
+    'cn_set_state': (C.c_int, [_P, _P, _P]),
+    'cn_get_state': (C.c_int, [_P, _P, _P]),
+    'cn_drop_robot_sim': (C.c_int, [_P]),
+    'cn_reset': (C.c_int, [_P, _P, _P, _P]),
+    'cn_orca': (C.c_int, [_P, _P]),
+    'cn_step': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    'cn_set_gamma': (C.c_int, [_P, C.c_double]),
+    'cn_rollout_begin': (C.c_int, [_P, C.POINTER(CnRolloutIo)]),
+    'cn_rollout': (C.c_int, [_P, C.POINTER(CnRolloutIo), C.c_int]),
+    'cn_mt_random': (C.c_int, [_P, C.c_uint32, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every declared symbol; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'crowdnav_amd: %s is missing. Build the HIP library first (make -C crowdnav_amd/csrc, or '
+            '__graft_entry__.build()); there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.cn_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError('crowdnav_amd: library ABI %d != binding ABI %d; rebuild' % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != CN_OK:
+        raise CrowdNavAmdError(status, load().cn_last_error().decode('utf-8', 'replace'))

@@ -1,0 +1,146 @@
+// Seeded scenario generation on device — replaces, per env,
+//   np.random.seed(offset + case)                        /root/reference crowd_sim/envs/crowd_sim.py:276
+//   CrowdSim.generate_random_human_position(rule)        crowd_sim.py:84-153
+//   generate_circle_crossing_human / generate_square_... crowd_sim.py:155-207
+//   Agent.sample_random_attributes                       crowd_sim/envs/utils/agent.py:39-45
+// numpy's legacy RandomState is MT19937 seeded by init_genrand; random() takes two 32-bit draws
+// (SURVEY.md Appendix C).  One lane generates one env; the 624-word generator state of lane-owner `slot`
+// lives in HBM as key[i * stride + slot], so the lanes of a wave touch consecutive words.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cn {
+
+struct Mt19937 {
+    uint32_t* key;  // key[i * stride]
+    int stride;
+    int pos;  // next word to regenerate, 0..623
+
+    // init_genrand(s); numpy then regenerates the whole block before the first draw, which the
+    // word-at-a-time update below reproduces exactly (word i only needs words i, i+1, i+397 mod 624).
+    __device__ void seed(uint32_t s) {
+        for (int i = 0; i < 624; ++i) {
+            key[(size_t)i * stride] = s;
+            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+        }
+        pos = 0;
+    }
+    __device__ uint32_t next32() {
+        const int i = pos;
+        const int i1 = (i + 1 == 624) ? 0 : i + 1;
+        const int im = (i + 397 >= 624) ? i + 397 - 624 : i + 397;
+        const uint32_t y = (key[(size_t)i * stride] & 0x80000000u) | (key[(size_t)i1 * stride] & 0x7fffffffu);
+        uint32_t v = key[(size_t)im * stride] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        key[(size_t)i * stride] = v;
+        pos = i1;
+        v ^= (v >> 11);
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= (v >> 18);
+        return v;
+    }
+    // np.random.random(): 53-bit double from two draws
+    __device__ double random() {
+        const uint32_t a = next32() >> 5;
+        const uint32_t b = next32() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ double uniform(double lo, double hi) { return lo + (hi - lo) * random(); }
+};
+
+// numpy's 2-vector norm on the reference image: sqrt(fma(y, y, x*x))
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(__builtin_fma(y, y, x * x)); }
+
+struct ScenarioCfg {
+    int num_agents;  // A
+    int rule;        // 0 circle_crossing, 1 square_crossing
+    int randomize;
+    double circle_radius, square_width, discomfort_dist;
+    double human_radius, human_v_pref, robot_radius, robot_v_pref;
+};
+
+// Writes agents [0, A) of one env into the SoA state (double2 planes indexed env*A + agent) and returns the
+// number of np.random.random() calls consumed.
+__device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng, uint32_t seed, size_t base,
+                                             double2* pos, double2* vel, double2* goal, double2* rv) {
+    const double kPi = 3.141592653589793;
+    rng.seed(seed);
+    uint64_t draws = 0;
+    const int A = c.num_agents;
+    const double R = c.circle_radius;
+    pos[base] = make_double2(0.0, -R);
+    goal[base] = make_double2(0.0, R);
+    vel[base] = make_double2(0.0, 0.0);
+    rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
+    for (int i = 1; i < A; ++i) {
+        double radius = c.human_radius, v_pref = c.human_v_pref;
+        if (c.randomize) {
+            v_pref = rng.uniform(0.5, 1.5);
+            radius = rng.uniform(0.3, 0.5);
+            draws += 2;
+        }
+        double x, y, tx, ty;
+        if (c.rule == 0) {
+            for (;;) {
+                const double angle = rng.random() * kPi * 2;
+                const double nx = (rng.random() - 0.5) * v_pref;
+                const double ny = (rng.random() - 0.5) * v_pref;
+                draws += 3;
+                x = R * cos(angle) + nx;
+                y = R * sin(angle) + ny;
+                bool collide = false;
+                for (int k = 0; k < i; ++k) {
+                    const double2 p = pos[base + k], g = goal[base + k];
+                    const double min_dist = radius + rv[base + k].x + c.discomfort_dist;
+                    if (norm2(x - p.x, y - p.y) < min_dist || norm2(x - g.x, y - g.y) < min_dist) {
+                        collide = true;
+                        break;
+                    }
+                }
+                if (!collide) break;
+            }
+            tx = -x;
+            ty = -y;
+        } else {
+            const double w = c.square_width;
+            const double sign = (rng.random() > 0.5) ? -1.0 : 1.0;
+            draws += 1;
+            for (;;) {
+                x = rng.random() * w * 0.5 * sign;
+                y = (rng.random() - 0.5) * w;
+                draws += 2;
+                bool collide = false;
+                for (int k = 0; k < i; ++k) {
+                    const double2 p = pos[base + k];
+                    if (norm2(x - p.x, y - p.y) < radius + rv[base + k].x + c.discomfort_dist) {
+                        collide = true;
+                        break;
+                    }
+                }
+                if (!collide) break;
+            }
+            for (;;) {
+                tx = rng.random() * w * 0.5 * -sign;
+                ty = (rng.random() - 0.5) * w;
+                draws += 2;
+                bool collide = false;
+                for (int k = 0; k < i; ++k) {
+                    const double2 g = goal[base + k];
+                    if (norm2(tx - g.x, ty - g.y) < radius + rv[base + k].x + c.discomfort_dist) {
+                        collide = true;
+                        break;
+                    }
+                }
+                if (!collide) break;
+            }
+        }
+        pos[base + i] = make_double2(x, y);
+        goal[base + i] = make_double2(tx, ty);
+        vel[base + i] = make_double2(0.0, 0.0);
+        rv[base + i] = make_double2(radius, v_pref);
+    }
+    return draws;
+}
+
+}  // namespace cn

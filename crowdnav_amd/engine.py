@@ -1,0 +1,171 @@
+"""BatchedCrowdSim — tensor-level host API over the C ABI (B independent CrowdSim envs on one GPU).
+
+Mirrors, batched over B envs, the reference calls
+    CrowdSim.configure / reset / step / onestep_lookahead   crowd_sim/envs/crowd_sim.py:51-79, 251-420
+    ORCA.predict for every agent                            crowd_sim/envs/policy/orca.py:82-132
+    Explorer.run_k_episodes' episode loop                   crowd_nav/utils/explorer.py:35-72
+torch is used for device memory and streams only; all compute happens in libcrowdnav_amd.so.
+Agent 0 of every env is the robot, agents 1..H the humans.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CnConfig, CnRolloutIo, check
+
+# shipped defaults of crowd_nav/configs/env.config + the hard-coded ORCA constants (orca.py:60-66)
+_DEFAULTS = dict(
+    num_envs=1, num_humans=5, time_step=0.25, time_limit=25.0, success_reward=1.0,
+    collision_penalty=-0.25, discomfort_dist=0.2, discomfort_penalty_factor=0.5, robot_visible=0,
+    robot_policy=_lib.ROBOT_ORCA, robot_safety_space=0.0, human_safety_space=0.0, neighbor_dist=10.0,
+    max_neighbors=10, scenario_rule=_lib.CIRCLE_CROSSING, time_horizon=5.0, time_horizon_obst=5.0,
+    circle_radius=4.0, square_width=10.0, human_radius=0.3, human_v_pref=1.0, robot_radius=0.3,
+    robot_v_pref=1.0, randomize_attributes=0, device=0)
+
+
+def default_config(**overrides):
+    d = dict(_DEFAULTS)
+    unknown = set(overrides) - set(d)
+    if unknown:
+        raise TypeError('unknown config keys: %s' % sorted(unknown))
+    d.update(overrides)
+    return d
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedCrowdSim(object):
+    """B crowd-navigation envs resident in HBM.  All tensors returned live on the engine's device."""
+
+    def __init__(self, **config):
+        self.config = default_config(**config)
+        self.B = int(self.config['num_envs'])
+        self.H = int(self.config['num_humans'])
+        self.A = self.H + 1
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        cfg = CnConfig(**self.config)
+        check(self._lib.cn_create(C.byref(cfg), C.byref(self._h)))
+        self.device = torch.device('cuda', int(self.config['device']))
+        self._rollout = None
+        self.use_current_stream()
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.cn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    # ---------------------------------------------------------------- plumbing
+    def use_current_stream(self):
+        """Launch on torch's current HIP stream so torch ops and torch.cuda.Event order with the engine."""
+        with torch.cuda.device(self.device):
+            check(self._lib.cn_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def sync(self):
+        check(self._lib.cn_sync(self._h))
+
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _dev(self, x, dtype, shape):
+        t = torch.as_tensor(x, dtype=dtype).to(self.device).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError('expected shape %s, got %s' % (tuple(shape), tuple(t.shape)))
+        return t
+
+    # ---------------------------------------------------------------- state
+    def set_state(self, state8=None, global_time=None):
+        """state8: [B, A, 8] float64 (px,py,vx,vy,gx,gy,radius,v_pref); global_time: [B] float64."""
+        s = None if state8 is None else self._dev(state8, torch.float64, (self.B, self.A, 8))
+        g = None if global_time is None else self._dev(global_time, torch.float64, (self.B,))
+        check(self._lib.cn_set_state(self._h, _ptr(s), _ptr(g)))
+        self.sync()  # s/g may be temporaries
+
+    def get_state(self):
+        s = self._new((self.B, self.A, 8), torch.float64)
+        g = self._new((self.B,), torch.float64)
+        check(self._lib.cn_get_state(self._h, _ptr(s), _ptr(g)))
+        return s, g
+
+    def drop_robot_sim(self):
+        check(self._lib.cn_drop_robot_sim(self._h))
+
+    def reset(self, seeds, mask=None):
+        """np.random.seed(seeds[b]) + scenario generation per env; returns the np.random.random() call counts."""
+        host = seeds.cpu().numpy() if torch.is_tensor(seeds) else np.asarray(seeds)
+        bits = np.ascontiguousarray(host.astype(np.uint32)).view(np.int32)  # torch has no uint32 arithmetic
+        sd = self._dev(torch.from_numpy(bits), torch.int32, (self.B,))
+        m = None if mask is None else self._dev(mask, torch.uint8, (self.B,))
+        draws = torch.zeros(self.B, dtype=torch.int64, device=self.device)
+        check(self._lib.cn_reset(self._h, _ptr(sd), _ptr(m), _ptr(draws)))
+        self.sync()
+        return draws
+
+    # ---------------------------------------------------------------- one transition
+    def orca(self):
+        out = self._new((self.B, self.A, 2), torch.float32)
+        check(self._lib.cn_orca(self._h, _ptr(out)))
+        return out
+
+    def step(self, action=None, update=True, want_obs=True):
+        """CrowdSim.step for every env.  action: [B, 2] float64 or None when the robot is ORCA on device."""
+        a = None if action is None else self._dev(action, torch.float64, (self.B, 2))
+        out = dict(
+            reward=self._new((self.B,), torch.float64), done=self._new((self.B,), torch.uint8),
+            info=self._new((self.B,), torch.uint8), dmin=self._new((self.B,), torch.float64),
+            action=self._new((self.B, 2), torch.float64),
+            orca_vel=self._new((self.B, self.A, 2), torch.float32),
+            obs=self._new((self.B, self.H, 5), torch.float64) if want_obs else None)
+        check(self._lib.cn_step(self._h, _ptr(a), int(bool(update)), _ptr(out['reward']), _ptr(out['done']),
+                                _ptr(out['info']), _ptr(out['dmin']), _ptr(out['action']),
+                                _ptr(out['orca_vel']), _ptr(out['obs'])))
+        if a is not None:
+            self.sync()  # `a` may be a temporary
+        return out
+
+    # ---------------------------------------------------------------- fused rollouts
+    def set_gamma(self, gamma):
+        check(self._lib.cn_set_gamma(self._h, float(gamma)))
+
+    def rollout_begin(self, seed_base, seed_mod, episode_limit=-1, record_capacity=8, env_offset=0,
+                      env_stride=None):
+        """Start Explorer-style episode bookkeeping: env b runs global episodes b, b+B, b+2B, ... (< limit),
+        episode c seeded with seed_base + c % seed_mod.  A shard of a larger job passes its first global env
+        id as env_offset and the global env count as env_stride."""
+        B, K = self.B, int(record_capacity)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
+        bufs = dict(
+            ep_outcome=z((B, K), torch.uint8), ep_steps=z((B, K), torch.int32), ep_return=z((B, K), torch.float64),
+            ep_time=z((B, K), torch.float64), ep_danger=z((B, K), torch.int32),
+            ep_danger_dmin_sum=z((B, K), torch.float64),
+            ep_count=z((B,), torch.int32), cur_steps=z((B,), torch.int32), cur_return=z((B,), torch.float64),
+            cur_danger=z((B,), torch.int32), cur_danger_dmin_sum=z((B,), torch.float64),
+            active=z((B,), torch.uint8), transitions=z((1,), torch.int64))
+        io = CnRolloutIo(seed_base=int(seed_base), seed_mod=int(seed_mod), episode_limit=int(episode_limit),
+                         env_offset=int(env_offset), env_stride=int(B if env_stride is None else env_stride),
+                         record_capacity=K, **{k: v.data_ptr() for k, v in bufs.items()})
+        self._rollout = (io, bufs)
+        check(self._lib.cn_rollout_begin(self._h, C.byref(io)))
+        return bufs
+
+    def rollout(self, n_steps):
+        """n_steps transitions per active env in one kernel launch (in-kernel auto-reset)."""
+        if self._rollout is None:
+            raise RuntimeError('call rollout_begin() first')
+        check(self._lib.cn_rollout(self._h, C.byref(self._rollout[0]), int(n_steps)))
+        return self._rollout[1]
+
+    def mt_random(self, seed, n):
+        out = self._new((n,), torch.float64)
+        check(self._lib.cn_mt_random(self._h, int(seed), int(n), _ptr(out)))
+        return out

@@ -1,0 +1,168 @@
+/*
+ * crowdnav_amd.h — C ABI of libcrowdnav_amd.so, the MI355X (gfx950) batched crowd-navigation engine.
+ *
+ * The reference (vita-epfl/CrowdNav) has NO C ABI for this path: its boundary is the Python plugin API
+ *   crowd_sim/envs/crowd_sim.py:51-79,251-420   CrowdSim.configure / reset / step / onestep_lookahead
+ *   crowd_sim/envs/policy/orca.py:82-132        ORCA.predict  (-> rvo2.PyRVOSimulator, the only native code)
+ *   crowd_nav/utils/explorer.py:21-90           Explorer.run_k_episodes
+ * Each entry point below names the reference interface it replaces.  The Python host side
+ * (crowdnav_amd/) binds these with ctypes and mirrors the reference's classes on top; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (CN_OK) or a negative cn_status; cn_last_error() gives the message of the
+ *     last failure on the calling thread; nothing throws across the ABI.
+ *   - all data pointers are DEVICE pointers (hipMalloc'd, e.g. a torch tensor's data_ptr()) unless the
+ *     parameter name ends in _host.  The caller owns them and keeps them alive until the stream is synced.
+ *   - calls are asynchronous on the engine's stream (cn_set_stream; default = the null stream) unless
+ *     documented otherwise.  An engine is bound to one device and is not thread-safe.
+ *   - agent 0 of every env is the robot, agents 1..H are the humans; A = H + 1.
+ *   - batched state layout ("state8"): double [B][A][8] = px, py, vx, vy, gx, gy, radius, v_pref
+ *     (crowd_sim/envs/utils/state.py:1-50 minus theta, which is constant for the holonomic robot).
+ */
+#ifndef CROWDNAV_AMD_H
+#define CROWDNAV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cn_status {
+    CN_OK = 0,
+    CN_ERR_INVALID = -1,     /* bad argument / config            */
+    CN_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here (e.g. unicycle robot) */
+    CN_ERR_HIP = -3,         /* a HIP runtime call failed         */
+    CN_ERR_NO_DEVICE = -4    /* no gfx950 device visible          */
+} cn_status;
+
+/* info codes returned by step (crowd_sim/envs/utils/info.py:1-38) */
+enum { CN_NOTHING = 0, CN_DANGER = 1, CN_REACH_GOAL = 2, CN_COLLISION = 3, CN_TIMEOUT = 4 };
+/* robot_policy */
+enum { CN_ROBOT_EXTERNAL = 0, CN_ROBOT_ORCA = 1 };
+/* scenario_rule (crowd_sim.py:84-153) */
+enum { CN_CIRCLE_CROSSING = 0, CN_SQUARE_CROSSING = 1 };
+
+/* Everything CrowdSim.configure (crowd_sim.py:51-79), the [humans]/[robot] sections read by Agent.__init__
+ * (crowd_sim/envs/utils/agent.py:10-31) and the hard-coded ORCA parameters (orca.py:60-66) provide. */
+typedef struct cn_config {
+    int32_t num_envs;   /* B */
+    int32_t num_humans; /* H, 1..63 */
+    double time_step;
+    double time_limit;
+    double success_reward;
+    double collision_penalty;
+    double discomfort_dist;
+    double discomfort_penalty_factor;
+    int32_t robot_visible; /* humans' ORCA sees the robot (crowd_sim.py:326-327) */
+    int32_t robot_policy;  /* CN_ROBOT_EXTERNAL: caller supplies the action; CN_ROBOT_ORCA: solved on device */
+    double robot_safety_space;
+    double human_safety_space;
+    double neighbor_dist;  /* 10 */
+    int32_t max_neighbors; /* 10 (<= 10 supported) */
+    int32_t scenario_rule;
+    double time_horizon;      /* 5 */
+    double time_horizon_obst; /* 5, unused: the reference never adds obstacles */
+    double circle_radius;
+    double square_width;
+    double human_radius;
+    double human_v_pref;
+    double robot_radius;
+    double robot_v_pref;
+    int32_t randomize_attributes; /* agent.py:39-45 */
+    int32_t device;               /* HIP device ordinal */
+} cn_config;
+
+typedef struct cn_engine cn_engine;
+
+/* message of the last failed call on this thread ("" if none) */
+const char* cn_last_error(void);
+/* ABI version of this header (bumped on any signature change) */
+int cn_abi_version(void);
+
+/* replaces gym.make('CrowdSim-v0') + CrowdSim.configure + set_robot (crowd_sim.py:13-82): allocates the
+ * SoA state of B envs in HBM.  Synchronous. */
+int cn_create(const cn_config* cfg, cn_engine** out);
+int cn_destroy(cn_engine* e);
+/* hipStream_t the engine launches on (pass torch.cuda.current_stream().cuda_stream); NULL = null stream */
+int cn_set_stream(cn_engine* e, void* hip_stream);
+/* blocks until everything queued on the engine's stream is done */
+int cn_sync(cn_engine* e);
+
+/* teacher forcing / inspection: copy state8 [B][A][8] f64 and global_time [B] f64 (either may be NULL).
+ * replaces Agent.set / get_full_state (agent.py:47-108). */
+int cn_set_state(cn_engine* e, const double* state8, const double* global_time);
+int cn_get_state(cn_engine* e, double* state8, double* global_time);
+/* forget the robot ORCA policy's captured radii (a new policy object; orca.py:95-104) */
+int cn_drop_robot_sim(cn_engine* e);
+
+/* replaces CrowdSim.reset (crowd_sim.py:251-312) for the envs with mask[b] != 0 (mask NULL = all):
+ * np.random.seed(seeds[b]) + generate_random_human_position, numpy-MT19937-compatible, on device.
+ * draws (optional, uint64 [B]) receives the number of np.random.random() calls consumed. */
+int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t* draws);
+
+/* replaces Human.act/Robot.act -> ORCA.predict -> rvo2 doStep -> getAgentVelocity(0) for EVERY agent of
+ * every env from the current state (orca.py:82-132): out_vel float [B][A][2].  Agent 0 is solved with the
+ * robot's ORCA parameters whatever robot_policy is. */
+int cn_orca(cn_engine* e, float* out_vel);
+
+/* replaces CrowdSim.step(action, update) / onestep_lookahead (crowd_sim.py:314-420).
+ *   action      double [B][2] (ActionXY), NULL iff robot_policy == CN_ROBOT_ORCA
+ *   reward      double [B]; done uint8 [B]; info uint8 [B] (CN_*); dmin double [B] (+inf if no human checked)
+ *   action_out  double [B][2] action actually applied (optional)
+ *   orca_vel    float [B][A][2] velocity chosen by every agent (optional)
+ *   obs         double [B][H][5] humans' ObservableState px,py,vx,vy,radius AFTER the step (update=1) or
+ *               their next observable state (update=0, agent.py:63-74) (optional) */
+int cn_step(cn_engine* e, const double* action, int update, double* reward, uint8_t* done, uint8_t* info,
+            double* dmin, double* action_out, float* orca_vel, double* obs);
+
+/* Episode bookkeeping of Explorer.run_k_episodes (explorer.py:35-72), kept per env on device. */
+typedef struct cn_rollout_io {
+    /* episode numbering: local env b has global env id g = env_offset + b and runs the global episode ids
+     * c = g + j*env_stride (j = 0,1,..) while c < episode_limit; episode c is seeded
+     * np.random.seed(seed_base + c % seed_mod) (crowd_sim.py:272-283).  A single engine uses env_offset 0,
+     * env_stride B; rank r of W uses env_offset r*B, env_stride W*B, so the set of episodes and every
+     * trajectory is independent of how the env axis is sharded. */
+    uint32_t seed_base;
+    uint32_t seed_mod;
+    int64_t episode_limit; /* <0: unbounded */
+    int64_t env_offset;
+    int64_t env_stride;    /* >= env_offset + B */
+    int32_t record_capacity; /* records kept per env (ring; older ones are overwritten) */
+    /* per-episode records, [B][record_capacity]; all optional */
+    uint8_t* ep_outcome;   /* CN_REACH_GOAL / CN_COLLISION / CN_TIMEOUT */
+    int32_t* ep_steps;
+    double* ep_return;     /* sum_t gamma^(t*dt*v_pref) * r_t, python left-to-right order (explorer.py:71-72) */
+    double* ep_time;       /* env.global_time at the end (explorer.py:52-62) */
+    int32_t* ep_danger;    /* number of Danger steps (explorer.py:46-48) */
+    double* ep_danger_dmin_sum;
+    /* per-env counters, [B], in/out; the caller zeroes them before the first launch */
+    int32_t* ep_count;     /* episodes finished so far by env b */
+    int32_t* cur_steps;    /* steps into the running episode */
+    double* cur_return;
+    int32_t* cur_danger;
+    double* cur_danger_dmin_sum;
+    uint8_t* active;       /* 0 once env b ran out of episodes (c >= episode_limit) */
+    uint64_t* transitions; /* [1] device counter: += number of step() transitions executed */
+} cn_rollout_io;
+
+/* discount table used for ep_return: gamma^(t * time_step * robot_v_pref), computed on the host with libm
+ * pow exactly as explorer.py:71 does.  Synchronous. */
+int cn_set_gamma(cn_engine* e, double gamma);
+
+/* (re)start episode bookkeeping: every env b with b < episode_limit is reset to its episode j=0 scenario
+ * and the per-env counters of io are zeroed. */
+int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io);
+/* replaces the `while not done: action = robot.act(ob); env.step(action)` loop of
+ * Explorer.run_k_episodes (explorer.py:41-48) for an on-device robot policy (robot_policy ==
+ * CN_ROBOT_ORCA): n_steps transitions per active env in ONE launch, with in-kernel auto-reset. */
+int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
+
+/* numpy legacy RNG probe (np.random.seed(seed); n × np.random.random()): out double [n].  For tests. */
+int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROWDNAV_AMD_H */

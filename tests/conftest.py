@@ -1,0 +1,63 @@
+"""Test configuration.  `-m "not gpu"`: oracle vs golden fixtures, host logic, C-ABI surface (CPU only).
+`-m gpu`: parity of the HIP path (through the C ABI) against the oracle and the golden fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run on the GPU box with -m gpu)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+def episodes_of(g):
+    """Split a packed trajectory fixture (oracle/gen_golden.py: pack) into per-episode dicts."""
+    out, s0, a0 = [], 0, 0
+    for T in g['steps'].tolist():
+        out.append(dict(states=g['states'][s0:s0 + T + 1], actions=g['actions'][a0:a0 + T],
+                        rewards=g['rewards'][a0:a0 + T], dones=g['dones'][a0:a0 + T],
+                        infos=g['infos'][a0:a0 + T], dmins=g['dmins'][a0:a0 + T]))
+        s0 += T + 1
+        a0 += T
+    return out
+
+
+# fixture name -> engine/oracle config overrides used when it was generated (oracle/gen_golden.py: main)
+TRAJ_FIXTURES = {
+    'traj_invisible_h5.npz': dict(num_humans=5, robot_visible=0),
+    'traj_visible_h5.npz': dict(num_humans=5, robot_visible=1),
+    'traj_invisible_h5_random.npz': dict(num_humans=5, robot_visible=0, randomize_attributes=1),
+    'traj_visible_h5_square.npz': dict(num_humans=5, robot_visible=1, scenario_rule=1),
+    'traj_visible_h10.npz': dict(num_humans=10, robot_visible=1),
+    'traj_visible_h20.npz': dict(num_humans=20, robot_visible=1),
+    'traj_debug_case.npz': dict(num_humans=3, robot_visible=0),
+}
+
+
+def flat_steps(g):
+    """All (state_before, state_after, global_time_before) pairs of a packed fixture, flattened over episodes."""
+    before, after, gtime = [], [], []
+    for e in episodes_of(g):
+        T = len(e['actions'])
+        before.append(e['states'][:T])
+        after.append(e['states'][1:T + 1])
+        gtime.append(np.arange(T) * 0.25)
+    return np.concatenate(before), np.concatenate(after), np.concatenate(gtime)
+
+
+@pytest.fixture(scope='session')
+def oracle_mod():
+    import crowd_oracle
+    crowd_oracle.build()
+    return crowd_oracle

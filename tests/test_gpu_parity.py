@@ -1,0 +1,251 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated fixtures.
+Bar (BASELINE.json north_star): reward / done / info bit-exact, positions / velocities within 1e-5 — the
+ORCA velocities and the float64 env arithmetic are in fact required to be bit-identical here; only scenario
+generation (device cos/sin vs numpy's) is compared with a tolerance (1e-12)."""
+import numpy as np
+import pytest
+
+from conftest import TRAJ_FIXTURES, episodes_of, flat_steps, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need a MI355X'
+    import crowdnav_amd
+    return crowdnav_amd
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_mt19937_matches_numpy_stream(amd):
+    g = load_golden('resets.npz')
+    eng = amd.BatchedCrowdSim(num_envs=1)
+    for s in (0, 1000, 2000, 4294965295):
+        assert np.array_equal(_np(eng.mt_random(s, 700)), g['mt_random_%d' % s])
+
+
+@pytest.mark.parametrize('name', sorted(TRAJ_FIXTURES))
+def test_orca_velocities_bit_exact_vs_oracle(amd, oracle_mod, name):
+    """K1 alone, teacher-forced on every state of the fixture: all agents, robot included."""
+    g = load_golden(name)
+    before, _, gtime = flat_steps(g)
+    cfg = TRAJ_FIXTURES[name]
+    eng = amd.BatchedCrowdSim(num_envs=len(before), robot_policy=amd.ROBOT_ORCA, **cfg)
+    eng.set_state(before, gtime)
+    got = _np(eng.orca())
+    o = oracle_mod.CrowdOracle(num_envs=len(before), robot_policy=1, **cfg)
+    o.set_state(before, gtime)
+    want = o.orca()
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize('update', [True, False])
+@pytest.mark.parametrize('name', sorted(TRAJ_FIXTURES))
+def test_step_bit_exact_vs_golden_and_oracle(amd, oracle_mod, name, update):
+    g = load_golden(name)
+    before, after, gtime = flat_steps(g)
+    cfg = TRAJ_FIXTURES[name]
+    eng = amd.BatchedCrowdSim(num_envs=len(before), robot_policy=amd.ROBOT_ORCA, **cfg)
+    eng.set_state(before, gtime)
+    out = {k: (None if v is None else _np(v)) for k, v in eng.step(None, update=update).items()}
+    state, gt = (_np(x) for x in eng.get_state())
+    # vs the unmodified reference (fixtures)
+    assert np.array_equal(out['reward'], g['rewards'])
+    assert np.array_equal(out['done'], g['dones'])
+    assert np.array_equal(out['info'], g['infos'])
+    assert np.array_equal(out['action'], g['actions'])
+    danger = g['infos'] == 1
+    assert np.array_equal(out['dmin'][danger], g['dmins'][danger])
+    if update:
+        assert np.array_equal(state, after)
+        assert np.array_equal(gt, gtime + 0.25)
+        assert np.array_equal(out['obs'], after[:, 1:, [0, 1, 2, 3, 6]])
+    else:
+        assert np.array_equal(state, before) and np.array_equal(gt, gtime)
+        assert np.array_equal(out['obs'], after[:, 1:, [0, 1, 2, 3, 6]])  # next observable states
+    # vs the oracle, every field
+    o = oracle_mod.CrowdOracle(num_envs=len(before), robot_policy=1, **cfg)
+    o.set_state(before, gtime)
+    want = o.step(None, update=update)
+    assert np.array_equal(out['dmin'], want['dmin'])
+    assert np.array_equal(out['orca_vel'].view(np.uint32), want['orca_vel'].view(np.uint32))
+
+
+def test_external_action_step_vs_oracle(amd, oracle_mod):
+    """CN_ROBOT_EXTERNAL (the path an RL robot policy uses): float64 actions supplied by the caller."""
+    g = load_golden('traj_visible_h5.npz')
+    before, _, gtime = flat_steps(g)
+    n = len(before)
+    rng = np.random.RandomState(7)
+    action = rng.uniform(-1, 1, size=(n, 2))
+    action[::7] = 0.0
+    cfg = dict(num_humans=5, robot_visible=1)
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_EXTERNAL, **cfg)
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=0, **cfg)
+    for update in (False, True):
+        eng.set_state(before, gtime)
+        o.set_state(before, gtime)
+        got = {k: _np(v) for k, v in eng.step(action, update=update).items()}
+        want = o.step(action, update=update)
+        for k in ('reward', 'done', 'info', 'dmin', 'action'):
+            assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(got['orca_vel'][:, 1:].view(np.uint32), want['orca_vel'][:, 1:].view(np.uint32))
+        assert np.array_equal(_np(eng.get_state()[0]), o.get_state()[0])
+
+
+@pytest.mark.parametrize('name', ['traj_invisible_h5.npz', 'traj_visible_h5.npz', 'traj_visible_h5_square.npz',
+                                  'traj_visible_h10.npz', 'traj_visible_h20.npz', 'traj_debug_case.npz'])
+def test_free_running_trajectories_vs_reference(amd, name):
+    """Whole episodes from the fixture's initial states, no teacher forcing: step-for-step identical."""
+    g = load_golden(name)
+    eps = episodes_of(g)
+    B = len(eps)
+    T = max(len(e['actions']) for e in eps)
+    eng = amd.BatchedCrowdSim(num_envs=B, robot_policy=amd.ROBOT_ORCA, **TRAJ_FIXTURES[name])
+    eng.set_state(np.stack([e['states'][0] for e in eps]), np.zeros(B))
+    for t in range(T):
+        out = {k: _np(v) for k, v in eng.step(None, update=True, want_obs=False).items() if v is not None}
+        state = _np(eng.get_state()[0])
+        for b, e in enumerate(eps):
+            if t < len(e['actions']):
+                assert out['reward'][b] == e['rewards'][t] and out['done'][b] == e['dones'][t]
+                assert out['info'][b] == e['infos'][t]
+                assert np.abs(state[b] - e['states'][t + 1]).max() <= 1e-5
+                assert np.array_equal(state[b], e['states'][t + 1])
+
+
+RESET_SPECS = {
+    'test_h5': dict(num_humans=5), 'train_h5': dict(num_humans=5), 'val_h5': dict(num_humans=5),
+    'test_h5_random': dict(num_humans=5, randomize_attributes=1),
+    'test_h5_square': dict(num_humans=5, scenario_rule=1),
+    'test_h10': dict(num_humans=10), 'test_h20': dict(num_humans=20),
+}
+
+
+@pytest.mark.parametrize('name', sorted(RESET_SPECS))
+def test_reset_vs_reference_generator(amd, oracle_mod, name):
+    g = load_golden('resets.npz')
+    want, seeds = g[name + '_states'], g[name + '_seeds']
+    eng = amd.BatchedCrowdSim(num_envs=len(seeds), **RESET_SPECS[name])
+    draws = _np(eng.reset(seeds))
+    got, gt = (_np(x) for x in eng.get_state())
+    assert np.all(gt == 0.0)
+    assert np.abs(got - want).max() <= 1e-12
+    assert np.array_equal(got[:, :, 6:], want[:, :, 6:]) and np.array_equal(got[:, 0], want[:, 0])
+    o = oracle_mod.CrowdOracle(num_envs=len(seeds), **RESET_SPECS[name])
+    assert np.array_equal(draws.astype(np.uint64), o.reset(seeds))  # same number of rejection attempts
+
+
+def test_reset_mask_and_max_seed(amd):
+    eng = amd.BatchedCrowdSim(num_envs=4)
+    eng.reset([1000, 1001, 4294967295, 0])
+    s0 = _np(eng.get_state()[0]).copy()
+    eng.reset([5, 5, 5, 5], mask=[0, 1, 0, 1])
+    s1 = _np(eng.get_state()[0])
+    assert np.array_equal(s1[[0, 2]], s0[[0, 2]]) and np.array_equal(s1[1], s1[3])
+    assert not np.array_equal(s1[1], s0[1])
+
+
+def _records(bufs, k):
+    return {name: _np(bufs[name])[:, :k] for name in ('ep_outcome', 'ep_steps', 'ep_return', 'ep_time',
+                                                     'ep_danger', 'ep_danger_dmin_sum')}
+
+
+@pytest.mark.parametrize('visible', [0, 1])
+def test_rollout_500_test_cases_vs_reference(amd, visible):
+    """Explorer.run_k_episodes(500, 'test') in one fused launch: per-case outcome, length, nav time and
+    discounted return vs the unmodified reference (outcomes_500.npz); aggregate 213/284/3, 15 190 steps."""
+    g = load_golden('outcomes_500.npz')
+    tag = 'visible' if visible else 'invisible'
+    eng = amd.BatchedCrowdSim(num_envs=500, robot_policy=amd.ROBOT_ORCA, robot_visible=visible)
+    bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=500, record_capacity=2)
+    eng.rollout(100)
+    eng.sync()
+    rec = _records(bufs, 1)
+    assert np.all(_np(bufs['ep_count']) == 1) and np.all(_np(bufs['active']) == 0)
+    assert int(_np(bufs['transitions'])[0]) == int(g[tag + '_steps'].sum())
+    assert np.array_equal(rec['ep_outcome'][:, 0], g[tag + '_info'])
+    assert np.array_equal(rec['ep_steps'][:, 0], g[tag + '_steps'])
+    assert np.allclose(rec['ep_return'][:, 0], g[tag + '_return'], rtol=0, atol=1e-9)
+    timeout = g[tag + '_info'] == 4
+    assert np.array_equal(rec['ep_time'][:, 0], np.where(timeout, 25.0, g[tag + '_steps'] * 0.25))
+
+
+def test_rollout_vs_oracle_with_auto_reset(amd, oracle_mod):
+    """64 envs x 150 transitions with in-kernel auto-reset, chunked launches, vs the oracle's rollout."""
+    B, K = 64, 16
+    eng = amd.BatchedCrowdSim(num_envs=B, robot_policy=amd.ROBOT_ORCA, robot_visible=1)
+    bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=-1, record_capacity=K)
+    for n in (1, 49, 100):
+        eng.rollout(n)
+    eng.sync()
+    o = oracle_mod.CrowdOracle(num_envs=B, robot_policy=1, robot_visible=1)
+    o.reset(1000 + np.arange(B))
+    ep_index, cur_steps, cur_ret = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.float64)
+    total, rec = o.rollout(150, 1000, 500, K, ep_index, cur_steps, cur_ret)
+    assert int(_np(bufs['transitions'])[0]) == total == B * 150
+    cnt = _np(bufs['ep_count'])
+    assert np.array_equal(cnt, rec['count'])
+    got = _records(bufs, K)
+    for b in range(B):
+        k = cnt[b]
+        assert np.array_equal(got['ep_outcome'][b, :k], rec['outcome'][b, :k])
+        assert np.array_equal(got['ep_steps'][b, :k], rec['steps'][b, :k])
+        assert np.allclose(got['ep_return'][b, :k], rec['ret'][b, :k], rtol=0, atol=1e-9)
+    assert np.array_equal(_np(bufs['cur_steps']), cur_steps)
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+
+
+def test_full_size_properties_4096x5(amd):
+    """BASELINE config 2 size: determinism, sharding invariance and physical invariants."""
+    B = 4096
+    cfg = dict(robot_policy=amd.ROBOT_ORCA, robot_visible=1)
+
+    def run(num_envs, offset):
+        eng = amd.BatchedCrowdSim(num_envs=num_envs, **cfg)
+        bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, record_capacity=8,
+                                 env_offset=offset, env_stride=B)
+        eng.rollout(64)
+        eng.sync()
+        return _np(eng.get_state()[0]), {k: _np(v) for k, v in bufs.items()}
+
+    s_full, b_full = run(B, 0)
+    s_again, b_again = run(B, 0)
+    assert np.array_equal(s_full, s_again)  # bitwise deterministic
+    for k in b_full:
+        assert np.array_equal(b_full[k], b_again[k]), k
+    s_lo, b_lo = run(B // 2, 0)
+    s_hi, b_hi = run(B // 2, B // 2)
+    assert np.array_equal(np.concatenate([s_lo, s_hi]), s_full)  # sharding the env axis changes nothing
+    for k in ('ep_count', 'ep_steps', 'ep_return', 'ep_outcome'):
+        assert np.array_equal(np.concatenate([b_lo[k], b_hi[k]]), b_full[k]), k
+    assert int(b_full['transitions'][0]) == B * 64
+    speed = np.hypot(s_full[:, :, 2], s_full[:, :, 3])
+    assert speed.max() <= 1.0 + 1e-4  # |v| <= maxSpeed (v_pref = 1)
+    assert np.all(np.isfinite(s_full))
+    done_eps = b_full['ep_count'].sum()
+    assert done_eps > B  # auto-reset happened
+    k = np.minimum(b_full['ep_count'], 8)
+    outcomes = np.concatenate([b_full['ep_outcome'][b, :k[b]] for b in range(B)])
+    assert set(np.unique(outcomes).tolist()) <= {2, 3, 4}
+
+
+def test_lone_agent_and_head_on_symmetry(amd):
+    """RVO2 known answers: a lone agent takes its (clipped) preferred velocity; the
+    hand-derived 2-agent case gives (0.138, 0)."""
+    eng = amd.BatchedCrowdSim(num_envs=2, num_humans=1, robot_policy=amd.ROBOT_ORCA, robot_visible=0)
+    st = np.zeros((2, 2, 8))
+    st[:, :, 6], st[:, :, 7] = 0.3, 1.0
+    st[0, 0, :2], st[0, 0, 4:6] = (50, 50), (53, 54)       # robot far away: goal offset (3, 4)
+    st[0, 1, :2], st[0, 1, 4:6] = (0, 0), (3, 4)           # lone human (robot invisible)
+    st[1, 0, :2], st[1, 0, 4:6] = (0, 0), (10, 0)          # robot at origin heading +x ...
+    st[1, 1, :2], st[1, 1, 4:6] = (2, 0), (2, 0)           # ... human 2 m ahead, at rest
+    eng.set_state(st, np.zeros(2))
+    v = _np(eng.orca())
+    assert v[0, 1].tolist() == [np.float32(0.6000000238418579), np.float32(0.800000011920929)]
+    assert v[1, 0].view(np.uint32).tolist() == [0x3e0d4fdf, 0]

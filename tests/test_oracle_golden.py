@@ -1,0 +1,103 @@
+"""The CPU oracle (oracle/crowd_oracle.cpp, a batched restatement of the reference hot path) against the
+fixtures that the UNMODIFIED reference Python produced (oracle/gen_golden.py).  This is what pins the oracle;
+the GPU parity tests then compare the HIP path with the oracle and with the same fixtures."""
+import numpy as np
+import pytest
+
+from conftest import TRAJ_FIXTURES, episodes_of, flat_steps, load_golden
+
+
+@pytest.mark.parametrize('name', sorted(TRAJ_FIXTURES))
+def test_teacher_forced_steps_bit_exact(oracle_mod, name):
+    g = load_golden(name)
+    before, after, gtime = flat_steps(g)
+    n = len(before)
+    # a fresh policy object per case in the random-attribute fixture, and fresh human policies per reset:
+    # a fresh oracle (no captured radii) per teacher-forced batch reproduces that for every step
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=1, **TRAJ_FIXTURES[name])
+    o.set_state(before, gtime)
+    out = o.step(None, update=True)
+    state, gt = o.get_state()
+    assert np.array_equal(out['reward'], g['rewards'])
+    assert np.array_equal(out['done'], g['dones'])
+    assert np.array_equal(out['info'], g['infos'])
+    assert np.array_equal(out['action'], g['actions'])
+    danger = g['infos'] == 1
+    assert np.array_equal(out['dmin'][danger], g['dmins'][danger])
+    assert np.array_equal(state, after)
+    assert np.array_equal(gt, gtime + 0.25)
+
+
+@pytest.mark.parametrize('name', ['traj_invisible_h5.npz', 'traj_visible_h5.npz', 'traj_visible_h20.npz'])
+def test_free_running_episodes_bit_exact(oracle_mod, name):
+    g = load_golden(name)
+    for e in episodes_of(g):
+        o = oracle_mod.CrowdOracle(num_envs=1, robot_policy=1, **TRAJ_FIXTURES[name])
+        o.set_state(e['states'][:1], np.zeros(1))
+        for t in range(len(e['actions'])):
+            out = o.step(None, update=True)
+            assert out['reward'][0] == e['rewards'][t] and out['done'][0] == e['dones'][t]
+            assert out['info'][0] == e['infos'][t]
+            assert np.array_equal(o.get_state()[0][0], e['states'][t + 1])
+        assert out['done'][0] == 1
+
+
+def test_lookahead_does_not_mutate(oracle_mod):
+    g = load_golden('traj_visible_h5.npz')
+    before, _, gtime = flat_steps(g)
+    o = oracle_mod.CrowdOracle(num_envs=len(before), robot_policy=1, num_humans=5, robot_visible=1)
+    o.set_state(before, gtime)
+    out = o.step(None, update=False)
+    state, gt = o.get_state()
+    assert np.array_equal(state, before) and np.array_equal(gt, gtime)
+    assert np.array_equal(out['reward'], g['rewards'])
+
+
+def test_mt19937_matches_numpy_stream(oracle_mod):
+    g = load_golden('resets.npz')
+    for s in (0, 1000, 2000, 4294965295):
+        assert np.array_equal(oracle_mod.mt_random(s, 700), g['mt_random_%d' % s])
+
+
+RESET_SPECS = {
+    'test_h5': dict(num_humans=5), 'train_h5': dict(num_humans=5), 'val_h5': dict(num_humans=5),
+    'test_h5_random': dict(num_humans=5, randomize_attributes=1),
+    'test_h5_square': dict(num_humans=5, scenario_rule=1),
+    'test_h10': dict(num_humans=10), 'test_h20': dict(num_humans=20),
+}
+
+
+@pytest.mark.parametrize('name', sorted(RESET_SPECS))
+def test_reset_matches_reference_generator(oracle_mod, name):
+    """Scenario generation vs the reference's own generator (numpy cos/sin vs libm: <= 1e-12)."""
+    g = load_golden('resets.npz')
+    want, seeds = g[name + '_states'], g[name + '_seeds']
+    o = oracle_mod.CrowdOracle(num_envs=len(seeds), **RESET_SPECS[name])
+    o.reset(seeds)
+    got, gt = o.get_state()
+    assert np.all(gt == 0.0)
+    assert np.abs(got - want).max() <= 1e-12
+    # attributes and the robot row involve no trigonometry: exact
+    assert np.array_equal(got[:, :, 6:], want[:, :, 6:]) and np.array_equal(got[:, 0], want[:, 0])
+
+
+def test_rollout_reproduces_500_case_anchor(oracle_mod):
+    """Explorer bookkeeping over the 500 test cases: 213 ReachGoal / 284 Collision / 3 Timeout, 15 190 steps
+    (SURVEY.md Appendix D), per-case outcome, length and discounted return."""
+    g = load_golden('outcomes_500.npz')
+    for tag, vis in (('invisible', 0), ('visible', 1)):
+        B = 500
+        o = oracle_mod.CrowdOracle(num_envs=B, robot_policy=1, robot_visible=vis)
+        o.reset(1000 + np.arange(B))
+        ep_index = np.zeros(B, np.int32)
+        cur_steps = np.zeros(B, np.int32)
+        cur_ret = np.zeros(B, np.float64)
+        _, rec = o.rollout(100, 1000, 500, 4, ep_index, cur_steps, cur_ret)
+        assert np.all(rec['count'] >= 1)
+        assert np.array_equal(rec['outcome'][:, 0], g[tag + '_info'])
+        assert np.array_equal(rec['steps'][:, 0], g[tag + '_steps'])
+        assert np.allclose(rec['ret'][:, 0], g[tag + '_return'], rtol=0, atol=1e-12)
+    assert np.bincount(g['invisible_info'], minlength=5).tolist() == [0, 0, 213, 284, 3]
+    assert int(g['invisible_steps'].sum()) == 15190
+    assert np.bincount(g['visible_info'], minlength=5).tolist() == [0, 0, 500, 0, 0]
+    assert int(g['visible_steps'].sum()) == 20037
