@@ -229,7 +229,7 @@ def test_full_size_properties_4096x5(amd):
     assert speed.max() <= 1.0 + 1e-4  # |v| <= maxSpeed (v_pref = 1)
     assert np.all(np.isfinite(s_full))
     done_eps = b_full['ep_count'].sum()
-    assert done_eps > B  # auto-reset happened
+    assert done_eps > B // 2  # auto-reset happened (visible-robot episodes last ~40 steps)
     k = np.minimum(b_full['ep_count'], 8)
     outcomes = np.concatenate([b_full['ep_outcome'][b, :k[b]] for b in range(B)])
     assert set(np.unique(outcomes).tolist()) <= {2, 3, 4}
