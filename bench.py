@@ -64,11 +64,11 @@ def cpu_baseline(envs, humans, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=4000)
+    ap.add_argument('--warmup', type=int, default=400)
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--humans', type=int, default=5)
-    ap.add_argument('--chunk', type=int, default=100, help='steps fused into one kernel launch')
+    ap.add_argument('--chunk', type=int, default=200, help='steps fused into one kernel launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -114,22 +114,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def shard_boundary():
+        """per-rank episode summary (finished episodes, sum/count of recorded returns) -> every rank (RCCL)"""
+        cnt = bufs['ep_count'].sum().to(torch.float64)
+        k = torch.clamp(bufs['ep_count'], max=bufs['ep_return'].shape[1])
+        mask = torch.arange(bufs['ep_return'].shape[1], device=k.device)[None, :] < k[:, None]
+        summary = torch.stack([cnt, (bufs['ep_return'] * mask).sum(), mask.sum().to(torch.float64)])
+        if world > 1:
+            gathered = [torch.empty_like(summary) for _ in range(world)]
+            dist.all_gather(gathered, summary)
+            summary = torch.stack(gathered).sum(0)
+        return summary
+
     run(args.warmup)
+    shard_boundary()  # warm-up of the torch / RCCL side too (lazy code-object loads, communicator setup)
     fence()
     before = int(bufs['transitions'].item())
     events = []
     fence()
     t0 = time.perf_counter()
     run(args.steps, events)
-    # shard boundary: per-rank episode summary (finished episodes, their mean discounted return) to all ranks
-    cnt = bufs['ep_count'].sum().to(torch.float64)
-    k = torch.clamp(bufs['ep_count'], max=bufs['ep_return'].shape[1])
-    mask = torch.arange(bufs['ep_return'].shape[1], device=k.device)[None, :] < k[:, None]
-    summary = torch.stack([cnt, (bufs['ep_return'] * mask).sum(), mask.sum().to(torch.float64)])
-    if world > 1:
-        gathered = [torch.empty_like(summary) for _ in range(world)]
-        dist.all_gather(gathered, summary)
-        summary = torch.stack(gathered).sum(0)
+    summary = shard_boundary()
     fence()
     elapsed = time.perf_counter() - t0
 

@@ -60,8 +60,8 @@ struct ScenarioCfg {
     double human_radius, human_v_pref, robot_radius, robot_v_pref;
 };
 
-// Writes agents [0, A) of one env into the SoA state (double2 planes indexed env*A + agent) and returns the
-// number of np.random.random() calls consumed.
+// Writes agents [0, A) of one env into the SoA state (double2 planes indexed base + agent; vel may be NULL:
+// every agent starts at rest) and returns the number of np.random.random() calls consumed.
 __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng, uint32_t seed, size_t base,
                                              double2* pos, double2* vel, double2* goal, double2* rv) {
     const double kPi = 3.141592653589793;
@@ -71,7 +71,7 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
     const double R = c.circle_radius;
     pos[base] = make_double2(0.0, -R);
     goal[base] = make_double2(0.0, R);
-    vel[base] = make_double2(0.0, 0.0);
+    if (vel) vel[base] = make_double2(0.0, 0.0);
     rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
     for (int i = 1; i < A; ++i) {
         double radius = c.human_radius, v_pref = c.human_v_pref;
@@ -137,7 +137,7 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
         }
         pos[base + i] = make_double2(x, y);
         goal[base + i] = make_double2(tx, ty);
-        vel[base + i] = make_double2(0.0, 0.0);
+        if (vel) vel[base + i] = make_double2(0.0, 0.0);
         rv[base + i] = make_double2(radius, v_pref);
     }
     return draws;

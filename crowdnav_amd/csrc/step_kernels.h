@@ -1,0 +1,612 @@
+// Device side of libcrowdnav_amd.so: the batched CrowdSim transition as a wave-level pipeline.
+//
+// One workgroup = one wave64 = E whole envs (E * A <= 64 agents).  A transition runs in phases that each
+// use the lanes differently (all separated by workgroup barriers, all data exchanged through LDS):
+//   stage      lane = agent            float32 view of the agents as rvo2 is told them (orca.py:100-110)
+//   pairs-1    lane = (agent, cand.)   squared distance of every ordered pair            (Appendix A.2)
+//   pairs-2    lane = (agent, cand.)   stable rank among the agent's candidates -> neighbour slot; the
+//                                      ORCA half-plane of that pair -> LDS float4 slot   (Appendix A.3)
+//   solve      lane = agent            half-planes -> VGPRs, unrolled 2-D program, rare 3-D fallback
+//   collide    lane = human            float64 swept robot-human distance (crowd_sim.py:331-351)
+//   reduce     lane = robot            reward / done / info (crowd_sim.py:364-389)
+//   integrate  lane = agent            Agent.step (agent.py:127-135)
+// The chip is latency-bound on this path (4096 envs x 6 agents = 24.6 k agents on 1024 SIMDs), so E is kept
+// small (2 envs per wave at 4096 envs): more waves, fewer serial passes, less divergence per wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits>
+
+#include "../../include/crowdnav_amd.h"
+#include "orca_device.h"
+#include "scenario_device.h"
+
+namespace cn {
+
+struct Params {
+    int B, A;          // envs, agents per env
+    int E;             // envs per wave
+    int nA;            // E * A agent lanes
+    int NC;            // A - 1 candidate neighbours per agent
+    int pairs;         // nA * NC
+    int ring_depth;    // scenarios kept ahead per env
+    int robot_visible, robot_orca;
+    double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
+    double robot_safety, human_safety;
+    OrcaParams orca;
+    ScenarioCfg scen;
+};
+
+struct StateView {
+    double2* pos;
+    double2* vel;
+    double2* goal;
+    double2* rv;  // (radius, v_pref)
+    double* gtime;
+    float* rsim_radius;     // [B*A] radii captured by the robot's persistent ORCA policy (orca.py:98-104)
+    float* rsim_max_speed;  // [B]
+    uint8_t* rsim_valid;    // [B]
+    uint32_t* mt_key;       // [624][B]   generator state of the env's own stream
+    int* mt_pos;            // [B]
+    // scenario ring: the next ring_depth episodes of every env, generated ahead of the rollout
+    double2* ring_pos;      // [B][D][A]
+    double2* ring_goal;
+    double2* ring_rv;
+    uint32_t* ring_mt_key;  // [624][B*D] generator scratch of the fill kernel
+    int* ring_filled_in;    // [B] episode ordinals < this have been generated (read side)
+    int* ring_filled_out;   // [B] (written by the fill kernel; the host swaps the two)
+};
+
+struct StepIo {
+    const double* action;
+    double* reward;
+    uint8_t* done;
+    uint8_t* info;
+    double* dmin;
+    double* action_out;
+    float* orca_vel;
+    double* obs;
+    int update;
+};
+
+// ---------------------------------------------------------------------------------------------- LDS carve-up
+struct Smem {
+    float4* kin;      // [nA] float32(px, py, vx, vy)
+    double2* posd;    // [nA] float64 position
+    double2* act;     // [nA] (robot lanes) applied robot action
+    float4* lines;    // [nA][kLineStride] ORCA half-planes, slot = neighbour rank
+    float4* proj;     // [nA][kLineStride] projected half-planes (3-D fallback scratch)
+    double* rad;      // [nA] float64 radius
+    double* closest;  // [nA] (human lanes) closest boundary distance during the step
+    float* hview;     // [nA] radius as a human's rvo2 sim holds it: float32(radius + 0.01 + human_safety)
+    float* rview;     // [nA] radius as the robot's rvo2 sim holds it (captured, see load_robot_view)
+    float* d2;        // [pairs] squared distance agent -> candidate (+inf if the pair does not exist)
+    int* pinfo;       // [pairs] packed pair descriptor
+    int* count;       // [nA] neighbours kept
+    int* flag;        // [nA] (robot lanes) per-env flag broadcast
+};
+
+__host__ __device__ inline size_t smem_bytes(int nA, int pairs) {
+    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64;
+}
+
+__device__ __forceinline__ Smem carve(const Params& P) {
+    extern __shared__ double2 smem_raw[];
+    Smem s;
+    char* p = reinterpret_cast<char*>(smem_raw);
+    const int nA = P.nA;
+    s.kin = reinterpret_cast<float4*>(p), p += 16 * nA;
+    s.posd = reinterpret_cast<double2*>(p), p += 16 * nA;
+    s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
+    s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.proj = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.rad = reinterpret_cast<double*>(p), p += 8 * nA;
+    s.closest = reinterpret_cast<double*>(p), p += 8 * nA;
+    s.hview = reinterpret_cast<float*>(p), p += 4 * nA;
+    s.rview = reinterpret_cast<float*>(p), p += 4 * nA;
+    s.count = reinterpret_cast<int*>(p), p += 4 * nA;
+    s.flag = reinterpret_cast<int*>(p), p += 4 * nA;
+    s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
+    s.pinfo = reinterpret_cast<int*>(p);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------- lanes
+struct Lane {
+    int lane, env, a, ebase;  // ebase = lane of this env's robot
+    bool valid;               // this lane owns an agent of an existing env
+    size_t gi;                // env * A + a
+};
+
+__device__ __forceinline__ Lane lane_of(const Params& P) {
+    Lane L;
+    L.lane = threadIdx.x;
+    const int el = L.lane / P.A;
+    L.a = L.lane - el * P.A;
+    L.env = blockIdx.x * P.E + el;
+    L.valid = (L.lane < P.nA) && (L.env < P.B);
+    L.ebase = el * P.A;
+    L.gi = (size_t)L.env * P.A + L.a;
+    return L;
+}
+
+struct AgentRegs {
+    double px, py, vx, vy, gx, gy, rad, vpref;
+};
+
+__device__ __forceinline__ void load_agent(const StateView& S, size_t gi, AgentRegs& r) {
+    const double2 p = S.pos[gi], v = S.vel[gi], g = S.goal[gi], q = S.rv[gi];
+    r.px = p.x, r.py = p.y, r.vx = v.x, r.vy = v.y, r.gx = g.x, r.gy = g.y, r.rad = q.x, r.vpref = q.y;
+}
+
+// Pair descriptors (agent lane q, candidate slot c): built once per launch.  Candidate order = the order
+// ORCA.predict adds the others to its rvo2 sim: the other humans by index, then the robot if it is visible
+// (crowd_sim.py:325-327, orca.py:102-104); the robot's own sim holds every human.
+//   bits 0-7 agent lane, 8-15 lane of the candidate, 16-23 candidate slot, 24 pair exists, 25 agent is a robot
+__device__ __forceinline__ void build_pairs(const Params& P, const Smem& s) {
+    for (int p = threadIdx.x; p < P.pairs; p += kWave) {
+        const int q = p / P.NC;
+        const int c = p - q * P.NC;
+        const int el = q / P.A;
+        const int a = q - el * P.A;
+        int j;
+        bool exists = ((int)blockIdx.x * P.E + el) < P.B;
+        if (a == 0) {
+            j = c + 1;
+        } else {
+            j = c + 1 + (c + 1 >= a ? 1 : 0);
+            if (j >= P.A) {
+                j = 0;
+                exists = exists && P.robot_visible;
+            }
+        }
+        s.pinfo[p] = q | ((el * P.A + j) << 8) | (c << 16) | (exists ? 1 << 24 : 0) | (a == 0 ? 1 << 25 : 0);
+    }
+}
+
+// The robot's ORCA policy object outlives episodes and keeps the radii / max speed it saw when its rvo2
+// simulator was first built (orca.py:95-104).  Load or capture them.
+__device__ __forceinline__ void load_robot_view(const Params& P, const StateView& S, const Smem& s,
+                                                const Lane& L, const AgentRegs& r, float& robot_max_speed) {
+    robot_max_speed = 0.0f;
+    if (!L.valid) return;
+    const bool have = S.rsim_valid[L.env] != 0;
+    float rr;
+    if (have) {
+        rr = S.rsim_radius[L.gi];
+    } else {
+        rr = (float)(r.rad + 0.01 + P.robot_safety);
+        S.rsim_radius[L.gi] = rr;
+    }
+    s.rview[L.lane] = rr;
+    if (L.a == 0) {
+        if (have) {
+            robot_max_speed = S.rsim_max_speed[L.env];
+        } else {
+            robot_max_speed = (float)r.vpref;
+            S.rsim_max_speed[L.env] = robot_max_speed;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- ORCA phases
+// Stage + pair phases + per-agent solve.  Called by all 64 lanes (contains barriers); on return every valid
+// agent lane with solve == true holds its new velocity (ORCA.predict, orca.py:82-132).
+template <int MAXL>
+__device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
+                                            float robot_max_speed, bool solve, float& out_vx, float& out_vy) {
+    if (L.lane < P.nA) {
+        s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
+        s.posd[L.lane] = make_double2(r.px, r.py);
+        s.rad[L.lane] = r.rad;
+        s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
+    }
+    __syncthreads();
+
+    // pairs-1: squared distances, self.pos - other.pos (Appendix A.2)
+    for (int p = L.lane; p < P.pairs; p += kWave) {
+        const int info = s.pinfo[p];
+        const float4 me = s.kin[info & 0xff];
+        const float4 ot = s.kin[(info >> 8) & 0xff];
+        const float dx = me.x - ot.x, dy = me.y - ot.y;
+        s.d2[p] = ((info >> 24) & 1) ? dx * dx + dy * dy : std::numeric_limits<float>::infinity();
+    }
+    __syncthreads();
+
+    // pairs-2: neighbour slot = stable rank by (distSq, visit order) among the in-range candidates, which
+    // is what RVO2's sorted insertion with strict '<' produces; slots >= maxNeighbors fall off the list.
+    const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
+    for (int p = L.lane; p < P.pairs; p += kWave) {
+        const int info = s.pinfo[p];
+        const int q = info & 0xff, c = (info >> 16) & 0xff;
+        const float mine = s.d2[p];
+        const float* row = s.d2 + (p - c);
+        int rank = 0, within = 0;
+        for (int k = 0; k < P.NC; ++k) {
+            const float v = row[k];
+            const bool in = v < range_sq;
+            within += in ? 1 : 0;
+            rank += (in && (v < mine || (v == mine && k < c))) ? 1 : 0;
+        }
+        if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
+        if (mine < range_sq && rank < P.orca.max_neighbors) {
+            const int ol = (info >> 8) & 0xff;
+            const float4 me = s.kin[q];
+            const float4 ot = s.kin[ol];
+            const bool robot_sim = (info >> 25) & 1;
+            const float rsum = robot_sim ? s.rview[q] + s.rview[ol] : s.hview[q] + s.hview[ol];
+            s.lines[q * kLineStride + rank] =
+                make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
+        }
+    }
+    __syncthreads();
+
+    out_vx = 0.0f, out_vy = 0.0f;
+    if (solve) {
+        const int n = s.count[L.lane];
+        const float4* mine = s.lines + L.lane * kLineStride;
+        float4 Lr[MAXL];
+#pragma unroll
+        for (int k = 0; k < MAXL; ++k) Lr[k] = (k < n) ? mine[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
+        const double gdx = r.gx - r.px, gdy = r.gy - r.py;
+        const double speed = norm2(gdx, gdy);
+        const float pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
+        const float pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
+        const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
+        float rx, ry;
+        const int fail = lp_planar_reg<MAXL>(Lr, n, max_speed, pref_x, pref_y, rx, ry);
+        if (fail < n) lp_relaxed_lds(mine, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
+        out_vx = rx, out_vy = ry;
+    }
+}
+
+// crowd_sim/envs/utils/utils.py:4-26 with (x3, y3) = (0, 0)
+__device__ __forceinline__ double point_to_segment_origin(double x1, double y1, double x2, double y2) {
+    const double sx = x2 - x1, sy = y2 - y1;
+    if (sx == 0.0 && sy == 0.0) return norm2(0.0 - x1, 0.0 - y1);
+    double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
+    if (u > 1.0) {
+        u = 1.0;
+    } else if (u < 0.0) {
+        u = 0.0;
+    }
+    const double x = x1 + u * sx, y = y1 + u * sy;
+    return norm2(x - 0.0, y - 0.0);
+}
+
+struct StepResult {  // meaningful on the robot lane
+    double reward, dmin, ax, ay;
+    uint8_t done, info;
+};
+
+// One transition for the lane's agent (crowd_sim.py:317-420).  `r` is updated in place when update != 0.
+// new_vx/new_vy: the velocity this lane's agent chose (float32 for ORCA agents, the action for the robot).
+// Must be called by all 64 lanes (contains workgroup barriers).
+template <int MAXL>
+__device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
+                                          double& gtime, float robot_max_speed, const double* ext_action,
+                                          int update, StepResult& res, double& new_vx, double& new_vy) {
+    float ovx, ovy;
+    orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy);
+    new_vx = ovx;
+    new_vy = ovy;
+    if (L.valid && L.a == 0) {
+        if (!P.robot_orca) {
+            new_vx = ext_action[2 * (size_t)L.env];
+            new_vy = ext_action[2 * (size_t)L.env + 1];
+        }
+        s.act[L.lane] = make_double2(new_vx, new_vy);
+    }
+    __syncthreads();
+
+    // swept robot-human collision over the step: human's CURRENT velocity vs the robot's NEW action
+    // (crowd_sim.py:331-351)
+    if (L.valid && L.a > 0) {
+        const double2 rp = s.posd[L.ebase];
+        const double2 act = s.act[L.ebase];
+        const double rx = r.px - rp.x, ry = r.py - rp.y;
+        const double wx = r.vx - act.x, wy = r.vy - act.y;
+        const double ex = rx + wx * P.dt, ey = ry + wy * P.dt;
+        s.closest[L.lane] = point_to_segment_origin(rx, ry, ex, ey) - r.rad - s.rad[L.ebase];
+    }
+    __syncthreads();
+
+    res.done = 0;
+    if (L.valid && L.a == 0) {
+        double dmin = std::numeric_limits<double>::infinity();
+        bool collision = false;
+        for (int i = 1; i < P.A; ++i) {  // the reference stops at the first colliding human; dmin is unused then
+            const double c = s.closest[L.lane + i];
+            if (c < 0.0) {
+                collision = true;
+                break;
+            } else if (c < dmin) {
+                dmin = c;
+            }
+        }
+        const double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+        const bool reaching = norm2(endx - r.gx, endy - r.gy) < r.rad;
+        if (gtime >= P.time_limit - 1.0) {
+            res.reward = 0.0, res.done = 1, res.info = CN_TIMEOUT;
+        } else if (collision) {
+            res.reward = P.collision_penalty, res.done = 1, res.info = CN_COLLISION;
+        } else if (reaching) {
+            res.reward = P.success_reward, res.done = 1, res.info = CN_REACH_GOAL;
+        } else if (dmin < P.discomfort_dist) {
+            res.reward = (dmin - P.discomfort_dist) * P.discomfort_factor * P.dt;
+            res.done = 0, res.info = CN_DANGER;
+        } else {
+            res.reward = 0.0, res.done = 0, res.info = CN_NOTHING;
+        }
+        res.dmin = dmin;
+        res.ax = new_vx, res.ay = new_vy;
+        if (update) gtime += P.dt;
+    }
+    if (update && L.valid) {  // Agent.step (agent.py:127-135)
+        r.px = r.px + new_vx * P.dt;
+        r.py = r.py + new_vy * P.dt;
+        r.vx = new_vx;
+        r.vy = new_vy;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- kernels
+
+template <int MAXL>
+__global__ __launch_bounds__(kWave) void orca_kernel(Params P, StateView S, float* out_vel) {
+    const Smem s = carve(P);
+    const Lane L = lane_of(P);
+    AgentRegs r = {};
+    if (L.valid) load_agent(S, L.gi, r);
+    float robot_max_speed;
+    load_robot_view(P, S, s, L, r, robot_max_speed);
+    build_pairs(P, s);
+    float vx, vy;
+    orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid, vx, vy);
+    if (L.valid) {
+        out_vel[2 * L.gi] = vx;
+        out_vel[2 * L.gi + 1] = vy;
+        if (L.a == 0) S.rsim_valid[L.env] = 1;
+    }
+}
+
+template <int MAXL>
+__global__ __launch_bounds__(kWave) void step_kernel(Params P, StateView S, StepIo io) {
+    const Smem s = carve(P);
+    const Lane L = lane_of(P);
+    AgentRegs r = {};
+    if (L.valid) load_agent(S, L.gi, r);
+    float robot_max_speed = 0.0f;
+    if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
+    build_pairs(P, s);
+    double gtime = (L.valid && L.a == 0) ? S.gtime[L.env] : 0.0;
+    const AgentRegs before = r;
+
+    StepResult res;
+    double nvx, nvy;
+    step_core<MAXL>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy);
+    if (!L.valid) return;
+
+    if (L.a == 0) {
+        io.reward[L.env] = res.reward;
+        io.done[L.env] = res.done;
+        io.info[L.env] = res.info;
+        if (io.dmin) io.dmin[L.env] = res.dmin;
+        if (io.action_out) {
+            io.action_out[2 * (size_t)L.env] = res.ax;
+            io.action_out[2 * (size_t)L.env + 1] = res.ay;
+        }
+        if (io.update) S.gtime[L.env] = gtime;
+        if (P.robot_orca) S.rsim_valid[L.env] = 1;
+    }
+    if (io.orca_vel) {
+        io.orca_vel[2 * L.gi] = (float)nvx;
+        io.orca_vel[2 * L.gi + 1] = (float)nvy;
+    }
+    if (io.update) {
+        S.pos[L.gi] = make_double2(r.px, r.py);
+        S.vel[L.gi] = make_double2(r.vx, r.vy);
+    }
+    if (io.obs && L.a > 0) {
+        // update: get_observable_state after the move; else get_next_observable_state (agent.py:63-74)
+        double* o = io.obs + ((size_t)L.env * (P.A - 1) + (L.a - 1)) * 5;
+        if (io.update) {
+            o[0] = r.px, o[1] = r.py, o[2] = r.vx, o[3] = r.vy;
+        } else {
+            o[0] = before.px + nvx * P.dt, o[1] = before.py + nvy * P.dt, o[2] = nvx, o[3] = nvy;
+        }
+        o[4] = r.rad;
+    }
+}
+
+// np.random.seed(seed) + scenario of one env per lane (lane = env)
+__global__ __launch_bounds__(kWave) void reset_kernel(Params P, StateView S, const uint32_t* seeds,
+                                                     const uint8_t* mask, uint64_t* draws) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    if (mask && !mask[b]) return;
+    Mt19937 rng{S.mt_key + b, P.B, 0};
+    const uint64_t n = generate_scenario(P.scen, rng, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+    S.mt_pos[b] = rng.pos;
+    S.gtime[b] = 0.0;
+    if (draws) draws[b] = n;
+}
+
+__global__ void mt_probe_kernel(uint32_t* key, uint32_t seed, int n, double* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Mt19937 rng{key, 1, 0};
+    rng.seed(seed);
+    for (int i = 0; i < n; ++i) out[i] = rng.random();
+}
+
+struct RolloutView {
+    cn_rollout_io io;
+    const double* discount;  // [discount_len]
+    int discount_len;
+};
+
+__device__ __forceinline__ int64_t episode_id(const cn_rollout_io& io, int b, int ordinal) {
+    return io.env_offset + b + (int64_t)ordinal * io.env_stride;
+}
+__device__ __forceinline__ uint32_t episode_seed(const cn_rollout_io& io, int64_t c) {
+    return io.seed_base + (uint32_t)((uint64_t)c % io.seed_mod);
+}
+
+// (re)start bookkeeping: env b begins its episode ordinal 0
+__global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, StateView S, RolloutView R) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const cn_rollout_io& io = R.io;
+    const int64_t c0 = episode_id(io, b, 0);
+    const bool on = io.episode_limit < 0 || c0 < io.episode_limit;
+    io.active[b] = on ? 1 : 0;
+    io.ep_count[b] = 0;
+    io.cur_steps[b] = 0;
+    io.cur_return[b] = 0.0;
+    if (io.cur_danger) io.cur_danger[b] = 0;
+    if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[b] = 0.0;
+    S.ring_filled_in[b] = 0;
+    S.ring_filled_out[b] = 0;
+    if (!on) return;
+    Mt19937 rng{S.mt_key + b, P.B, 0};
+    generate_scenario(P.scen, rng, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+    S.mt_pos[b] = rng.pos;
+    S.gtime[b] = 0.0;
+}
+
+// Scenario ring fill: one lane per (env, ring slot) generates the episode whose ordinal maps to that slot
+// if it has not been generated yet, so that ordinals [next, next + D) are resident when the rollout
+// launch that follows needs them.  Fully parallel and coalesced (generator state is [624][B*D]).
+__global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, StateView S, RolloutView R) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = P.ring_depth;
+    if (idx >= P.B * D) return;
+    const int b = idx / D, slot = idx - b * D;
+    const cn_rollout_io& io = R.io;
+    const int next = io.ep_count[b] + 1;  // first ordinal the rollout may still ask for
+    if (slot == 0) S.ring_filled_out[b] = next + D;
+    if (!io.active[b]) return;
+    const int ordinal = next + ((slot - next % D) + D) % D;
+    if (ordinal < S.ring_filled_in[b]) return;  // still resident from an earlier fill
+    const int64_t c = episode_id(io, b, ordinal);
+    if (io.episode_limit >= 0 && c >= io.episode_limit) return;
+    Mt19937 rng{S.ring_mt_key + idx, P.B * D, 0};
+    generate_scenario(P.scen, rng, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr,
+                      S.ring_goal, S.ring_rv);
+}
+
+// n_steps transitions per active env in one launch; state lives in VGPRs between steps, finished envs pick
+// their next scenario from the ring (or, if the ring ran dry, generate it in place).
+template <int MAXL>
+__global__ __launch_bounds__(kWave) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps) {
+    const Smem s = carve(P);
+    const cn_rollout_io& io = R.io;
+    const Lane L = lane_of(P);
+    AgentRegs r = {};
+    if (L.valid) load_agent(S, L.gi, r);
+    float robot_max_speed = 0.0f;
+    load_robot_view(P, S, s, L, r, robot_max_speed);
+    build_pairs(P, s);
+
+    const bool robot = L.valid && L.a == 0;
+    double gtime = 0.0, cur_return = 0.0, cur_dsum = 0.0;
+    int cur_steps = 0, cur_danger = 0, ep_count = 0, ring_filled = 0;
+    bool active = false;
+    if (robot) {
+        gtime = S.gtime[L.env];
+        active = io.active[L.env] != 0;
+        ep_count = io.ep_count[L.env];
+        cur_steps = io.cur_steps[L.env];
+        cur_return = io.cur_return[L.env];
+        if (io.cur_danger) cur_danger = io.cur_danger[L.env];
+        if (io.cur_danger_dmin_sum) cur_dsum = io.cur_danger_dmin_sum[L.env];
+        ring_filled = S.ring_filled_in[L.env];
+    }
+    unsigned long long transitions = 0;
+    if (robot) s.flag[L.lane] = active ? 1 : 0;
+    __syncthreads();
+
+    for (int step = 0; step < n_steps; ++step) {
+        Lane Ls = L;
+        Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env still has episodes to run
+
+        StepResult res;
+        double nvx, nvy;
+        step_core<MAXL>(P, s, Ls, r, gtime, robot_max_speed, nullptr, 1, res, nvx, nvy);
+
+        // flag: 1 = keep going, 0 = env retired, 2 + slot = load next scenario from ring slot,
+        //       -1 = next scenario was generated in place into the state arrays
+        int next_flag = 0;
+        if (robot && active) {
+            next_flag = 1;
+            ++transitions;
+            const double disc = cur_steps < R.discount_len ? R.discount[cur_steps] : 0.0;
+            cur_return = cur_return + disc * res.reward;  // python sum(): left to right
+            ++cur_steps;
+            if (res.info == CN_DANGER) {
+                ++cur_danger;
+                cur_dsum += res.dmin;
+            }
+            if (res.done) {
+                if (io.record_capacity > 0) {
+                    const size_t k = (size_t)L.env * io.record_capacity + (ep_count % io.record_capacity);
+                    if (io.ep_outcome) io.ep_outcome[k] = res.info;
+                    if (io.ep_steps) io.ep_steps[k] = cur_steps;
+                    if (io.ep_return) io.ep_return[k] = cur_return;
+                    if (io.ep_time) io.ep_time[k] = (res.info == CN_TIMEOUT) ? P.time_limit : gtime;
+                    if (io.ep_danger) io.ep_danger[k] = cur_danger;
+                    if (io.ep_danger_dmin_sum) io.ep_danger_dmin_sum[k] = cur_dsum;
+                }
+                ++ep_count;
+                cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
+                const int64_t c = episode_id(io, L.env, ep_count);
+                if (io.episode_limit >= 0 && c >= io.episode_limit) {
+                    active = false;
+                    next_flag = 0;
+                } else if (ep_count < ring_filled) {
+                    next_flag = 2 + ep_count % P.ring_depth;
+                    gtime = 0.0;
+                } else {
+                    Mt19937 rng{S.mt_key + L.env, P.B, 0};
+                    generate_scenario(P.scen, rng, episode_seed(io, c), (size_t)L.env * P.A, S.pos, S.vel, S.goal,
+                                      S.rv);
+                    S.mt_pos[L.env] = rng.pos;
+                    gtime = 0.0;
+                    next_flag = -1;
+                }
+            }
+        }
+        if (robot) s.flag[L.lane] = next_flag;
+        __syncthreads();
+        if (L.valid) {
+            const int f = s.flag[L.ebase];
+            if (f >= 2) {
+                const size_t ri = ((size_t)L.env * P.ring_depth + (f - 2)) * P.A + L.a;
+                const double2 p = S.ring_pos[ri], g = S.ring_goal[ri], q = S.ring_rv[ri];
+                r.px = p.x, r.py = p.y, r.vx = 0.0, r.vy = 0.0, r.gx = g.x, r.gy = g.y, r.rad = q.x, r.vpref = q.y;
+            } else if (f < 0) {
+                load_agent(S, L.gi, r);
+            }
+        }
+    }
+
+    if (L.valid) {
+        S.pos[L.gi] = make_double2(r.px, r.py);
+        S.vel[L.gi] = make_double2(r.vx, r.vy);
+        S.goal[L.gi] = make_double2(r.gx, r.gy);
+        S.rv[L.gi] = make_double2(r.rad, r.vpref);
+    }
+    if (robot) {
+        S.gtime[L.env] = gtime;
+        S.rsim_valid[L.env] = 1;
+        io.active[L.env] = active ? 1 : 0;
+        io.ep_count[L.env] = ep_count;
+        io.cur_steps[L.env] = cur_steps;
+        io.cur_return[L.env] = cur_return;
+        if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
+        if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
+        if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, transitions);
+    }
+}
+
+}  // namespace cn
