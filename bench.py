@@ -75,6 +75,7 @@ def main():
     import torch
     import torch.distributed as dist
     import crowdnav_amd
+    from crowdnav_amd import distributed as cd
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -93,7 +94,7 @@ def main():
                                        robot_visible=1, device=local_rank)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
     bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, episode_limit=-1, record_capacity=4,
-                             env_offset=rank * B, env_stride=world * B)
+                             env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1])
 
     def run(n_steps, events=None):
         left = n_steps
@@ -115,16 +116,14 @@ def main():
             torch.cuda.synchronize()
 
     def shard_boundary():
-        """per-rank episode summary (finished episodes, sum/count of recorded returns) -> every rank (RCCL)"""
-        cnt = bufs['ep_count'].sum().to(torch.float64)
-        k = torch.clamp(bufs['ep_count'], max=bufs['ep_return'].shape[1])
-        mask = torch.arange(bufs['ep_return'].shape[1], device=k.device)[None, :] < k[:, None]
-        summary = torch.stack([cnt, (bufs['ep_return'] * mask).sum(), mask.sum().to(torch.float64)])
+        """episode records of this shard -> every rank (one RCCL all-gather), then the job-wide summary"""
+        rec, cnt = cd.pack_records(bufs)
+        rec, cnt = cd.gather_records(rec, cnt)
+        have = torch.arange(rec.shape[1], device=rec.device)[None, :] < cnt[:, None]
+        finished = bufs['ep_count'].sum().to(torch.float64)
         if world > 1:
-            gathered = [torch.empty_like(summary) for _ in range(world)]
-            dist.all_gather(gathered, summary)
-            summary = torch.stack(gathered).sum(0)
-        return summary
+            dist.all_reduce(finished)
+        return torch.stack([finished, (rec[:, :, 2] * have).sum(), have.sum().to(torch.float64)])
 
     run(args.warmup)
     shard_boundary()  # warm-up of the torch / RCCL side too (lazy code-object loads, communicator setup)

@@ -1,0 +1,228 @@
+"""CrowdSim — the reference's gym.Env surface (crowd_sim/envs/crowd_sim.py:13-420) over a 1-env engine.
+
+    env = CrowdSim(); env.configure(env_config); env.set_robot(robot)
+    ob = env.reset(phase, test_case); ob, reward, done, info = env.step(action); env.onestep_lookahead(action)
+
+Every transition (the humans' ORCA solves, collision / reward / done, integration) and every seeded reset runs
+in libcrowdnav_amd on the GPU; this class only moves the results into the objects the reference's callers read.
+Not covered (raise NotImplementedError): render, get_human_times, the 'mixed' scenario rule, unicycle robots —
+out of the accelerated path."""
+import configparser
+import logging
+
+import numpy as np
+
+from .. import _lib
+from ..engine import BatchedCrowdSim
+from .agents import Human
+from .policy import is_device_orca
+from .types import ActionXY, ObservableState, info_from_code
+
+try:  # pragma: no cover
+    import gym
+    _Base = gym.Env
+except Exception:
+    _Base = object
+
+_RULES = {'circle_crossing': _lib.CIRCLE_CROSSING, 'square_crossing': _lib.SQUARE_CROSSING}
+
+
+def default_env_config(overrides=None):
+    """The shipped crowd_nav/configs/env.config as a RawConfigParser; overrides: {(section, key): value}."""
+    cfg = configparser.RawConfigParser()
+    cfg.read_dict({
+        'env': dict(time_limit=25, time_step=0.25, val_size=100, test_size=500, randomize_attributes='false'),
+        'reward': dict(success_reward=1, collision_penalty=-0.25, discomfort_dist=0.2, discomfort_penalty_factor=0.5),
+        'sim': dict(train_val_sim='circle_crossing', test_sim='circle_crossing', square_width=10, circle_radius=4,
+                    human_num=5),
+        'humans': dict(visible='true', policy='orca', radius=0.3, v_pref=1, sensor='coordinates'),
+        'robot': dict(visible='false', policy='none', radius=0.3, v_pref=1, sensor='coordinates'),
+    })
+    for (sec, key), val in (overrides or {}).items():
+        cfg.set(sec, key, str(val))
+    return cfg
+
+
+class CrowdSim(_Base):
+    metadata = {'render.modes': ['human']}
+
+    def __init__(self):
+        self.time_limit = self.time_step = None
+        self.robot = self.humans = None
+        self.global_time = None
+        self.human_times = None
+        self.success_reward = self.collision_penalty = self.discomfort_dist = self.discomfort_penalty_factor = None
+        self.config = None
+        self.case_capacity = self.case_size = self.case_counter = None
+        self.randomize_attributes = None
+        self.train_val_sim = self.test_sim = None
+        self.square_width = self.circle_radius = self.human_num = None
+        self.states = None
+        self.action_values = self.attention_weights = None
+        self._engines = {}
+        self._eng = None
+        self.device = 0
+
+    # ------------------------------------------------------------------ crowd_sim.py:51-82
+    def configure(self, config):
+        self.config = config
+        self.time_limit = config.getint('env', 'time_limit')
+        self.time_step = config.getfloat('env', 'time_step')
+        self.randomize_attributes = config.getboolean('env', 'randomize_attributes')
+        self.success_reward = config.getfloat('reward', 'success_reward')
+        self.collision_penalty = config.getfloat('reward', 'collision_penalty')
+        self.discomfort_dist = config.getfloat('reward', 'discomfort_dist')
+        self.discomfort_penalty_factor = config.getfloat('reward', 'discomfort_penalty_factor')
+        if config.get('humans', 'policy') != 'orca':
+            raise NotImplementedError
+        umax = int(np.iinfo(np.uint32).max)
+        self.case_capacity = {'train': umax - 2000, 'val': 1000, 'test': 1000}
+        self.case_size = {'train': umax - 2000, 'val': config.getint('env', 'val_size'),
+                          'test': config.getint('env', 'test_size')}
+        self.train_val_sim = config.get('sim', 'train_val_sim')
+        self.test_sim = config.get('sim', 'test_sim')
+        self.square_width = config.getfloat('sim', 'square_width')
+        self.circle_radius = config.getfloat('sim', 'circle_radius')
+        self.human_num = config.getint('sim', 'human_num')
+        self.case_counter = {'train': 0, 'test': 0, 'val': 0}
+        logging.info('human number: {}'.format(self.human_num))
+        logging.info('Training simulation: {}, test simulation: {}'.format(self.train_val_sim, self.test_sim))
+        logging.info('Square width: {}, circle width: {}'.format(self.square_width, self.circle_radius))
+
+    def set_robot(self, robot):
+        self.robot = robot
+        if is_device_orca(getattr(robot, 'policy', None)):
+            robot.policy._sim_env = self
+        for eng in self._engines.values():  # a new robot (policy object): nothing captured yet (orca.py:95-104)
+            eng.drop_robot_sim()
+
+    # ------------------------------------------------------------------ engine plumbing
+    def engine_config(self, num_envs, human_num, rule, robot_policy):
+        """cn_config for this env's settings (used for the 1-env engine and by Explorer's batched rollouts)."""
+        if rule not in _RULES:
+            raise NotImplementedError("scenario rule %r is outside the accelerated path" % rule)
+        if getattr(self.robot, 'kinematics', 'holonomic') != 'holonomic':
+            raise NotImplementedError('unicycle robots are outside the accelerated path')
+        pol = self.robot.policy
+        return dict(
+            num_envs=num_envs, num_humans=human_num, time_step=self.time_step, time_limit=float(self.time_limit),
+            success_reward=self.success_reward, collision_penalty=self.collision_penalty,
+            discomfort_dist=self.discomfort_dist, discomfort_penalty_factor=self.discomfort_penalty_factor,
+            robot_visible=int(bool(self.robot.visible)), robot_policy=robot_policy,
+            robot_safety_space=float(getattr(pol, 'safety_space', 0) or 0), human_safety_space=0.0,
+            scenario_rule=_RULES[rule], circle_radius=self.circle_radius, square_width=self.square_width,
+            human_radius=self.config.getfloat('humans', 'radius'), human_v_pref=self.config.getfloat('humans', 'v_pref'),
+            robot_radius=float(self.robot.radius), robot_v_pref=float(self.robot.v_pref),
+            randomize_attributes=int(bool(self.randomize_attributes)), device=self.device)
+
+    def _engine(self, human_num, rule):
+        cfg = self.engine_config(1, human_num, rule, _lib.ROBOT_EXTERNAL)
+        key = tuple(sorted(cfg.items()))
+        if key not in self._engines:
+            self._engines[key] = BatchedCrowdSim(**cfg)
+        return self._engines[key]
+
+    def _pull(self):
+        """device state -> robot / human objects"""
+        s, g = self._eng.get_state()
+        s = s.cpu().numpy()[0]
+        self.global_time = float(g.cpu()[0])
+        r = s[0]
+        self.robot.px, self.robot.py, self.robot.vx, self.robot.vy = (float(x) for x in r[:4])
+        for h, row in zip(self.humans, s[1:]):
+            h.set(*(float(row[i]) for i in (0, 1, 4, 5, 2, 3)), theta=0.0, radius=float(row[6]), v_pref=float(row[7]))
+
+    # ------------------------------------------------------------------ crowd_sim.py:251-312
+    def reset(self, phase='test', test_case=None):
+        if self.robot is None:
+            raise AttributeError('robot has to be set!')
+        assert phase in ['train', 'val', 'test']
+        if test_case is not None:
+            self.case_counter[phase] = test_case
+        multi = getattr(self.robot.policy, 'multiagent_training', None)
+        if not multi:
+            self.train_val_sim = 'circle_crossing'
+        offset = {'train': self.case_capacity['val'] + self.case_capacity['test'], 'val': 0,
+                  'test': self.case_capacity['val']}
+        self.robot.set(0, -self.circle_radius, 0, self.circle_radius, 0, 0, np.pi / 2)
+        case = self.case_counter[phase]
+        if case >= 0:
+            if phase in ('train', 'val'):
+                human_num, rule = (self.human_num if multi else 1), self.train_val_sim
+            else:
+                human_num, rule = self.human_num, self.test_sim
+            self._rule = rule
+            self._eng = self._engine(human_num, rule)
+            self._eng.reset([offset[phase] + case])
+            self.case_counter[phase] = (case + 1) % self.case_size[phase]
+        else:
+            assert phase == 'test'
+            if case != -1:
+                raise NotImplementedError
+            self.human_num = human_num = 3  # the reference's debug layout (crowd_sim.py:286-292)
+            self._rule = self.test_sim
+            self._eng = self._engine(3, self.test_sim)
+            hr, hv = self.config.getfloat('humans', 'radius'), self.config.getfloat('humans', 'v_pref')
+            R = self.circle_radius
+            st = np.array([[0, -R, 0, 0, 0, R, self.robot.radius, self.robot.v_pref],
+                           [0, -6, 0, 0, 0, 5, hr, hv], [-5, -5, 0, 0, -5, 5, hr, hv], [5, -5, 0, 0, 5, 5, hr, hv]],
+                          dtype=np.float64)[None]
+            self._eng.set_state(st, np.zeros(1))
+        self.humans = [Human(self.config, 'humans') for _ in range(human_num)]
+        self.human_times = [0] * human_num
+        self._pull()
+        self.global_time = 0
+        for agent in [self.robot] + self.humans:
+            agent.time_step = self.time_step
+            if agent.policy is not None:
+                agent.policy.time_step = self.time_step
+        self.states = list()
+        if hasattr(self.robot.policy, 'action_values'):
+            self.action_values = list()
+        if hasattr(self.robot.policy, 'get_attention_weights'):
+            self.attention_weights = list()
+        if self.robot.sensor != 'coordinates':
+            raise NotImplementedError
+        return [h.get_observable_state() for h in self.humans]
+
+    # ------------------------------------------------------------------ crowd_sim.py:314-420
+    def onestep_lookahead(self, action):
+        return self.step(action, update=False)
+
+    def step(self, action, update=True):
+        if not isinstance(action, tuple) or not hasattr(action, 'vx'):
+            raise NotImplementedError('only holonomic ActionXY actions are on the accelerated path')
+        if update:
+            self.states.append([self.robot.get_full_state(), [h.get_full_state() for h in self.humans]])
+            if hasattr(self.robot.policy, 'action_values'):
+                self.action_values.append(self.robot.policy.action_values)
+            if hasattr(self.robot.policy, 'get_attention_weights'):
+                self.attention_weights.append(self.robot.policy.get_attention_weights())
+        out = self._eng.step(np.array([[action.vx, action.vy]], dtype=np.float64), update=update)
+        reward = float(out['reward'].cpu()[0])
+        done = bool(out['done'].cpu()[0])
+        info = info_from_code(out['info'].cpu()[0], out['dmin'].cpu()[0])
+        obs = out['obs'].cpu().numpy()[0]
+        if update:
+            self._pull()
+            for i, h in enumerate(self.humans):
+                if self.human_times[i] == 0 and h.reached_destination():
+                    self.human_times[i] = self.global_time
+        ob = [ObservableState(*(float(x) for x in row)) for row in obs]
+        return ob, reward, done, info
+
+    def robot_orca_action(self):
+        """Agent 0's ORCA velocity from the current device state (used by the device-backed ORCA policy)."""
+        want = float(getattr(self.robot.policy, 'safety_space', 0) or 0)
+        if want != self._eng.config['robot_safety_space']:  # test.py / train.py set it after set_robot
+            s, g = self._eng.get_state()
+            self._eng = self._engine(self._eng.H, self._rule)
+            self._eng.set_state(s, g)
+        v = self._eng.orca().cpu().numpy()[0, 0]
+        return float(v[0]), float(v[1])
+
+    def render(self, mode='human', output_file=None):
+        raise NotImplementedError('rendering is outside the accelerated path; use the reference CrowdSim')
+
+    def get_human_times(self):
+        raise NotImplementedError('get_human_times is outside the accelerated path')

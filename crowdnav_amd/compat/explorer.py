@@ -1,0 +1,170 @@
+"""Explorer — the reference's episode driver surface (crowd_nav/utils/explorer.py:7-125).
+
+run_k_episodes(k, phase, ...) keeps the reference's signature, bookkeeping and log lines.  When the robot's
+policy lives on the device (ORCA) and no replay memory has to be filled, all k episodes run as ONE batch of
+min(k, max_envs) envs inside the fused rollout kernel (cn_rollout): episode i of the call is the scenario the
+reference would have produced on its i-th env.reset(phase).  Otherwise the reference's own loop runs on top of
+CrowdSim.step (one launch per transition)."""
+import copy
+import logging
+
+import torch
+
+from .. import _lib
+from ..engine import BatchedCrowdSim
+from .policy import is_device_orca
+from .types import Collision, Danger, ReachGoal, Timeout
+
+
+def average(values):
+    return sum(values) / len(values) if values else 0
+
+
+class Explorer(object):
+    max_envs = 4096  # envs per batched launch
+
+    def __init__(self, env, robot, device, memory=None, gamma=None, target_policy=None):
+        self.env = env
+        self.robot = robot
+        self.device = device
+        self.memory = memory
+        self.gamma = gamma
+        self.target_policy = target_policy
+        self.target_model = None
+        self.last_batch = None  # per-episode arrays of the last batched call (for callers that want more)
+
+    def update_target_model(self, target_model):
+        self.target_model = copy.deepcopy(target_model)
+
+    # ------------------------------------------------------------------ explorer.py:21-90
+    def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
+                       print_failure=False):
+        self.robot.policy.set_phase(phase)
+        batched = (is_device_orca(self.robot.policy) and not update_memory and hasattr(self.env, 'engine_config')
+                   and self.env.case_counter[phase] >= 0
+                   and self.env.case_counter[phase] + k <= self.env.case_size[phase])  # no wrap of the case table
+        if batched:
+            stats = self._run_batched(k, phase)
+        else:
+            stats = self._run_sequential(k, phase, update_memory, imitation_learning)
+        self._report(k, phase, episode, print_failure, *stats)
+
+    def _run_sequential(self, k, phase, update_memory, imitation_learning):
+        success_times, collision_times, timeout_times = [], [], []
+        too_close, min_dist, cumulative_rewards = 0, [], []
+        collision_cases, timeout_cases = [], []
+        for i in range(k):
+            ob = self.env.reset(phase)
+            done = False
+            states, actions, rewards = [], [], []
+            while not done:
+                action = self.robot.act(ob)
+                ob, reward, done, info = self.env.step(action)
+                states.append(self.robot.policy.last_state)
+                actions.append(action)
+                rewards.append(reward)
+                if isinstance(info, Danger):
+                    too_close += 1
+                    min_dist.append(info.min_dist)
+            if isinstance(info, ReachGoal):
+                success_times.append(self.env.global_time)
+            elif isinstance(info, Collision):
+                collision_cases.append(i)
+                collision_times.append(self.env.global_time)
+            elif isinstance(info, Timeout):
+                timeout_cases.append(i)
+                timeout_times.append(self.env.time_limit)
+            else:
+                raise ValueError('Invalid end signal from environment')
+            if update_memory and isinstance(info, (ReachGoal, Collision)):
+                self.update_memory(states, actions, rewards, imitation_learning)
+            cumulative_rewards.append(sum([pow(self.gamma, t * self.robot.time_step * self.robot.v_pref) * reward
+                                           for t, reward in enumerate(rewards)]))
+        return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, too_close,
+                average(min_dist), cumulative_rewards)
+
+    def _run_batched(self, k, phase):
+        env = self.env
+        self.robot.time_step = env.time_step  # CrowdSim.reset does this (crowd_sim.py:296-298)
+        self.robot.policy.time_step = env.time_step
+        multi = getattr(self.robot.policy, 'multiagent_training', None)
+        if phase == 'test':
+            human_num, rule = env.human_num, env.test_sim
+        else:
+            human_num, rule = (env.human_num if multi else 1), ('circle_crossing' if not multi else env.train_val_sim)
+        offset = {'train': env.case_capacity['val'] + env.case_capacity['test'], 'val': 0,
+                  'test': env.case_capacity['val']}[phase]
+        start = env.case_counter[phase]
+        size = env.case_size[phase]
+        B = int(min(k, self.max_envs))
+        eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
+        eng.set_gamma(self.gamma)
+        per_env = (k + B - 1) // B
+        # episode i of this call is case start + i of the phase (no wrap: checked by the caller)
+        bufs = eng.rollout_begin(seed_base=offset + start, seed_mod=size, episode_limit=k, record_capacity=per_env)
+        max_steps = int(round(env.time_limit / env.time_step)) + 2
+        while True:
+            eng.rollout(max_steps)
+            if int(bufs['active'].sum().item()) == 0:
+                break
+        rec = {n: bufs[n].cpu().numpy() for n in ('ep_outcome', 'ep_steps', 'ep_return', 'ep_time', 'ep_danger',
+                                                  'ep_danger_dmin_sum', 'ep_count')}
+        env.case_counter[phase] = (start + k) % size
+        # episode id c = b + j*B  ->  record [b, j]
+        order = [(c % B, c // B) for c in range(k)]
+        outcome = [int(rec['ep_outcome'][b, j]) for b, j in order]
+        times = [float(rec['ep_time'][b, j]) for b, j in order]
+        returns = [float(rec['ep_return'][b, j]) for b, j in order]
+        self.last_batch = dict(outcome=outcome, nav_time=times, discounted_return=returns,
+                               steps=[int(rec['ep_steps'][b, j]) for b, j in order])
+        success_times = [t for o, t in zip(outcome, times) if o == _lib.REACH_GOAL]
+        collision_times = [t for o, t in zip(outcome, times) if o == _lib.COLLISION]
+        timeout_times = [t for o, t in zip(outcome, times) if o == _lib.TIMEOUT]
+        collision_cases = [i for i, o in enumerate(outcome) if o == _lib.COLLISION]
+        timeout_cases = [i for i, o in enumerate(outcome) if o == _lib.TIMEOUT]
+        too_close = int(sum(rec['ep_danger'][b, j] for b, j in order))
+        dsum = float(sum(rec['ep_danger_dmin_sum'][b, j] for b, j in order))
+        return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, too_close,
+                dsum / too_close if too_close else 0, returns)
+
+    def _report(self, k, phase, episode, print_failure, success_times, collision_times, timeout_times,
+                collision_cases, timeout_cases, too_close, avg_min_dist, cumulative_rewards):
+        success, collision, timeout = len(success_times), len(collision_times), len(timeout_times)
+        success_rate = success / k
+        collision_rate = collision / k
+        assert success + collision + timeout == k
+        avg_nav_time = sum(success_times) / len(success_times) if success_times else self.env.time_limit
+        extra_info = '' if episode is None else 'in episode {} '.format(episode)
+        logging.info('{:<5} {}has success rate: {:.2f}, collision rate: {:.2f}, nav time: {:.2f}, total reward: {:.4f}'.
+                     format(phase.upper(), extra_info, success_rate, collision_rate, avg_nav_time,
+                            average(cumulative_rewards)))
+        if phase in ['val', 'test']:
+            num_step = sum(success_times + collision_times + timeout_times) / self.robot.time_step
+            logging.info('Frequency of being in danger: %.2f and average min separate distance in danger: %.2f',
+                         too_close / num_step, avg_min_dist)
+        if print_failure:
+            logging.info('Collision cases: ' + ' '.join([str(x) for x in collision_cases]))
+            logging.info('Timeout cases: ' + ' '.join([str(x) for x in timeout_cases]))
+        self.last_stats = dict(success_rate=success_rate, collision_rate=collision_rate, nav_time=avg_nav_time,
+                               total_reward=average(cumulative_rewards), too_close=too_close,
+                               collision_cases=collision_cases, timeout_cases=timeout_cases)
+
+    # ------------------------------------------------------------------ explorer.py:92-125
+    def update_memory(self, states, actions, rewards, imitation_learning=False):
+        if self.memory is None or self.gamma is None:
+            raise ValueError('Memory or gamma value is not set!')
+        for i, state in enumerate(states):
+            reward = rewards[i]
+            if imitation_learning:
+                state = self.target_policy.transform(state)
+                value = sum([pow(self.gamma, max(t - i, 0) * self.robot.time_step * self.robot.v_pref) * reward
+                             * (1 if t >= i else 0) for t, reward in enumerate(rewards)])
+            else:
+                if i == len(states) - 1:
+                    value = reward
+                else:
+                    next_state = states[i + 1]
+                    gamma_bar = pow(self.gamma, self.robot.time_step * self.robot.v_pref)
+                    value = reward + gamma_bar * self.target_model(next_state.unsqueeze(0)).data.item()
+            value = torch.Tensor([value]).to(self.device)
+            self.memory.push((state, value))

@@ -1,0 +1,68 @@
+"""Sim-side policies on the reference's Policy protocol (crowd_sim/envs/policy/policy.py:5-49).
+ORCA here is device-backed: predict() asks the env's engine for agent 0's ORCA velocity (cn_orca) instead of
+driving an rvo2 simulator (crowd_sim/envs/policy/orca.py:82-132)."""
+from .types import ActionXY
+
+
+class Policy(object):
+    def __init__(self):
+        self.trainable = False
+        self.phase = None
+        self.model = None
+        self.device = None
+        self.last_state = None
+        self.time_step = None
+        self.env = None
+
+    def configure(self, config):
+        return
+
+    def set_phase(self, phase):
+        self.phase = phase
+
+    def set_device(self, device):
+        self.device = device
+
+    def set_env(self, env):
+        self.env = env
+
+    def get_model(self):
+        return self.model
+
+    def predict(self, state):
+        raise NotImplementedError
+
+
+class ORCA(Policy):
+    """Same attributes as the reference's ORCA (orca.py:55-67); the solve itself runs in libcrowdnav_amd."""
+
+    def __init__(self):
+        super().__init__()
+        self.name = 'ORCA'
+        self.trainable = False
+        self.multiagent_training = None
+        self.kinematics = 'holonomic'
+        self.safety_space = 0
+        self.neighbor_dist = 10
+        self.max_neighbors = 10
+        self.time_horizon = 5
+        self.time_horizon_obst = 5
+        self.radius = 0.3
+        self.max_speed = 1
+        self._sim_env = None  # the CrowdSim that owns the robot using this policy (wired by set_robot)
+
+    def predict(self, state):
+        env = self._sim_env if self._sim_env is not None else self.env
+        if env is None or not hasattr(env, 'robot_orca_action'):
+            raise RuntimeError('crowdnav_amd ORCA policy is not attached to a crowdnav_amd CrowdSim '
+                               '(env.set_robot(robot) wires it); there is no CPU rvo2 fallback')
+        vx, vy = env.robot_orca_action()
+        self.last_state = state
+        return ActionXY(vx, vy)
+
+
+def is_device_orca(policy):
+    return isinstance(policy, ORCA)
+
+
+policy_factory = {'orca': ORCA, 'none': lambda: None}

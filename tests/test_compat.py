@@ -1,0 +1,113 @@
+"""The drop-in surface (crowdnav_amd.compat): gym-style CrowdSim + Explorer against the reference-generated
+fixtures.  CPU part: value types, config plumbing, report formatting.  GPU part: trajectories and the
+Explorer.run_k_episodes log line of `test.py --policy orca` (0.43 / 0.57 / 10.86)."""
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import episodes_of, load_golden
+
+
+def _setup(robot_visible=False, overrides=None):
+    import crowdnav_amd.compat as c
+    ov = {('robot', 'visible'): 'true' if robot_visible else 'false'}
+    ov.update(overrides or {})
+    cfg = c.default_env_config(ov)
+    env = c.CrowdSim()
+    env.configure(cfg)
+    robot = c.Robot(cfg, 'robot')
+    policy = c.ORCA()
+    robot.set_policy(policy)
+    env.set_robot(robot)
+    policy.set_env(env)
+    return c, env, robot
+
+
+def test_types_and_config_cpu():
+    c, env, robot = _setup()
+    assert env.case_size == {'train': 2 ** 32 - 1 - 2000, 'val': 100, 'test': 500}
+    assert env.case_capacity['val'] + env.case_capacity['test'] == 2000
+    assert (env.time_limit, env.time_step, env.human_num) == (25, 0.25, 5)
+    o = c.ObservableState(1.0, 2.0, 3.0, 4.0, 0.3)
+    f = c.FullState(1.0, 2.0, 3.0, 4.0, 0.3, 5.0, 6.0, 1.0, 0.0)
+    # joint row = self (9) followed by human (5), as multi_human_rl.py:43 flattens it
+    assert (f + o) == (1.0, 2.0, 3.0, 4.0, 0.3, 5.0, 6.0, 1.0, 0.0) + (1.0, 2.0, 3.0, 4.0, 0.3)
+    assert str(c.ReachGoal()) == 'Reaching goal' and str(c.Nothing()) == '' and c.Danger(0.1).min_dist == 0.1
+    cfg = env.engine_config(7, 5, 'square_crossing', 1)
+    assert cfg['num_envs'] == 7 and cfg['scenario_rule'] == 1 and cfg['robot_visible'] == 0
+    with pytest.raises(NotImplementedError):
+        env.engine_config(1, 5, 'mixed', 1)
+    with pytest.raises(AttributeError):
+        c.CrowdSim().reset('test')
+
+
+def test_report_line_format_cpu(caplog):
+    c, env, robot = _setup()
+    robot.time_step = 0.25
+    ex = c.Explorer(env, robot, 'cpu', gamma=0.9)
+    with caplog.at_level(logging.INFO):
+        ex._report(4, 'test', None, True, [10.0, 11.0], [3.0], [25], [2], [3], 5, 0.081, [1.0, 0.5, -0.25, 0.0])
+    assert ('TEST  has success rate: 0.50, collision rate: 0.25, nav time: 10.50, total reward: 0.3125'
+            in caplog.text)
+    assert 'Frequency of being in danger: 0.03 and average min separate distance in danger: 0.08' in caplog.text
+    assert 'Collision cases: 2' in caplog.text and 'Timeout cases: 3' in caplog.text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,visible', [('traj_invisible_h5.npz', False), ('traj_visible_h5.npz', True)])
+def test_gym_surface_reproduces_reference_episodes(name, visible):
+    """reset / robot.act / step exactly as Explorer drives them, vs the unmodified reference."""
+    c, env, robot = _setup(robot_visible=visible)
+    g = load_golden(name)
+    for case, e in zip(g['cases'].tolist()[:6], episodes_of(g)[:6]):
+        ob = env.reset('test', case)
+        assert len(ob) == 5 and abs(ob[0].px - e['states'][0][1][0]) <= 1e-12
+        # start from the reference's exact initial state (numpy vs device cos/sin may differ in the last ulp)
+        env._eng.set_state(e['states'][:1], np.zeros(1))
+        env._pull()
+        ob = [h.get_observable_state() for h in env.humans]
+        for t in range(len(e['actions'])):
+            action = robot.act(ob)
+            assert (action.vx, action.vy) == tuple(e['actions'][t])
+            look = env.onestep_lookahead(action)
+            ob, reward, done, info = env.step(action)
+            assert look[1] == reward and look[2] == done
+            assert reward == e['rewards'][t] and done == bool(e['dones'][t])
+            assert type(info).__name__ == ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')[e['infos'][t]]
+            got = np.array([[h.px, h.py, h.vx, h.vy] for h in env.humans])
+            assert np.array_equal(got, e['states'][t + 1][1:, :4])
+            assert (robot.px, robot.py) == tuple(e['states'][t + 1][0, :2])
+        assert done and env.global_time == 0.25 * len(e['actions'])
+    assert env.case_counter['test'] == (g['cases'].tolist()[5] + 1) % 500
+
+
+@pytest.mark.gpu
+def test_explorer_500_test_cases_log_line(caplog):
+    """`python test.py --policy orca` on the shipped configs: success 0.43, collision 0.57, nav time 10.86."""
+    c, env, robot = _setup(robot_visible=False)
+    ex = c.Explorer(env, robot, 'cuda:0', gamma=0.9)
+    with caplog.at_level(logging.INFO):
+        ex.run_k_episodes(env.case_size['test'], 'test', print_failure=True)
+    assert 'TEST  has success rate: 0.43, collision rate: 0.57, nav time: 10.86, total reward: -0.0220' in caplog.text
+    assert 'Frequency of being in danger: 0.30 and average min separate distance in danger: 0.08' in caplog.text
+    g = load_golden('outcomes_500.npz')
+    assert ex.last_batch['outcome'] == g['invisible_info'].tolist()
+    assert ex.last_batch['steps'] == g['invisible_steps'].tolist()
+    assert ex.last_stats['collision_cases'] == np.nonzero(g['invisible_info'] == 3)[0].tolist()
+    assert env.case_counter['test'] == 0  # wrapped: 500 % 500
+
+
+@pytest.mark.gpu
+def test_explorer_sequential_equals_batched():
+    c, env, robot = _setup(robot_visible=True)
+    ex = c.Explorer(env, robot, 'cuda:0', gamma=0.9)
+    ex.run_k_episodes(12, 'val')
+    batched = dict(ex.last_stats)
+    env.case_counter['val'] = 0
+    stats = ex._run_sequential(12, 'val', False, False)
+    ex._report(12, 'val', None, False, *stats)
+    for key in ('success_rate', 'collision_rate', 'too_close', 'collision_cases', 'timeout_cases'):
+        assert ex.last_stats[key] == batched[key], key
+    assert abs(ex.last_stats['nav_time'] - batched['nav_time']) < 1e-12
+    assert abs(ex.last_stats['total_reward'] - batched['total_reward']) < 1e-9

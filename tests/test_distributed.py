@@ -1,0 +1,70 @@
+"""N>1 path on CPU: world_size-2 gloo processes exchange episode records exactly as ranks do over RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_bufs(rank, B, K, world):
+    """Deterministic stand-in for what the rollout kernel leaves in the record buffers of one shard."""
+    g = torch.arange(B) + rank * B  # global env ids
+    counts = (g % (K + 1)).to(torch.int32)
+    j = torch.arange(K)[None, :]
+    c = g[:, None] + j * (world * B)  # global episode ids
+    return dict(ep_outcome=(2 + c % 3).to(torch.uint8), ep_steps=(10 + c % 50).to(torch.int32),
+                ep_return=c.to(torch.float64) * 0.001, ep_time=c.to(torch.float64) * 0.25,
+                ep_danger=(c % 4).to(torch.int32), ep_danger_dmin_sum=c.to(torch.float64) * 0.01, ep_count=counts)
+
+
+def _worker(rank, world, port, B, K, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from crowdnav_amd import distributed as cd
+    assert cd.shard(rank, world, B) == (rank * B, world * B)
+    rec, cnt = cd.pack_records(_fake_bufs(rank, B, K, world))
+    allr, allc = cd.gather_records(rec, cnt)
+    ids, vals = cd.episodes_in_global_order(allr, allc, world * B)
+    ret[rank] = (allr.clone(), allc.clone(), ids.clone(), vals.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_records_world2_gloo():
+    world, B, K = 2, 8, 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), B, K, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)  # identical on every rank
+    allr, allc, ids, vals = r0
+    assert allr.shape == (world * B, K, 6) and allc.tolist() == [(g % (K + 1)) for g in range(world * B)]
+    # what a single process owning all 16 envs would hold
+    from crowdnav_amd import distributed as cd
+    want = [cd.pack_records(_fake_bufs(r, B, K, world)) for r in range(world)]
+    assert torch.equal(allr, torch.cat([w[0] for w in want])) and torch.equal(allc, torch.cat([w[1] for w in want]))
+    # global episode order: ids strictly increasing, discounted_return column = 0.001 * id
+    assert torch.all(ids[1:] > ids[:-1]) and len(ids) == int(allc.sum())
+    assert torch.allclose(vals[:, 2], ids.to(torch.float64) * 0.001)
+
+
+def test_gather_is_identity_without_process_group():
+    from crowdnav_amd import distributed as cd
+    rec, cnt = cd.pack_records(_fake_bufs(0, 4, 2, 1))
+    a, b = cd.gather_records(rec, cnt)
+    assert a is rec and b is cnt
+    with pytest.raises(ValueError):
+        cd.shard(2, 2, 4)
