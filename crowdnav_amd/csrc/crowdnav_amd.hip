@@ -52,8 +52,12 @@ int fail(int code, const char* fmt, ...) {
 struct cn_engine {
     cn_config cfg;
     cn::Params P;
+    cn::ScenarioCfg C;
     cn::StateView S;
     hipStream_t stream;
+    cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
+    cn_rollout_io* io_dev;   // device copy the rollout kernels read through
+    bool io_valid;
     double* discount;
     int discount_len;
     uint32_t* probe_key;
@@ -128,6 +132,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (!e) return fail(CN_ERR_INVALID, "out of host memory");
     e->cfg = *c;
     e->stream = nullptr;
+    e->io_valid = false;
     cn::Params& P = e->P;
     P.B = c->num_envs;
     P.A = c->num_humans + 1;
@@ -157,16 +162,16 @@ int cn_create(const cn_config* c, cn_engine** out) {
     P.orca.inv_time_horizon = 1.0f / (float)c->time_horizon;
     P.orca.inv_time_step = 1.0f / (float)c->time_step;
     P.orca.max_neighbors = c->max_neighbors;
-    P.scen.num_agents = P.A;
-    P.scen.rule = c->scenario_rule;
-    P.scen.randomize = c->randomize_attributes ? 1 : 0;
-    P.scen.circle_radius = c->circle_radius;
-    P.scen.square_width = c->square_width;
-    P.scen.discomfort_dist = c->discomfort_dist;
-    P.scen.human_radius = c->human_radius;
-    P.scen.human_v_pref = c->human_v_pref;
-    P.scen.robot_radius = c->robot_radius;
-    P.scen.robot_v_pref = c->robot_v_pref;
+    e->C.num_agents = P.A;
+    e->C.rule = c->scenario_rule;
+    e->C.randomize = c->randomize_attributes ? 1 : 0;
+    e->C.circle_radius = c->circle_radius;
+    e->C.square_width = c->square_width;
+    e->C.discomfort_dist = c->discomfort_dist;
+    e->C.human_radius = c->human_radius;
+    e->C.human_v_pref = c->human_v_pref;
+    e->C.robot_radius = c->robot_radius;
+    e->C.robot_v_pref = c->robot_v_pref;
 
     const size_t n = (size_t)P.B * P.A;
     int rc = CN_OK;
@@ -179,7 +184,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_pos, n * P.ring_depth)) || (rc = dev_alloc(e, &S.ring_goal, n * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_rv, n * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_mt_key, (size_t)624 * P.B * P.ring_depth)) ||
-        (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B))) {
+        (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &e->io_dev, (size_t)1))) {
         cn_destroy(e);
         return rc;
     }
@@ -272,7 +278,7 @@ int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t*
     int rc = bind(e);
     if (rc) return rc;
     if (!seeds) return fail(CN_ERR_INVALID, "cn_reset: seeds is NULL");
-    hipLaunchKernelGGL(cn::reset_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->S, seeds, mask,
+    hipLaunchKernelGGL(cn::reset_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, seeds, mask,
                        draws);
     CN_HIP(hipGetLastError());
     return CN_OK;
@@ -317,6 +323,15 @@ int cn_set_gamma(cn_engine* e, double gamma) {
     return CN_OK;
 }
 
+// Upload the caller's io struct (ordered on the engine's stream) if it differs from the device copy.
+static int upload_io(cn_engine* e, const cn_rollout_io* io) {
+    if (e->io_valid && std::memcmp(&e->io_host, io, sizeof(*io)) == 0) return CN_OK;
+    e->io_host = *io;
+    CN_HIP(hipMemcpyAsync(e->io_dev, &e->io_host, sizeof(*io), hipMemcpyHostToDevice, e->stream));
+    e->io_valid = true;
+    return CN_OK;
+}
+
 static int check_io(const cn_engine* e, const cn_rollout_io* io) {
     if (!io) return fail(CN_ERR_INVALID, "rollout io is NULL");
     if (!e->P.robot_orca)
@@ -333,9 +348,9 @@ static int check_io(const cn_engine* e, const cn_rollout_io* io) {
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     int rc = bind(e);
     if (rc) return rc;
-    if ((rc = check_io(e, io))) return rc;
-    cn::RolloutView R{*io, e->discount, e->discount_len};
-    hipLaunchKernelGGL(cn::rollout_begin_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->S, R);
+    if ((rc = check_io(e, io)) || (rc = upload_io(e, io))) return rc;
+    cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
+    hipLaunchKernelGGL(cn::rollout_begin_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -346,11 +361,12 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     if ((rc = check_io(e, io))) return rc;
     if (n_steps < 0) return fail(CN_ERR_INVALID, "n_steps must be >= 0");
     if (n_steps == 0) return CN_OK;
-    cn::RolloutView R{*io, e->discount, e->discount_len};
+    if ((rc = upload_io(e, io))) return rc;
+    cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     // top the scenario ring up to ring_depth episodes ahead of every env, then run the fused transitions
     const int fill_lanes = e->P.B * e->P.ring_depth;
     hipLaunchKernelGGL(cn::ring_fill_kernel, dim3((fill_lanes + cn::kWave - 1) / cn::kWave), dim3(cn::kWave), 0,
-                       e->stream, e->P, e->S, R);
+                       e->stream, e->P, e->C, e->S, R);
     std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
     CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps);
     CN_HIP(hipGetLastError());

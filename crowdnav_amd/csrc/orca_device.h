@@ -30,6 +30,10 @@ struct OrcaParams {
 };
 
 // Build one ORCA half-plane (Appendix A.3): self (sp, sv), other (op, ov), rsum = combined padded radius.
+// The three geometric cases (cut-off disc, left/right leg, already overlapping) are folded into ONE
+// sqrt + ONE reciprocal with selected operands, so that lanes of a wave in different cases do not serialise
+// three divergent branches.  Every selected value is produced by exactly the operations RVO2 performs for
+// that case, so the result is bit-identical to the branchy form.
 __device__ __forceinline__ float4 make_half_plane(const OrcaParams& P, float spx, float spy, float svx,
                                                   float svy, float opx, float opy, float ovx, float ovy,
                                                   float rsum) {
@@ -37,50 +41,29 @@ __device__ __forceinline__ float4 make_half_plane(const OrcaParams& P, float spx
     const float rvx = svx - ovx, rvy = svy - ovy;
     const float dist_sq = rpx * rpx + rpy * rpy;
     const float rsum_sq = rsum * rsum;
-    float ux, uy, ldx, ldy;
-    if (dist_sq > rsum_sq) {
-        const float wx = rvx - P.inv_time_horizon * rpx;
-        const float wy = rvy - P.inv_time_horizon * rpy;
-        const float wlen_sq = wx * wx + wy * wy;
-        const float dot1 = wx * rpx + wy * rpy;
-        if (dot1 < 0.0f && dot1 * dot1 > rsum_sq * wlen_sq) {
-            // closest point of the velocity obstacle is on its cut-off disc
-            const float wlen = sqrtf(wlen_sq);
-            const float inv = 1.0f / wlen;
-            const float nx = wx * inv, ny = wy * inv;
-            ldx = ny;
-            ldy = -nx;
-            const float k = rsum * P.inv_time_horizon - wlen;
-            ux = k * nx;
-            uy = k * ny;
-        } else {
-            // ... on one of its legs
-            const float leg = sqrtf(dist_sq - rsum_sq);
-            const float inv = 1.0f / dist_sq;
-            if (rpx * wy - rpy * wx > 0.0f) {
-                ldx = (rpx * leg - rpy * rsum) * inv;
-                ldy = (rpx * rsum + rpy * leg) * inv;
-            } else {
-                ldx = -((rpx * leg + rpy * rsum) * inv);
-                ldy = -((-rpx * rsum + rpy * leg) * inv);
-            }
-            const float dot2 = rvx * ldx + rvy * ldy;
-            ux = dot2 * ldx - rvx;
-            uy = dot2 * ldy - rvy;
-        }
-    } else {
-        // already overlapping: get out within one time step
-        const float wx = rvx - P.inv_time_step * rpx;
-        const float wy = rvy - P.inv_time_step * rpy;
-        const float wlen = sqrtf(wx * wx + wy * wy);
-        const float inv = 1.0f / wlen;
-        const float nx = wx * inv, ny = wy * inv;
-        ldx = ny;
-        ldy = -nx;
-        const float k = rsum * P.inv_time_step - wlen;
-        ux = k * nx;
-        uy = k * ny;
-    }
+    const bool overlap = !(dist_sq > rsum_sq);  // already colliding: resolve within one time step
+    const float inv_t = overlap ? P.inv_time_step : P.inv_time_horizon;
+    const float wx = rvx - inv_t * rpx;
+    const float wy = rvy - inv_t * rpy;
+    const float wlen_sq = wx * wx + wy * wy;
+    const float dot1 = wx * rpx + wy * rpy;
+    // closest point of the velocity obstacle on its cut-off disc (always so when overlapping), else on a leg
+    const bool disc = overlap || (dot1 < 0.0f && dot1 * dot1 > rsum_sq * wlen_sq);
+    const float root = sqrtf(disc ? wlen_sq : dist_sq - rsum_sq);  // |w|  or  leg length
+    const float inv = 1.0f / (disc ? root : dist_sq);
+    // disc case
+    const float nx = wx * inv, ny = wy * inv;
+    const float kd = rsum * inv_t - root;
+    // leg case
+    const bool left = rpx * wy - rpy * wx > 0.0f;
+    const float llx = (rpx * root - rpy * rsum) * inv, lly = (rpx * rsum + rpy * root) * inv;
+    const float lrx = -((rpx * root + rpy * rsum) * inv), lry = -((-rpx * rsum + rpy * root) * inv);
+    const float gx = left ? llx : lrx, gy = left ? lly : lry;
+    const float dot2 = rvx * gx + rvy * gy;
+    const float ldx = disc ? ny : gx;
+    const float ldy = disc ? -nx : gy;
+    const float ux = disc ? kd * nx : dot2 * gx - rvx;
+    const float uy = disc ? kd * ny : dot2 * gy - rvy;
     return make_float4(svx + 0.5f * ux, svy + 0.5f * uy, ldx, ldy);
 }
 
@@ -110,34 +93,28 @@ __device__ __forceinline__ bool lp_on_line_reg(const float4 (&L)[MAXL], int k, f
     const float root = sqrtf(disc);
     float t_lo = -dp - root;
     float t_hi = -dp + root;
+    // Branch-free form of RVO2's loop: a failed program keeps ok == false whatever follows, and the interval
+    // test is monotone (t_lo only grows, t_hi only shrinks), so evaluating it every iteration is equivalent.
 #pragma unroll
     for (int i = 0; i < MAXL - 1; ++i) {
-        if (i < k && ok) {
+        if (i < k) {
             const float den = dx * L[i].w - dy * L[i].z;
             const float num = L[i].z * (py - L[i].y) - L[i].w * (px - L[i].x);
-            if (fabsf(den) <= kRvoEps) {
-                if (num < 0.0f) ok = false;
-            } else {
-                const float t = num / den;
-                if (den >= 0.0f) {
-                    t_hi = (t < t_hi) ? t : t_hi;
-                } else {
-                    t_lo = (t_lo < t) ? t : t_lo;
-                }
-                if (t_lo > t_hi) ok = false;
-            }
+            const bool parallel = fabsf(den) <= kRvoEps;
+            const float t = num / den;
+            ok = ok && !(parallel && num < 0.0f);
+            const bool upper = !parallel && den >= 0.0f;
+            const bool lower = !parallel && !(den >= 0.0f);
+            t_hi = (upper && t < t_hi) ? t : t_hi;
+            t_lo = (lower && t_lo < t) ? t : t_lo;
+            ok = ok && !(t_lo > t_hi);
         }
     }
-    if (!ok) return false;
     float t = dx * (ox - px) + dy * (oy - py);
-    if (t < t_lo) {
-        t = t_lo;
-    } else if (t > t_hi) {
-        t = t_hi;
-    }
-    rx = px + t * dx;
-    ry = py + t * dy;
-    return true;
+    t = (t < t_lo) ? t_lo : ((t > t_hi) ? t_hi : t);
+    rx = ok ? px + t * dx : rx;
+    ry = ok ? py + t * dy : ry;
+    return ok;
 }
 
 // 2-D program over the first n of MAXL register-resident half-planes; returns the first infeasible index or n.

@@ -33,7 +33,6 @@ struct Params {
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double robot_safety, human_safety;
     OrcaParams orca;
-    ScenarioCfg scen;
 };
 
 struct StateView {
@@ -260,20 +259,6 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     }
 }
 
-// crowd_sim/envs/utils/utils.py:4-26 with (x3, y3) = (0, 0)
-__device__ __forceinline__ double point_to_segment_origin(double x1, double y1, double x2, double y2) {
-    const double sx = x2 - x1, sy = y2 - y1;
-    if (sx == 0.0 && sy == 0.0) return norm2(0.0 - x1, 0.0 - y1);
-    double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
-    if (u > 1.0) {
-        u = 1.0;
-    } else if (u < 0.0) {
-        u = 0.0;
-    }
-    const double x = x1 + u * sx, y = y1 + u * sy;
-    return norm2(x - 0.0, y - 0.0);
-}
-
 struct StepResult {  // meaningful on the robot lane
     double reward, dmin, ax, ay;
     uint8_t done, info;
@@ -299,33 +284,47 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
     }
     __syncthreads();
 
-    // swept robot-human collision over the step: human's CURRENT velocity vs the robot's NEW action
-    // (crowd_sim.py:331-351)
-    if (L.valid && L.a > 0) {
+    // One float64 distance per agent lane, computed branch-free so that humans and the robot share the
+    // instruction stream:
+    //   human: swept robot-human distance over the step, human's CURRENT velocity vs the robot's NEW action
+    //          = point_to_segment_dist(px, py, ex, ey, 0, 0) - r_h - r_r      (crowd_sim.py:331-351)
+    //   robot: distance of its end position to its goal                       (crowd_sim.py:364-366)
+    double goal_dist = 0.0;
+    if (L.valid) {
+        const bool human = L.a > 0;
         const double2 rp = s.posd[L.ebase];
         const double2 act = s.act[L.ebase];
-        const double rx = r.px - rp.x, ry = r.py - rp.y;
+        const double x1 = r.px - rp.x, y1 = r.py - rp.y;
         const double wx = r.vx - act.x, wy = r.vy - act.y;
-        const double ex = rx + wx * P.dt, ey = ry + wy * P.dt;
-        s.closest[L.lane] = point_to_segment_origin(rx, ry, ex, ey) - r.rad - s.rad[L.ebase];
+        const double x2 = x1 + wx * P.dt, y2 = y1 + wy * P.dt;
+        const double sx = x2 - x1, sy = y2 - y1;
+        double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
+        u = (u > 1.0) ? 1.0 : ((u < 0.0) ? 0.0 : u);
+        const bool degenerate = (sx == 0.0 && sy == 0.0);  // utils.py:11-13
+        const double cx = degenerate ? 0.0 - x1 : (x1 + u * sx) - 0.0;
+        const double cy = degenerate ? 0.0 - y1 : (y1 + u * sy) - 0.0;
+        const double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+        const double d = norm2(human ? cx : endx - r.gx, human ? cy : endy - r.gy);
+        if (human) {
+            s.closest[L.lane] = d - r.rad - s.rad[L.ebase];
+        } else {
+            goal_dist = d;
+        }
     }
     __syncthreads();
 
     res.done = 0;
     if (L.valid && L.a == 0) {
+        // the reference stops scanning at the first colliding human (dmin keeps the minimum seen before it)
         double dmin = std::numeric_limits<double>::infinity();
         bool collision = false;
-        for (int i = 1; i < P.A; ++i) {  // the reference stops at the first colliding human; dmin is unused then
+        for (int i = 1; i < P.A; ++i) {
             const double c = s.closest[L.lane + i];
-            if (c < 0.0) {
-                collision = true;
-                break;
-            } else if (c < dmin) {
-                dmin = c;
-            }
+            const bool hit = c < 0.0;
+            dmin = (!collision && !hit && c < dmin) ? c : dmin;
+            collision = collision || hit;
         }
-        const double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
-        const bool reaching = norm2(endx - r.gx, endy - r.gy) < r.rad;
+        const bool reaching = goal_dist < r.rad;
         if (gtime >= P.time_limit - 1.0) {
             res.reward = 0.0, res.done = 1, res.info = CN_TIMEOUT;
         } else if (collision) {
@@ -420,13 +419,13 @@ __global__ __launch_bounds__(kWave) void step_kernel(Params P, StateView S, Step
 }
 
 // np.random.seed(seed) + scenario of one env per lane (lane = env)
-__global__ __launch_bounds__(kWave) void reset_kernel(Params P, StateView S, const uint32_t* seeds,
+__global__ __launch_bounds__(kWave) void reset_kernel(Params P, ScenarioCfg C, StateView S, const uint32_t* seeds,
                                                      const uint8_t* mask, uint64_t* draws) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
     if (mask && !mask[b]) return;
     Mt19937 rng{S.mt_key + b, P.B, 0};
-    const uint64_t n = generate_scenario(P.scen, rng, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+    const uint64_t n = generate_scenario(C, rng, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
     S.mt_pos[b] = rng.pos;
     S.gtime[b] = 0.0;
     if (draws) draws[b] = n;
@@ -439,11 +438,17 @@ __global__ void mt_probe_kernel(uint32_t* key, uint32_t seed, int n, double* out
     for (int i = 0; i < n; ++i) out[i] = rng.random();
 }
 
+// Rollout bookkeeping lives behind ONE pointer to a device copy of the caller's cn_rollout_io: the ~20
+// pointers in it are needed only when an episode ends, and keeping them out of the kernel arguments keeps
+// them out of the SGPR file of the step loop.
 struct RolloutView {
-    cn_rollout_io io;
+    const cn_rollout_io* io;
     const double* discount;  // [discount_len]
     int discount_len;
 };
+
+// io.active[] states
+enum { kRetired = 0, kRunning = 1, kWaitingScenario = 2 };
 
 __device__ __forceinline__ int64_t episode_id(const cn_rollout_io& io, int b, int ordinal) {
     return io.env_offset + b + (int64_t)ordinal * io.env_stride;
@@ -453,13 +458,13 @@ __device__ __forceinline__ uint32_t episode_seed(const cn_rollout_io& io, int64_
 }
 
 // (re)start bookkeeping: env b begins its episode ordinal 0
-__global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, StateView S, RolloutView R) {
+__global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
-    const cn_rollout_io& io = R.io;
+    const cn_rollout_io io = *R.io;
     const int64_t c0 = episode_id(io, b, 0);
     const bool on = io.episode_limit < 0 || c0 < io.episode_limit;
-    io.active[b] = on ? 1 : 0;
+    io.active[b] = on ? kRunning : kRetired;
     io.ep_count[b] = 0;
     io.cur_steps[b] = 0;
     io.cur_return[b] = 0.0;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, StateVie
     S.ring_filled_out[b] = 0;
     if (!on) return;
     Mt19937 rng{S.mt_key + b, P.B, 0};
-    generate_scenario(P.scen, rng, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+    generate_scenario(C, rng, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
     S.mt_pos[b] = rng.pos;
     S.gtime[b] = 0.0;
 }
@@ -477,30 +482,65 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, StateVie
 // Scenario ring fill: one lane per (env, ring slot) generates the episode whose ordinal maps to that slot
 // if it has not been generated yet, so that ordinals [next, next + D) are resident when the rollout
 // launch that follows needs them.  Fully parallel and coalesced (generator state is [624][B*D]).
-__global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, StateView S, RolloutView R) {
+__global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int D = P.ring_depth;
     if (idx >= P.B * D) return;
     const int b = idx / D, slot = idx - b * D;
-    const cn_rollout_io& io = R.io;
-    const int next = io.ep_count[b] + 1;  // first ordinal the rollout may still ask for
+    const cn_rollout_io io = *R.io;
+    const int state = io.active[b];
+    // first ordinal the rollout may still ask for (an env waiting for a scenario has not consumed ep_count yet)
+    const int next = io.ep_count[b] + (state == kWaitingScenario ? 0 : 1);
     if (slot == 0) S.ring_filled_out[b] = next + D;
-    if (!io.active[b]) return;
+    if (state == kRetired) return;
     const int ordinal = next + ((slot - next % D) + D) % D;
     if (ordinal < S.ring_filled_in[b]) return;  // still resident from an earlier fill
     const int64_t c = episode_id(io, b, ordinal);
     if (io.episode_limit >= 0 && c >= io.episode_limit) return;
     Mt19937 rng{S.ring_mt_key + idx, P.B * D, 0};
-    generate_scenario(P.scen, rng, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr,
-                      S.ring_goal, S.ring_rv);
+    generate_scenario(C, rng, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr, S.ring_goal,
+                      S.ring_rv);
 }
 
-// n_steps transitions per active env in one launch; state lives in VGPRs between steps, finished envs pick
-// their next scenario from the ring (or, if the ring ran dry, generate it in place).
+__device__ __forceinline__ void load_from_ring(const Params& P, const StateView& S, const Lane& L, int slot,
+                                               AgentRegs& r) {
+    const size_t ri = ((size_t)L.env * P.ring_depth + slot) * P.A + L.a;
+    const double2 p = S.ring_pos[ri], g = S.ring_goal[ri], q = S.ring_rv[ri];
+    r.px = p.x, r.py = p.y, r.vx = 0.0, r.vy = 0.0, r.gx = g.x, r.gy = g.y, r.rad = q.x, r.vpref = q.y;
+}
+
+// Episode end on the robot lane (explorer.py:50-72): append the record, pick the next episode.  Returns the
+// per-env flag: 0 = stop stepping (retired, or waiting for the ring to be refilled), 2 + slot = load ring slot.
+__device__ __forceinline__ int finish_episode(const RolloutView R, int env, int ring_depth, int ring_filled,
+                                          double time_limit, int info, double gtime, int& ep_count,
+                                          int cur_steps, double cur_return, int cur_danger, double cur_dsum,
+                                          int& state) {
+    const cn_rollout_io io = *R.io;
+    if (io.record_capacity > 0) {
+        const size_t k = (size_t)env * io.record_capacity + (ep_count % io.record_capacity);
+        if (io.ep_outcome) io.ep_outcome[k] = (uint8_t)info;
+        if (io.ep_steps) io.ep_steps[k] = cur_steps;
+        if (io.ep_return) io.ep_return[k] = cur_return;
+        if (io.ep_time) io.ep_time[k] = (info == CN_TIMEOUT) ? time_limit : gtime;
+        if (io.ep_danger) io.ep_danger[k] = cur_danger;
+        if (io.ep_danger_dmin_sum) io.ep_danger_dmin_sum[k] = cur_dsum;
+    }
+    ++ep_count;
+    const int64_t c = episode_id(io, env, ep_count);
+    if (io.episode_limit >= 0 && c >= io.episode_limit) {
+        state = kRetired;
+        return 0;
+    }
+    if (ep_count < ring_filled) return 2 + ep_count % ring_depth;
+    state = kWaitingScenario;  // ring ran dry: pause this env until the next launch has refilled it
+    return 0;
+}
+
+// Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs
+// take their next scenario from the ring.
 template <int MAXL>
 __global__ __launch_bounds__(kWave) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps) {
     const Smem s = carve(P);
-    const cn_rollout_io& io = R.io;
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);
@@ -510,35 +550,39 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(Params P, StateView S, R
 
     const bool robot = L.valid && L.a == 0;
     double gtime = 0.0, cur_return = 0.0, cur_dsum = 0.0;
-    int cur_steps = 0, cur_danger = 0, ep_count = 0, ring_filled = 0;
-    bool active = false;
+    int cur_steps = 0, cur_danger = 0, ep_count = 0, ring_filled = 0, state = kRetired;
     if (robot) {
+        const cn_rollout_io io = *R.io;
         gtime = S.gtime[L.env];
-        active = io.active[L.env] != 0;
+        state = io.active[L.env];
         ep_count = io.ep_count[L.env];
         cur_steps = io.cur_steps[L.env];
         cur_return = io.cur_return[L.env];
         if (io.cur_danger) cur_danger = io.cur_danger[L.env];
         if (io.cur_danger_dmin_sum) cur_dsum = io.cur_danger_dmin_sum[L.env];
         ring_filled = S.ring_filled_in[L.env];
+        int f = state == kRunning ? 1 : 0;
+        if (state == kWaitingScenario && ep_count < ring_filled) {  // the fill kernel has just produced it
+            f = 2 + ep_count % P.ring_depth;
+            state = kRunning;
+            gtime = 0.0;
+        }
+        s.flag[L.lane] = f;
     }
-    unsigned long long transitions = 0;
-    if (robot) s.flag[L.lane] = active ? 1 : 0;
     __syncthreads();
+    if (L.valid && s.flag[L.ebase] >= 2) load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+    unsigned int transitions = 0;
 
     for (int step = 0; step < n_steps; ++step) {
         Lane Ls = L;
-        Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env still has episodes to run
+        Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env is running
 
         StepResult res;
         double nvx, nvy;
         step_core<MAXL>(P, s, Ls, r, gtime, robot_max_speed, nullptr, 1, res, nvx, nvy);
 
-        // flag: 1 = keep going, 0 = env retired, 2 + slot = load next scenario from ring slot,
-        //       -1 = next scenario was generated in place into the state arrays
-        int next_flag = 0;
-        if (robot && active) {
-            next_flag = 1;
+        if (robot && state == kRunning) {
+            int next_flag = 1;
             ++transitions;
             const double disc = cur_steps < R.discount_len ? R.discount[cur_steps] : 0.0;
             cur_return = cur_return + disc * res.reward;  // python sum(): left to right
@@ -548,46 +592,15 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(Params P, StateView S, R
                 cur_dsum += res.dmin;
             }
             if (res.done) {
-                if (io.record_capacity > 0) {
-                    const size_t k = (size_t)L.env * io.record_capacity + (ep_count % io.record_capacity);
-                    if (io.ep_outcome) io.ep_outcome[k] = res.info;
-                    if (io.ep_steps) io.ep_steps[k] = cur_steps;
-                    if (io.ep_return) io.ep_return[k] = cur_return;
-                    if (io.ep_time) io.ep_time[k] = (res.info == CN_TIMEOUT) ? P.time_limit : gtime;
-                    if (io.ep_danger) io.ep_danger[k] = cur_danger;
-                    if (io.ep_danger_dmin_sum) io.ep_danger_dmin_sum[k] = cur_dsum;
-                }
-                ++ep_count;
+                next_flag = finish_episode(R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
+                                           cur_steps, cur_return, cur_danger, cur_dsum, state);
                 cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
-                const int64_t c = episode_id(io, L.env, ep_count);
-                if (io.episode_limit >= 0 && c >= io.episode_limit) {
-                    active = false;
-                    next_flag = 0;
-                } else if (ep_count < ring_filled) {
-                    next_flag = 2 + ep_count % P.ring_depth;
-                    gtime = 0.0;
-                } else {
-                    Mt19937 rng{S.mt_key + L.env, P.B, 0};
-                    generate_scenario(P.scen, rng, episode_seed(io, c), (size_t)L.env * P.A, S.pos, S.vel, S.goal,
-                                      S.rv);
-                    S.mt_pos[L.env] = rng.pos;
-                    gtime = 0.0;
-                    next_flag = -1;
-                }
+                gtime = 0.0;
             }
+            s.flag[L.lane] = next_flag;
         }
-        if (robot) s.flag[L.lane] = next_flag;
         __syncthreads();
-        if (L.valid) {
-            const int f = s.flag[L.ebase];
-            if (f >= 2) {
-                const size_t ri = ((size_t)L.env * P.ring_depth + (f - 2)) * P.A + L.a;
-                const double2 p = S.ring_pos[ri], g = S.ring_goal[ri], q = S.ring_rv[ri];
-                r.px = p.x, r.py = p.y, r.vx = 0.0, r.vy = 0.0, r.gx = g.x, r.gy = g.y, r.rad = q.x, r.vpref = q.y;
-            } else if (f < 0) {
-                load_agent(S, L.gi, r);
-            }
-        }
+        if (L.valid && s.flag[L.ebase] >= 2) load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
     }
 
     if (L.valid) {
@@ -597,15 +610,16 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(Params P, StateView S, R
         S.rv[L.gi] = make_double2(r.rad, r.vpref);
     }
     if (robot) {
+        const cn_rollout_io io = *R.io;
         S.gtime[L.env] = gtime;
         S.rsim_valid[L.env] = 1;
-        io.active[L.env] = active ? 1 : 0;
+        io.active[L.env] = (uint8_t)state;
         io.ep_count[L.env] = ep_count;
         io.cur_steps[L.env] = cur_steps;
         io.cur_return[L.env] = cur_return;
         if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
-        if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, transitions);
+        if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, (unsigned long long)transitions);
     }
 }
 
