@@ -57,6 +57,16 @@ class CnRolloutIo(C.Structure):
     ]
 
 
+class CnSarlConfig(C.Structure):
+    """struct cn_sarl_config (include/crowdnav_amd.h)."""
+    _fields_ = [
+        ('n_actions', C.c_int32), ('with_om', C.c_int32), ('cell_num', C.c_int32), ('om_channel_size', C.c_int32),
+        ('cell_size', C.c_double), ('gamma', C.c_double), ('with_global_state', C.c_int32),
+        ('mlp1_dims', C.c_int32 * 2), ('mlp2_dims', C.c_int32 * 2), ('attention_dims', C.c_int32 * 3),
+        ('mlp3_dims', C.c_int32 * 4), ('reserved', C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/crowdnav_amd.h declares
 _P = C.c_void_p
 SYMBOLS = {
@@ -75,6 +85,10 @@ SYMBOLS = {
     'cn_set_gamma': (C.c_int, [_P, C.c_double]),
     'cn_rollout_begin': (C.c_int, [_P, C.POINTER(CnRolloutIo)]),
     'cn_rollout': (C.c_int, [_P, C.POINTER(CnRolloutIo), C.c_int]),
+    'cn_sarl_configure': (C.c_int, [_P, C.POINTER(CnSarlConfig), _P]),
+    'cn_sarl_set_weights': (C.c_int, [_P, C.POINTER(_P)]),
+    'cn_sarl_select': (C.c_int, [_P, _P, _P, _P]),
+    'cn_sarl_export': (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
     'cn_mt_random': (C.c_int, [_P, C.c_uint32, C.c_int, _P]),
 }
 

@@ -24,6 +24,7 @@
 
 #include "../../include/crowdnav_amd.h"
 #include "step_kernels.h"
+#include "sarl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ C ABI
 
@@ -58,6 +59,7 @@ struct cn_engine {
     cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
     cn_rollout_io* io_dev;   // device copy the rollout kernels read through
     bool io_valid;
+    struct cn_sarl* sarl;    // SARL decision state (sarl_abi.inc), NULL until cn_sarl_configure
     double* discount;
     int discount_len;
     uint32_t* probe_key;
@@ -133,6 +135,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->cfg = *c;
     e->stream = nullptr;
     e->io_valid = false;
+    e->sarl = nullptr;
     cn::Params& P = e->P;
     P.B = c->num_envs;
     P.A = c->num_humans + 1;
@@ -200,12 +203,15 @@ int cn_create(const cn_config* c, cn_engine** out) {
     return rc;
 }
 
+static void sarl_release(cn_engine* e);
+
 int cn_destroy(cn_engine* e) {
     if (!e) return CN_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->discount) (void)hipFree(e->discount);
+    sarl_release(e);
     delete e;
     return CN_OK;
 }
@@ -383,3 +389,5 @@ int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out) {
 }
 
 }  // extern "C"
+
+#include "sarl_abi.inc"

@@ -1,0 +1,422 @@
+// SARL robot decision on device — replaces, batched over B envs x K candidate actions,
+//   MultiHumanRL.predict                     /root/reference crowd_nav/policy/multi_human_rl.py:11-63
+//   CrowdSim.onestep_lookahead (reward part) crowd_sim/envs/crowd_sim.py:314-389 (via step_core-compatible code)
+//   CADRL.propagate / rotate                 crowd_nav/policy/cadrl.py:104-129, 187-222
+//   MultiHumanRL.build_occupancy_maps        multi_human_rl.py:109-163
+//   sarl.ValueNetwork.forward                crowd_nav/policy/sarl.py:28-65 (mlp(): cadrl.py:11-19)
+//
+// Kernels (launched back to back on the engine's stream by cn_sarl_select):
+//   orca_kernel            (step_kernels.h) the humans' next velocities — computed ONCE per env: they do not
+//                          depend on the candidate action
+//   sarl_lookahead_kernel  lane = env: next human observable states (float64) and, with_om, their occupancy maps
+//   sarl_reward_kernel     lane = (env, action): float64 reward of onestep_lookahead(action)
+//   sarl_feature_kernel    lane = (env, action, human): float32 rotated 13-vector (+48 map values) -> X
+//   sarl_mlp_kernel        workgroup = 16 (env, action) groups x H humans: the whole value network on FP32 MFMA
+//                          (v_mfma_f32_16x16x4_f32: exact f32, k-ordered fma chain), activations in LDS
+//   sarl_select_kernel     lane = env: value = reward + gamma^(dt v_pref) * V, first strict maximum
+//
+// Row order inside an MLP tile is HUMAN-MAJOR: row = h * 16 + g (g = group within the tile).  A 16-row MFMA
+// tile then holds human h of 16 different groups, so the per-group reductions of the network (mean over
+// humans, masked softmax over humans, weighted feature sum) combine values that sit at the same lane / same
+// accumulator register of different row tiles — no cross-lane traffic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scenario_device.h"  // norm2
+
+namespace cn {
+
+constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
+constexpr int kSarlMaxHumans = 8;    // LDS budget of the fused MLP kernel (H = 5 in every BASELINE config)
+constexpr int kSarlThreads = 256;    // 4 waves per MLP workgroup
+constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One packed linear layer: B-operand fragments of v_mfma_f32_16x16x4_f32, fragment (ct, ks) at
+// w[(ct * ksteps + ks) * 64 + lane] = W[n = ct*16 + (lane & 15)][k = ks*4 + (lane >> 4)] (0 outside), so a wave
+// fetches a fragment with one coalesced 256-byte load; bias padded to ctiles * 16.
+struct PackedLinear {
+    const float* w;
+    const float* bias;
+    int K, N;       // true sizes
+    int ksteps;     // ceil(K / 4)
+    int ctiles;     // ceil(N / 16)
+};
+
+enum {
+    kL_mlp1_0, kL_mlp1_2, kL_mlp2_0, kL_mlp2_2, kL_att0_local, kL_att0_global, kL_att_2, kL_att_4,
+    kL_mlp3_0, kL_mlp3_2, kL_mlp3_4, kL_mlp3_6
+};
+
+struct SarlNet {
+    PackedLinear L[kSarlLayers];
+    int in_dim;        // 13 or 13 + cell_num^2 * om_channel_size
+    int with_global;   // sarl.py:17-21
+    int H;
+    // LDS leading dimensions (floats); every ld is == 4 (mod 8) to spread the accumulator stores over banks
+    int ld_x, ld_a, ld_b, ld_c;
+};
+
+struct SarlCfg {
+    int B, H, n_actions;
+    int with_om, cell_num, om_channels;
+    double cell_size;
+    double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
+    double gamma_bar;  // pow(gamma, time_step * v_pref), computed on the host like multi_human_rl.py:52
+};
+
+// torch.nn.Linear weight [N][K] (row-major) -> MFMA B fragments
+__global__ void sarl_pack_kernel(const float* W, const float* bias, int N, int K, int k_offset, int k_count,
+                                 int ksteps, int ctiles, float* wp, float* bp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = ctiles * ksteps * 64;
+    if (idx < total) {
+        const int lane = idx & 63;
+        const int frag = idx >> 6;
+        const int ct = frag / ksteps, ks = frag - ct * ksteps;
+        const int n = ct * 16 + (lane & 15);
+        const int k = ks * 4 + (lane >> 4);
+        wp[idx] = (n < N && k < k_count) ? W[(size_t)n * K + k_offset + k] : 0.0f;
+    }
+    if (idx < ctiles * 16) bp[idx] = (bias && idx < N) ? bias[idx] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------ lookahead / reward
+// Next observable state of every human (get_next_observable_state, agent.py:63-74) from the ORCA velocities,
+// and (with_om) the occupancy map each human would see (multi_human_rl.py:109-163; robot excluded).
+__global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const double2* rv, const float* orca_vel,
+                                      double* next_obs /*[B][H][5]*/, float* om /*[B][H][cells*ch]*/) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C.B * C.H) return;
+    const int b = idx / C.H, i = idx - b * C.H;
+    const int A = C.H + 1;
+    auto next_of = [&](int j, double& px, double& py, double& vx, double& vy) {
+        const size_t gj = (size_t)b * A + 1 + j;
+        vx = orca_vel[2 * gj], vy = orca_vel[2 * gj + 1];
+        px = pos[gj].x + vx * C.dt, py = pos[gj].y + vy * C.dt;
+    };
+    double px, py, vx, vy;
+    next_of(i, px, py, vx, vy);
+    double* o = next_obs + (size_t)idx * 5;
+    o[0] = px, o[1] = py, o[2] = vx, o[3] = vy, o[4] = rv[(size_t)b * A + 1 + i].x;
+    if (!C.with_om) return;
+
+    const int cells = C.cell_num * C.cell_num;
+    const int ch = C.om_channels;
+    float* m = om + (size_t)idx * cells * ch;
+    const double my_angle = atan2(vy, vx);
+    // per cell: count, sum vx', sum vy' in visit order (python sum(): 0 + x1 + x2 ...)
+    for (int cell = 0; cell < cells; ++cell) {
+        double cnt = 0.0, svx = 0.0, svy = 0.0;
+        for (int j = 0; j < C.H; ++j) {
+            if (j == i) continue;
+            double qx, qy, wx, wy;
+            next_of(j, qx, qy, wx, wy);
+            const double ox = qx - px, oy = qy - py;
+            const double rotation = atan2(oy, ox) - my_angle;
+            const double dist = sqrt(ox * ox + oy * oy);
+            const double rx = cos(rotation) * dist, ry = sin(rotation) * dist;
+            const double xi = floor(rx / C.cell_size + C.cell_num / 2.0);
+            const double yi = floor(ry / C.cell_size + C.cell_num / 2.0);
+            if (xi < 0 || xi >= C.cell_num || yi < 0 || yi >= C.cell_num) continue;
+            if ((int)(C.cell_num * yi + xi) != cell) continue;
+            const double vrot = atan2(wy, wx) - my_angle;
+            const double speed = sqrt(wx * wx + wy * wy);
+            cnt += 1.0;
+            svx += cos(vrot) * speed;
+            svy += sin(vrot) * speed;
+        }
+        if (ch == 1) {
+            m[cell] = cnt > 0.0 ? 1.0f : 0.0f;
+        } else if (ch == 2) {
+            m[2 * cell] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
+            m[2 * cell + 1] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
+        } else {
+            m[3 * cell] = cnt > 0.0 ? (float)(cnt / cnt) : 0.0f;
+            m[3 * cell + 1] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
+            m[3 * cell + 2] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
+        }
+    }
+}
+
+// Reward of onestep_lookahead(action) for every (env, action) (crowd_sim.py:331-389, update = False).
+__global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* goal,
+                                   const double2* rv, const double* gtime, const double* actions /*[K][2]*/,
+                                   double* reward /*[B][K]*/) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C.B * C.n_actions) return;
+    const int b = idx / C.n_actions, a = idx - b * C.n_actions;
+    const int A = C.H + 1;
+    const size_t g0 = (size_t)b * A;
+    const double ax = actions[2 * a], ay = actions[2 * a + 1];
+    const double2 rp = pos[g0];
+    const double rrad = rv[g0].x;
+    double dmin = __builtin_inf();
+    bool collision = false;
+    for (int i = 1; i < A; ++i) {
+        const double2 hp = pos[g0 + i], hv = vel[g0 + i];
+        const double x1 = hp.x - rp.x, y1 = hp.y - rp.y;
+        const double wx = hv.x - ax, wy = hv.y - ay;
+        const double x2 = x1 + wx * C.dt, y2 = y1 + wy * C.dt;
+        const double sx = x2 - x1, sy = y2 - y1;
+        double d;
+        if (sx == 0.0 && sy == 0.0) {
+            d = norm2(0.0 - x1, 0.0 - y1);
+        } else {
+            double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
+            u = (u > 1.0) ? 1.0 : ((u < 0.0) ? 0.0 : u);
+            d = norm2((x1 + u * sx) - 0.0, (y1 + u * sy) - 0.0);
+        }
+        const double c = d - rv[g0 + i].x - rrad;
+        if (c < 0.0) {
+            collision = true;
+            break;
+        } else if (c < dmin) {
+            dmin = c;
+        }
+    }
+    const double endx = rp.x + ax * C.dt, endy = rp.y + ay * C.dt;
+    const double2 gl = goal[g0];
+    const bool reaching = norm2(endx - gl.x, endy - gl.y) < rrad;
+    double r;
+    if (gtime[b] >= C.time_limit - 1.0) {
+        r = 0.0;
+    } else if (collision) {
+        r = C.collision_penalty;
+    } else if (reaching) {
+        r = C.success_reward;
+    } else if (dmin < C.discomfort_dist) {
+        r = (dmin - C.discomfort_dist) * C.discomfort_factor * C.dt;
+    } else {
+        r = 0.0;
+    }
+    reward[idx] = r;
+}
+
+// ------------------------------------------------------------------------------------ features
+// X row of (env b, action a, human h): CADRL.rotate of the float32 joint row
+// [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written in MLP tile order:
+// group G = b * K + a -> tile G / 16, g = G % 16, row = h * 16 + g, X[(tile * 16 * H + row) * ld_x + feature].
+__global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ld_x, const double2* pos, const double2* goal,
+                                    const double2* rv, const double* actions, const double* next_obs,
+                                    const float* om, float* X) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rows = (size_t)C.B * C.n_actions * C.H;
+    if (idx >= rows) return;
+    const int h = (int)(idx % C.H);
+    const size_t G = idx / C.H;
+    const int a = (int)(G % C.n_actions);
+    const int b = (int)(G / C.n_actions);
+    const size_t g0 = (size_t)b * (C.H + 1);
+    // propagate(self_state, action) in float64 (cadrl.py:113-118), then torch.Tensor([...]) narrows to float32
+    const double ax = actions[2 * a], ay = actions[2 * a + 1];
+    const float px = (float)(pos[g0].x + ax * C.dt), py = (float)(pos[g0].y + ay * C.dt);
+    const float vx = (float)ax, vy = (float)ay;
+    const float radius = (float)rv[g0].x, v_pref = (float)rv[g0].y;
+    const float gx = (float)goal[g0].x, gy = (float)goal[g0].y;
+    const double* o = next_obs + ((size_t)b * C.H + h) * 5;
+    const float px1 = (float)o[0], py1 = (float)o[1], vx1 = (float)o[2], vy1 = (float)o[3], radius1 = (float)o[4];
+    // CADRL.rotate (cadrl.py:195-221), float32, one rounding per torch op
+    const float dx = gx - px, dy = gy - py;
+    const float rot = atan2f(dy, dx);
+    const float dg = sqrtf(dx * dx + dy * dy);
+    const float c = cosf(rot), s = sinf(rot);
+    float f[13];
+    f[0] = dg;
+    f[1] = v_pref;
+    f[2] = 0.0f;  // theta: unused for holonomic robots
+    f[3] = radius;
+    f[4] = vx * c + vy * s;
+    f[5] = vy * c - vx * s;
+    f[6] = (px1 - px) * c + (py1 - py) * s;
+    f[7] = (py1 - py) * c - (px1 - px) * s;
+    f[8] = vx1 * c + vy1 * s;
+    f[9] = vy1 * c - vx1 * s;
+    f[10] = radius1;
+    const float ex = px - px1, ey = py - py1;
+    f[11] = sqrtf(ex * ex + ey * ey);
+    f[12] = radius + radius1;
+    const size_t tile = G / kSarlGroups;
+    const int g = (int)(G % kSarlGroups);
+    float* x = X + ((tile * kSarlGroups * C.H) + (size_t)h * kSarlGroups + g) * ld_x;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) x[k] = f[k];
+    const int extra = in_dim - 13;
+    const float* m = om + ((size_t)b * C.H + h) * (extra > 0 ? extra : 0);
+    for (int k = 0; k < extra; ++k) x[13 + k] = m[k];
+    for (int k = in_dim; k < ld_x; ++k) x[k] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------ value network
+// Dense layer on MFMA: out[r][n] = act(bias[n] + extra[g][n] + sum_k in[r][k] W[n][k]) for r in [0, RT*16).
+// A wave owns whole column tiles (ct = wave, wave + 4, ...) and all RT row tiles of them: per k-step it reads
+// RT A fragments from LDS and ONE B fragment from L2 and issues RT independent MFMAs.
+template <int RT>
+__device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* in, int ld_in, float* out, int ld_out,
+                                           bool relu, const float* extra, int ld_extra, int wave, int lane) {
+    const int col = lane & 15, quad = lane >> 4;
+    for (int ct = wave; ct < P.ctiles; ct += kSarlThreads / 64) {
+        f32x4 acc[RT];
+        const float b0 = P.bias[ct * 16 + col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            // accumulator element i of this lane is row quad*4 + i of the tile = group quad*4 + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[rt][i] = b0 + (extra ? extra[(quad * 4 + i) * ld_extra + ct * 16 + col] : 0.0f);
+        }
+        const float* wfrag = P.w + (size_t)ct * P.ksteps * 64 + lane;
+        const float* arow = in + col * ld_in + quad;  // A[l & 15][k = l >> 4]
+        for (int ks = 0; ks < P.ksteps; ++ks) {
+            const float bfrag = wfrag[(size_t)ks * 64];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float afrag = arow[(rt * 16) * ld_in + ks * 4];
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag, bfrag, acc[rt], 0, 0, 0);
+            }
+        }
+        const int n = ct * 16 + col;
+        if (n < P.N) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[rt][i];
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    out[(rt * 16 + quad * 4 + i) * ld_out + n] = v;
+                }
+            }
+        }
+    }
+}
+
+__host__ __device__ inline int sarl_ld(int n) {  // smallest ld >= n with ld % 8 == 4
+    int ld = (n + 3) / 4 * 4;
+    while (ld % 8 != 4) ld += 4;
+    return ld;
+}
+
+// Whole sarl.ValueNetwork.forward for one tile of 16 groups x H humans; X in tile order, V[group] out.
+template <int H>
+__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+    extern __shared__ float lds[];
+    constexpr int R = H * kSarlGroups;  // rows of the tile
+    float* bufA = lds;                       // [R][ld_a]  widest hidden layer
+    float* bufB = bufA + R * net.ld_a;       // [R][ld_b]  mlp1 output (h2) / X staging before that
+    float* bufC = bufB + R * net.ld_b;       // [R][ld_c]  mlp2 output (per-human feature)
+    float* gbuf = bufC + R * net.ld_c;       // [16][ld_b] mean over humans of h2, later its attention term
+    float* jbuf = gbuf + kSarlGroups * net.ld_b;  // [16][ld_a] joint state / mlp3 ping
+    float* kbuf = jbuf + kSarlGroups * net.ld_a;  // [16][ld_a] mlp3 pong
+    float* sbuf = kbuf + kSarlGroups * net.ld_a;  // [R] attention scores -> weights
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t tile = blockIdx.x;
+
+    // stage X (coalesced) into bufB's space with leading dimension ld_x
+    float* xs = bufB;
+    const float* xg = X + tile * R * net.ld_x;
+    for (int i = tid; i < R * net.ld_x; i += kSarlThreads) xs[i] = xg[i];
+    __syncthreads();
+    // self_state = state[:, 0, :6] (sarl.py:36): features 0..5 of human 0's row of each group
+    if (tid < kSarlGroups * 6) jbuf[(tid / 6) * net.ld_a + (tid % 6)] = xs[(tid / 6) * net.ld_x + (tid % 6)];
+
+    dense_mfma<H>(net.L[kL_mlp1_0], xs, net.ld_x, bufA, net.ld_a, true, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_mlp1_2], bufA, net.ld_a, bufB, net.ld_b, true, nullptr, 0, wave, lane);  // h2
+    __syncthreads();
+    // global state: mean over the humans of a group (sarl.py:42), sum in human order then / H
+    const int n1 = net.L[kL_mlp1_2].N;
+    if (net.with_global) {
+        for (int i = tid; i < kSarlGroups * n1; i += kSarlThreads) {
+            const int g = i / n1, c = i - g * n1;
+            float sum = 0.0f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) sum += bufB[(h * kSarlGroups + g) * net.ld_b + c];
+            gbuf[g * net.ld_b + c] = sum / (float)H;
+        }
+    }
+    dense_mfma<H>(net.L[kL_mlp2_0], bufB, net.ld_b, bufA, net.ld_a, true, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_mlp2_2], bufA, net.ld_a, bufC, net.ld_c, false, nullptr, 0, wave, lane);  // features
+    // attention layer 0 on [h2 | global]: the global half is the same for every human of a group, so it is
+    // one 16-row product (kbuf) added to every row tile's accumulator at the matching group row
+    if (net.with_global)
+        dense_mfma<1>(net.L[kL_att0_global], gbuf, net.ld_b, kbuf, net.ld_a, false, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_att0_local], bufB, net.ld_b, bufA, net.ld_a, true, net.with_global ? kbuf : nullptr,
+                  net.ld_a, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_att_2], bufA, net.ld_a, bufB, net.ld_b, true, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_att_4], bufB, net.ld_b, sbuf, 1, false, nullptr, 0, wave, lane);  // scores [R]
+    __syncthreads();
+    // masked softmax without max subtraction (sarl.py:52-53) + weighted feature sum (sarl.py:60)
+    if (tid < kSarlGroups) {
+        float e[H], total = 0.0f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float sc = sbuf[h * kSarlGroups + tid];
+            e[h] = expf(sc) * (sc != 0.0f ? 1.0f : 0.0f);
+            total += e[h];
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) sbuf[h * kSarlGroups + tid] = e[h] / total;
+    }
+    __syncthreads();
+    const int nf = net.L[kL_mlp2_2].N;
+    for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
+        const int g = i / nf, c = i - g * nf;
+        float sum = 0.0f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) sum += sbuf[h * kSarlGroups + g] * bufC[(h * kSarlGroups + g) * net.ld_c + c];
+        jbuf[g * net.ld_a + 6 + c] = sum;
+    }
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ld_a, kbuf, net.ld_a, true, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ld_a, jbuf, net.ld_a, true, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ld_a, kbuf, net.ld_a, true, nullptr, 0, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_6], kbuf, net.ld_a, sbuf, 1, false, nullptr, 0, wave, lane);
+    __syncthreads();
+    if (tid < kSarlGroups) {
+        const size_t G = tile * kSarlGroups + tid;
+        if (G < (size_t)n_groups) V[G] = sbuf[tid];
+    }
+}
+
+__host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
+    const size_t R = (size_t)net.H * kSarlGroups;
+    return sizeof(float) * (R * (net.ld_a + net.ld_b + net.ld_c) + kSarlGroups * (net.ld_b + 2 * net.ld_a) + R + 64);
+}
+
+// ------------------------------------------------------------------------------------ action selection
+// value = reward + pow(gamma, time_step * v_pref) * V (multi_human_rl.py:52); the first strict maximum wins (:54);
+// a robot already at its goal stops (:22-23, policy.py:43-49).  best = -1 encodes that stop action.
+__global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2* goal, const double2* rv,
+                                   const double* actions, const double* reward, const float* V, double* values,
+                                   int* best, double* action_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= C.B) return;
+    const size_t g0 = (size_t)b * (C.H + 1);
+    int arg = -1;
+    double best_v = -__builtin_inf();
+    for (int a = 0; a < C.n_actions; ++a) {
+        const double v = reward[(size_t)b * C.n_actions + a] + C.gamma_bar * (double)V[(size_t)b * C.n_actions + a];
+        if (values) values[(size_t)b * C.n_actions + a] = v;
+        if (v > best_v) {
+            best_v = v;
+            arg = a;
+        }
+    }
+    const double dy = pos[g0].y - goal[g0].y, dx = pos[g0].x - goal[g0].x;
+    const bool arrived = norm2(dy, dx) < rv[g0].x;  // np.linalg.norm((py - gy, px - gx))
+    if (arrived) arg = -1;
+    best[b] = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
+    action_out[2 * b] = arg >= 0 ? actions[2 * arg] : 0.0;
+    action_out[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
+}
+
+}  // namespace cn

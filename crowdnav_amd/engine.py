@@ -169,3 +169,75 @@ class BatchedCrowdSim(object):
         out = self._new((n,), torch.float64)
         check(self._lib.cn_mt_random(self._h, int(seed), int(n), _ptr(out)))
         return out
+
+
+# ---------------------------------------------------------------------------------------- SARL decision
+SARL_PARAM_ORDER = tuple('%s.%d.%s' % (m, i, p) for m, idxs in (('mlp1', (0, 2)), ('mlp2', (0, 2)),
+                                                               ('attention', (0, 2, 4)), ('mlp3', (0, 2, 4, 6)))
+                         for i in idxs for p in ('weight', 'bias'))
+
+
+def _sarl_configure(self, actions, gamma=0.9, with_om=False, cell_num=4, cell_size=1.0, om_channel_size=3,
+                    with_global_state=True, mlp1_dims=(150, 100), mlp2_dims=(100, 50), attention_dims=(100, 100, 1),
+                    mlp3_dims=(150, 100, 100, 1)):
+    """SARL.configure + build_action_space for this engine.  actions: [K, 2] float64 ActionXY table (host)."""
+    acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(-1, 2))
+    cfg = _lib.CnSarlConfig(n_actions=len(acts), with_om=int(bool(with_om)), cell_num=int(cell_num),
+                            om_channel_size=int(om_channel_size), cell_size=float(cell_size), gamma=float(gamma),
+                            with_global_state=int(bool(with_global_state)),
+                            mlp1_dims=(C.c_int32 * 2)(*mlp1_dims), mlp2_dims=(C.c_int32 * 2)(*mlp2_dims),
+                            attention_dims=(C.c_int32 * 3)(*attention_dims), mlp3_dims=(C.c_int32 * 4)(*mlp3_dims))
+    check(self._lib.cn_sarl_configure(self._h, C.byref(cfg), acts.ctypes.data_as(C.c_void_p)))
+    self.sarl = dict(n_actions=len(acts), in_dim=13 + (cell_num ** 2 * om_channel_size if with_om else 0),
+                     actions=acts)
+
+
+def _sarl_set_weights(self, state_dict):
+    """Hand the value network's parameters (sarl.ValueNetwork.state_dict()) to the device kernels."""
+    tensors = [state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+               for k in SARL_PARAM_ORDER]
+    ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    check(self._lib.cn_sarl_set_weights(self._h, ptrs))
+    self.sync()  # the temporaries above must outlive the repack kernels
+
+
+def _sarl_select(self, want_values=True):
+    """Greedy SARL action of every env: dict(values [B,K] f64, best [B] i32, action [B,2] f64)."""
+    K = self.sarl['n_actions']
+    out = dict(values=self._new((self.B, K), torch.float64) if want_values else None,
+               best=self._new((self.B,), torch.int32), action=self._new((self.B, 2), torch.float64))
+    check(self._lib.cn_sarl_select(self._h, _ptr(out['values']), _ptr(out['best']), _ptr(out['action'])))
+    return out
+
+
+def _sarl_export(self, name):
+    """Internal buffers of the last sarl_select (tests): reward, V, next_obs, om, X (natural [B,K,H,ld] order)."""
+    K, H = self.sarl['n_actions'], self.H
+    if name == 'reward':
+        t, which = self._new((self.B, K), torch.float64), 0
+    elif name == 'V':
+        t, which = self._new((self.B, K), torch.float32), 1
+    elif name == 'next_obs':
+        t, which = self._new((self.B, H, 5), torch.float64), 2
+    elif name == 'om':
+        t, which = self._new((self.B, H, self.sarl['in_dim'] - 13), torch.float32), 3
+    elif name == 'X':
+        ld = (self.sarl['in_dim'] + 3) // 4 * 4
+        while ld % 8 != 4:
+            ld += 4
+        groups = self.B * K
+        tiles = (groups + 15) // 16
+        t, which = self._new((tiles, H, 16, ld), torch.float32), 4
+    else:
+        raise KeyError(name)
+    check(self._lib.cn_sarl_export(self._h, which, _ptr(t), t.numel() * t.element_size()))
+    if name == 'X':  # tile order [tile][h][g][ld] -> [B, K, H, in_dim]
+        t = t.permute(0, 2, 1, 3).reshape(-1, H, t.shape[-1])[:self.B * K, :, :self.sarl['in_dim']]
+        t = t.reshape(self.B, K, H, -1)
+    return t
+
+
+BatchedCrowdSim.sarl_configure = _sarl_configure
+BatchedCrowdSim.sarl_set_weights = _sarl_set_weights
+BatchedCrowdSim.sarl_select = _sarl_select
+BatchedCrowdSim.sarl_export = _sarl_export

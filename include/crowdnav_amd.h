@@ -159,6 +159,44 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io);
  * CN_ROBOT_ORCA): n_steps transitions per active env in ONE launch, with in-kernel auto-reset. */
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
 
+/* ------------------------------------------------------------------------------------------------------
+ * SARL robot decision (crowd_nav/policy/sarl.py:9-86 on top of multi_human_rl.py:11-63, cadrl.py:82-222).
+ * Needs robot_policy == CN_ROBOT_EXTERNAL: the chosen action is then applied with cn_step(action). */
+typedef struct cn_sarl_config {
+    int32_t n_actions;          /* 81 = speed_samples * rotation_samples + 1 (cadrl.py:82-102) */
+    int32_t with_om;            /* [sarl] with_om: append the occupancy map (multi_human_rl.py:109-163) */
+    int32_t cell_num;           /* [om] cell_num */
+    int32_t om_channel_size;    /* [om] om_channel_size: 1, 2 or 3 */
+    double cell_size;           /* [om] cell_size */
+    double gamma;               /* [rl] gamma */
+    int32_t with_global_state;  /* [sarl] with_global_state */
+    int32_t mlp1_dims[2];       /* [sarl] mlp1_dims      (150, 100) */
+    int32_t mlp2_dims[2];       /* [sarl] mlp2_dims      (100, 50) */
+    int32_t attention_dims[3];  /* [sarl] attention_dims (100, 100, 1) */
+    int32_t mlp3_dims[4];       /* [sarl] mlp3_dims      (150, 100, 100, 1) */
+    int32_t reserved;
+} cn_sarl_config;
+
+/* replaces SARL.configure + CADRL.build_action_space: actions_host = double [n_actions][2] (ActionXY table, HOST
+ * pointer, computed by the caller exactly as cadrl.py:86-99 does).  Synchronous; once per engine. */
+int cn_sarl_configure(cn_engine* e, const cn_sarl_config* cfg, const double* actions_host);
+/* replaces model.load_state_dict: params_host_array = HOST array of 22 DEVICE pointers to the float32 tensors of
+ * sarl.ValueNetwork.state_dict() in its own order (mlp1.0.weight, mlp1.0.bias, mlp1.2.*, mlp2.0.*, mlp2.2.*,
+ * attention.0.*, attention.2.*, attention.4.*, mlp3.0.*, mlp3.2.*, mlp3.4.*, mlp3.6.*); weights are [out][in]
+ * row-major as torch stores them.  Repacked into MFMA operand order on device; call again after every optimizer
+ * step whose result the rollout should see. */
+int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array);
+/* replaces the greedy branch of MultiHumanRL.predict (multi_human_rl.py:32-58) for every env:
+ *   values  double [B][n_actions] (optional) reward(lookahead) + gamma^(dt*v_pref) * V(next state)
+ *   best    int32  [B] index of the first strict maximum; -1 = robot already at its goal -> stop action (:22-23);
+ *                  -2 = no finite value (the reference raises ValueError, :57-58)
+ *   action  double [B][2] the chosen ActionXY */
+int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action);
+/* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):
+ *   0 reward f64 [B][K] · 1 V f32 [B*K] · 2 next human states f64 [B][H][5] · 3 occupancy maps f32 [B][H][cells*ch]
+ *   4 X f32 in MLP tile order (see sarl_kernels.h) */
+int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes);
+
 /* numpy legacy RNG probe (np.random.seed(seed); n × np.random.random()): out double [n].  For tests. */
 int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out);
 

@@ -1,0 +1,102 @@
+"""SARL robot decision: the torch mirror of the value network (CPU) and the HIP pipeline behind cn_sarl_select
+(GPU) against fixtures produced by the unmodified reference SARL.predict (oracle/gen_golden_sarl.py).
+Tolerances (BASELINE north_star: positions/velocities 1e-5, here the float32 network): features 5e-6, network
+output and action values 2e-5 absolute (values are O(0.1)); the arg-max must agree whenever the reference's top
+two values are further apart than that tolerance.  Lookahead rewards and next human states are float64 env
+arithmetic and must be bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+FIXTURES = ['sarl_plain.npz', 'sarl_om.npz']
+
+
+def _mirror(g):
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    in_dim = 13 + (48 if int(g['with_om']) else 0)
+    net = ValueNetwork(in_dim, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    net.load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param_')})
+    return net
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_value_network_mirror_matches_reference_cpu(name):
+    g = load_golden(name)
+    net = _mirror(g)
+    assert sum(p.numel() for p in net.parameters()) == (103702 if int(g['with_om']) else 96502)
+    x = torch.from_numpy(g['inputs'])  # [decisions, 81, H, in_dim]
+    d, k, h, f = x.shape
+    with torch.no_grad():
+        out = net(x.reshape(d * k, h, f)).reshape(d, k).numpy()
+    assert np.abs(out - g['net_out']).max() <= 2e-6
+
+
+def test_action_space_matches_reference_cpu():
+    from crowdnav_amd.compat.sarl import build_action_space
+    g = load_golden('sarl_plain.npz')
+    space, speeds, rotations = build_action_space(1.0, 5, 16)
+    assert np.array_equal(np.array([[a.vx, a.vy] for a in space]), g['action_space'])
+    assert len(space) == 81 and speeds[-1] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', FIXTURES)
+def test_sarl_select_vs_reference(name):
+    import crowdnav_amd
+    g = load_golden(name)
+    n = len(g['states'])
+    with_om = bool(int(g['with_om']))
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                       robot_visible=int(g['robot_visible']))
+    eng.set_state(g['states'], g['gtime'])
+    eng.sarl_configure(actions=g['action_space'], gamma=0.9, with_om=with_om)
+    eng.sarl_set_weights(_mirror(g).state_dict())
+    out = eng.sarl_select()
+    eng.sync()
+    cpu = lambda t: t.cpu().numpy()  # noqa: E731
+    assert np.array_equal(cpu(eng.sarl_export('reward')), g['rewards'])          # float64 lookahead: exact
+    assert np.array_equal(cpu(eng.sarl_export('next_obs')), g['next_obs'])
+    X = cpu(eng.sarl_export('X'))
+    assert X.shape == g['inputs'].shape
+    assert np.abs(X[..., :13] - g['inputs'][..., :13]).max() <= 5e-6
+    if with_om:
+        assert np.abs(X[..., 13:] - g['inputs'][..., 13:]).max() <= 5e-6
+        assert np.abs(cpu(eng.sarl_export('om')) - g['inputs'][:, 0, :, 13:]).max() <= 5e-6
+    V = cpu(eng.sarl_export('V'))
+    assert np.abs(V - g['net_out']).max() <= 2e-5
+    values = cpu(out['values'])
+    assert np.abs(values - g['values']).max() <= 2e-5
+    best = cpu(out['best'])
+    top2 = np.sort(g['values'], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 4e-5
+    assert clear.sum() >= n // 2
+    assert np.array_equal(best[clear], g['best'][clear])
+    chosen = cpu(out['action'])
+    assert np.array_equal(chosen[clear], g['action'][clear])
+    # wherever the arg-max differs it is a numerical tie: the value picked is within tolerance of the maximum
+    assert np.all(g['values'][np.arange(n), best] >= g['values'].max(axis=1) - 4e-5)
+
+
+@pytest.mark.gpu
+def test_sarl_mlp_vs_torch_fp32_random_inputs():
+    """The MFMA value network alone against the torch fp32 module on random states (bigger, non-fixture batch)."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(3)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    B = 37  # not a multiple of 16 groups
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.reset(1000 + np.arange(B))
+    eng.step(np.zeros((B, 2)), update=True)  # humans get non-zero velocities
+    space, _, _ = build_action_space(1.0)
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+    eng.sarl_set_weights(net.state_dict())
+    out = eng.sarl_select()
+    X = eng.sarl_export('X').cpu()
+    V = eng.sarl_export('V').cpu().numpy()
+    with torch.no_grad():
+        want = net(X.reshape(B * 81, 5, 13)).reshape(B, 81).numpy()
+    assert np.abs(V - want).max() <= 2e-5
+    assert np.all(out['best'].cpu().numpy() >= 0)
