@@ -221,6 +221,15 @@ class CrowdSim(_Base):
         v = self._eng.orca().cpu().numpy()[0, 0]
         return float(v[0]), float(v[1])
 
+    def sarl_action(self, policy):
+        """Greedy SARL decision for the current device state: (best index | -1 stop | -2 invalid, 81 values)."""
+        eng = self._eng
+        if getattr(eng, 'sarl', None) is None:
+            eng.sarl_configure(**policy.engine_kwargs())
+        eng.sarl_set_weights(policy.model.state_dict())  # the Trainer may have stepped since the last call
+        out = eng.sarl_select()
+        return int(out['best'].cpu()[0]), out['values'].cpu().numpy()[0].tolist()
+
     def render(self, mode='human', output_file=None):
         raise NotImplementedError('rendering is outside the accelerated path; use the reference CrowdSim')
 

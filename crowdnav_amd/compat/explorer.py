@@ -13,6 +13,8 @@ import torch
 from .. import _lib
 from ..engine import BatchedCrowdSim
 from .policy import is_device_orca
+from .sarl import SARL
+from ..sarl_rollout import SarlRollout
 from .types import Collision, Danger, ReachGoal, Timeout
 
 
@@ -40,7 +42,8 @@ class Explorer(object):
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
                        print_failure=False):
         self.robot.policy.set_phase(phase)
-        batched = (is_device_orca(self.robot.policy) and not update_memory and hasattr(self.env, 'engine_config')
+        on_device = is_device_orca(self.robot.policy) or (isinstance(self.robot.policy, SARL) and phase != 'train')
+        batched = (on_device and not update_memory and hasattr(self.env, 'engine_config')
                    and self.env.case_counter[phase] >= 0
                    and self.env.case_counter[phase] + k <= self.env.case_size[phase])  # no wrap of the case table
         if batched:
@@ -97,18 +100,31 @@ class Explorer(object):
         start = env.case_counter[phase]
         size = env.case_size[phase]
         B = int(min(k, self.max_envs))
-        eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
-        eng.set_gamma(self.gamma)
         per_env = (k + B - 1) // B
-        # episode i of this call is case start + i of the phase (no wrap: checked by the caller)
-        bufs = eng.rollout_begin(seed_base=offset + start, seed_mod=size, episode_limit=k, record_capacity=per_env)
         max_steps = int(round(env.time_limit / env.time_step)) + 2
-        while True:
-            eng.rollout(max_steps)
-            if int(bufs['active'].sum().item()) == 0:
-                break
-        rec = {n: bufs[n].cpu().numpy() for n in ('ep_outcome', 'ep_steps', 'ep_return', 'ep_time', 'ep_danger',
-                                                  'ep_danger_dmin_sum', 'ep_count')}
+        names = ('ep_outcome', 'ep_steps', 'ep_return', 'ep_time', 'ep_danger', 'ep_danger_dmin_sum')
+        # episode i of this call is case start + i of the phase (no wrap: checked by the caller)
+        if is_device_orca(self.robot.policy):
+            eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
+            eng.set_gamma(self.gamma)
+            bufs = eng.rollout_begin(seed_base=offset + start, seed_mod=size, episode_limit=k, record_capacity=per_env)
+            while True:
+                eng.rollout(max_steps)
+                if int(bufs['active'].sum().item()) == 0:
+                    break
+            rec = {n: bufs[n].cpu().numpy() for n in names}
+        else:  # SARL value network: select + step + masked reset per batched step
+            policy = self.robot.policy
+            if policy.action_space is None:
+                policy.build_action_space(self.robot.v_pref)
+            eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_EXTERNAL))
+            eng.sarl_configure(**policy.engine_kwargs())
+            eng.sarl_set_weights(policy.model.state_dict())
+            ro = SarlRollout(eng, self.gamma, seed_base=offset + start, seed_mod=size, episode_limit=k,
+                             record_capacity=per_env)
+            while ro.any_active():
+                ro.run(8)
+            rec = {n: ro.rec[m].cpu().numpy() for n, m in zip(names, ('outcome', 'steps', 'ret', 'time', 'danger', 'dsum'))}
         env.case_counter[phase] = (start + k) % size
         # episode id c = b + j*B  ->  record [b, j]
         order = [(c % B, c // B) for c in range(k)]

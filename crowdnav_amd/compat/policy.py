@@ -66,3 +66,9 @@ def is_device_orca(policy):
 
 
 policy_factory = {'orca': ORCA, 'none': lambda: None}
+
+
+def _register_trainable():
+    from .sarl import SARL  # late import: sarl.py imports this module
+    policy_factory['sarl'] = SARL
+

@@ -153,20 +153,104 @@ class SARL(Policy):
         env = self.env
         if env is None or not hasattr(env, 'sarl_action'):
             raise RuntimeError('crowdnav_amd SARL needs policy.set_env(<crowdnav_amd CrowdSim>)')
+        if self.reach_destination(state):
+            return ActionXY(0, 0)
         probability = np.random.random()  # drawn in every phase (multi_human_rl.py:28)
         if self.phase == 'train' and probability < self.epsilon:
-            if self.reach_destination(state):
-                return ActionXY(0, 0)
-            return self.action_space[np.random.choice(len(self.action_space))]
-        best, values = env.sarl_action(self)
-        if best == -1:
-            return ActionXY(0, 0)
-        if best < 0:
-            raise ValueError('Value network is not well trained. ')
-        self.action_values = values
-        return self.action_space[best]
+            action = self.action_space[np.random.choice(len(self.action_space))]
+        else:
+            best, values = env.sarl_action(self)
+            if best < 0:
+                raise ValueError('Value network is not well trained. ')
+            self.action_values = values
+            action = self.action_space[best]
+        if self.phase == 'train':
+            self.last_state = self.transform(state)
+        return action
 
     @staticmethod
     def reach_destination(state):
         s = state.self_state
         return np.linalg.norm((s.py - s.gy, s.px - s.gx)) < s.radius
+
+
+def default_policy_config(overrides=None):
+    """The shipped crowd_nav/configs/policy.config sections SARL reads, as a RawConfigParser."""
+    import configparser
+    cfg = configparser.RawConfigParser()
+    cfg.read_dict({
+        'rl': dict(gamma=0.9),
+        'om': dict(cell_num=4, cell_size=1, om_channel_size=3),
+        'action_space': dict(kinematics='holonomic', speed_samples=5, rotation_samples=16, sampling='exponential',
+                             query_env='true'),
+        'sarl': dict(mlp1_dims='150, 100', mlp2_dims='100, 50', attention_dims='100, 100, 1',
+                     mlp3_dims='150, 100, 100, 1', multiagent_training='true', with_om='false',
+                     with_global_state='true'),
+    })
+    for (sec, key), val in (overrides or {}).items():
+        cfg.set(sec, key, str(val))
+    return cfg
+
+
+def rotate(state):
+    """Agent-centric 13-vector rows from 14-float joint rows (CADRL.rotate, cadrl.py:187-222), holonomic."""
+    dx, dy = state[:, 5] - state[:, 0], state[:, 6] - state[:, 1]
+    rot = torch.atan2(dy, dx)
+    c, s = torch.cos(rot), torch.sin(rot)
+    dg = torch.norm(torch.stack([dx, dy], dim=1), 2, dim=1)
+    ex, ey = state[:, 9] - state[:, 0], state[:, 10] - state[:, 1]
+    cols = [dg, state[:, 7], torch.zeros_like(dg), state[:, 4],
+            state[:, 2] * c + state[:, 3] * s, state[:, 3] * c - state[:, 2] * s,
+            ex * c + ey * s, ey * c - ex * s,
+            state[:, 11] * c + state[:, 12] * s, state[:, 12] * c - state[:, 11] * s,
+            state[:, 13], torch.norm(torch.stack([-ex, -ey], dim=1), 2, dim=1), state[:, 4] + state[:, 13]]
+    return torch.stack(cols, dim=1)
+
+
+def occupancy_maps(human_states, cell_num, cell_size, channels):
+    """(H, cell_num^2 * channels) float32 maps (MultiHumanRL.build_occupancy_maps, multi_human_rl.py:109-163)."""
+    hs = np.array([[h.px, h.py, h.vx, h.vy] for h in human_states], dtype=np.float64)
+    cells = cell_num ** 2
+    out = np.zeros((len(hs), cells * channels), dtype=np.float64)
+    for i, me in enumerate(hs):
+        others = np.delete(hs, i, axis=0)
+        ox, oy = others[:, 0] - me[0], others[:, 1] - me[1]
+        mine = np.arctan2(me[3], me[2])
+        rot = np.arctan2(oy, ox) - mine
+        dist = np.linalg.norm([ox, oy], axis=0)
+        xi = np.floor(np.cos(rot) * dist / cell_size + cell_num / 2)
+        yi = np.floor(np.sin(rot) * dist / cell_size + cell_num / 2)
+        inside = (xi >= 0) & (xi < cell_num) & (yi >= 0) & (yi < cell_num)
+        vrot = np.arctan2(others[:, 3], others[:, 2]) - mine
+        speed = np.linalg.norm(others[:, 2:4], axis=1)
+        ovx, ovy = np.cos(vrot) * speed, np.sin(vrot) * speed
+        sums = [[[] for _ in range(3)] for _ in range(cells)]
+        for j in np.nonzero(inside)[0]:
+            cell = int(cell_num * yi[j] + xi[j])
+            sums[cell][0].append(1)
+            sums[cell][1].append(ovx[j])
+            sums[cell][2].append(ovy[j])
+        for cell in range(cells):
+            if not sums[cell][0]:
+                continue
+            mean = [sum(v) / len(v) for v in sums[cell]]
+            if channels == 1:
+                out[i, cell] = 1
+            elif channels == 2:
+                out[i, 2 * cell:2 * cell + 2] = mean[1:]
+            else:
+                out[i, 3 * cell:3 * cell + 3] = mean
+    return torch.from_numpy(out).float()
+
+
+def _transform(self, state):
+    """Replay-memory view of a joint state (MultiHumanRL.transform, multi_human_rl.py:90-104)."""
+    rows = torch.cat([torch.Tensor([state.self_state + h]).to(self.device) for h in state.human_states], dim=0)
+    x = rotate(rows)
+    if self.with_om:
+        om = occupancy_maps(state.human_states, self.cell_num, self.cell_size, self.om_channel_size)
+        x = torch.cat([x, om.to(self.device)], dim=1)
+    return x
+
+
+SARL.transform = _transform

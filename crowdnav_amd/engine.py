@@ -111,6 +111,10 @@ class BatchedCrowdSim(object):
         self.sync()
         return draws
 
+    def reset_async(self, seeds_i32, mask_u8):
+        """cn_reset with device-resident seeds (int32 bit patterns of the uint32 seeds) and mask; no sync."""
+        check(self._lib.cn_reset(self._h, _ptr(seeds_i32), _ptr(mask_u8), None))
+
     # ---------------------------------------------------------------- one transition
     def orca(self):
         out = self._new((self.B, self.A, 2), torch.float32)
@@ -129,8 +133,8 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_step(self._h, _ptr(a), int(bool(update)), _ptr(out['reward']), _ptr(out['done']),
                                 _ptr(out['info']), _ptr(out['dmin']), _ptr(out['action']),
                                 _ptr(out['orca_vel']), _ptr(out['obs'])))
-        if a is not None:
-            self.sync()  # `a` may be a temporary
+        if a is not None and not (torch.is_tensor(action) and a.data_ptr() == action.data_ptr()):
+            self.sync()  # `a` is a temporary copy
         return out
 
     # ---------------------------------------------------------------- fused rollouts

@@ -100,3 +100,82 @@ def test_sarl_mlp_vs_torch_fp32_random_inputs():
         want = net(X.reshape(B * 81, 5, 13)).reshape(B, 81).numpy()
     assert np.abs(V - want).max() <= 2e-5
     assert np.all(out['best'].cpu().numpy() >= 0)
+
+
+def _joint_rows(g, d, a):
+    """float32 joint rows [propagate(self, action a) | next human h] of decision d, as MultiHumanRL.predict builds them."""
+    s, act = g['states'][d], g['action_space'][a]
+    me = [s[0, 0] + act[0] * 0.25, s[0, 1] + act[1] * 0.25, act[0], act[1], s[0, 6], s[0, 4], s[0, 5], s[0, 7], np.pi / 2]
+    return torch.cat([torch.Tensor([tuple(me) + tuple(h)]) for h in g['next_obs'][d].tolist()], dim=0)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_host_rotate_and_occupancy_maps_match_reference_cpu(name):
+    """The host-side feature builders used by SARL.transform (replay memory) vs the reference's own outputs."""
+    from crowdnav_amd.compat.sarl import occupancy_maps, rotate
+    from crowdnav_amd.compat.types import ObservableState
+    g = load_golden(name)
+    for d in (0, 5, 17):
+        for a in (0, 1, 40, 80):
+            assert np.abs(rotate(_joint_rows(g, d, a)).numpy() - g['inputs'][d, a, :, :13]).max() <= 1e-6
+        if int(g['with_om']):
+            hs = [ObservableState(*row) for row in g['next_obs'][d].tolist()]
+            assert np.abs(occupancy_maps(hs, 4, 1.0, 3).numpy() - g['inputs'][d, 0, :, 13:]).max() <= 1e-6
+
+
+def _sarl_setup(g):
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config
+    with_om, visible = bool(int(g['with_om'])), bool(int(g['robot_visible']))
+    cfg = c.default_env_config({('robot', 'visible'): 'true' if visible else 'false'})
+    env = c.CrowdSim()
+    env.configure(cfg)
+    robot = c.Robot(cfg, 'robot')
+    policy = c.policy_factory['sarl']()
+    policy.configure(default_policy_config({('sarl', 'with_om'): 'true' if with_om else 'false'}))
+    policy.get_model().load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items()
+                                        if k.startswith('param_')})
+    robot.set_policy(policy)
+    env.set_robot(robot)
+    policy.set_phase('test')
+    policy.set_device(torch.device('cpu'))
+    policy.set_env(env)
+    return c, env, robot, policy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', FIXTURES)
+def test_gym_surface_with_sarl_policy_follows_reference_episode(name):
+    """env.reset / robot.act (SARL.predict on device) / env.step exactly as the reference loop, first fixture episode."""
+    g = load_golden(name)
+    c, env, robot, policy = _sarl_setup(g)
+    case = 3 if int(g['with_om']) else 0
+    ob = env.reset('test', case)
+    env._eng.set_state(g['states'][:1], np.zeros(1))  # the reference's exact initial state
+    env._pull()
+    ob = [h.get_observable_state() for h in env.humans]
+    for d in range(8):
+        assert np.array_equal(np.array([[h.px, h.py, h.vx, h.vy] for h in env.humans]), g['states'][d][1:, :4])
+        action = robot.act(ob)
+        assert (action.vx, action.vy) == tuple(g['action'][d])
+        assert np.abs(np.array(policy.action_values) - g['values'][d]).max() <= 1e-6
+        ob, reward, done, info = env.step(action)
+        assert reward == g['rewards'][d][g['best'][d]]
+        if done:
+            break
+
+
+@pytest.mark.gpu
+def test_explorer_batched_sarl_equals_sequential():
+    g = load_golden('sarl_plain.npz')
+    c, env, robot, policy = _sarl_setup(g)
+    ex = c.Explorer(env, robot, 'cpu', gamma=0.9)
+    ex.run_k_episodes(6, 'val')  # batched: select + step + masked reset on 6 envs
+    batched, outcome, steps = dict(ex.last_stats), list(ex.last_batch['outcome']), list(ex.last_batch['steps'])
+    env.case_counter['val'] = 0
+    stats = ex._run_sequential(6, 'val', False, False)
+    ex._report(6, 'val', None, False, *stats)
+    for key in ('success_rate', 'collision_rate', 'too_close', 'collision_cases', 'timeout_cases'):
+        assert ex.last_stats[key] == batched[key], key
+    assert abs(ex.last_stats['total_reward'] - batched['total_reward']) < 1e-6
+    assert len(outcome) == 6 and all(o in (2, 3, 4) for o in outcome) and min(steps) >= 1
