@@ -17,8 +17,13 @@
 //
 // Row order inside an MLP tile is HUMAN-MAJOR: row = h * 16 + g (g = group within the tile).  A 16-row MFMA
 // tile then holds human h of 16 different groups, so the per-group reductions of the network (mean over
-// humans, masked softmax over humans, weighted feature sum) combine values that sit at the same lane / same
-// accumulator register of different row tiles — no cross-lane traffic.
+// humans, masked softmax over humans, weighted feature sum) combine values at the same offset of different row
+// tiles — no cross-lane traffic.
+//
+// Activations live in LDS in MFMA A-FRAGMENT ORDER: element (row tile rt, row r, feature n) of a buffer with
+// `ks` k-steps per row tile sits at ((rt * ks + n / 4) * 64 + (n % 4) * 16 + r).  A wave then fetches the A operand
+// of k-step s with lane l reading word (rt * ks + s) * 64 + l (conflict-free ds_read_b32), and the 4 accumulator
+// values a lane owns (rows quad*4 .. quad*4+3 of one column) are 4 consecutive words: one ds_write_b128.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,18 +34,20 @@ namespace cn {
 constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
 constexpr int kSarlMaxHumans = 8;    // LDS budget of the fused MLP kernel (H = 5 in every BASELINE config)
 constexpr int kSarlThreads = 256;    // 4 waves per MLP workgroup
+constexpr int kSarlKChunk = 4;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time)
 constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One packed linear layer: B-operand fragments of v_mfma_f32_16x16x4_f32, fragment (ct, ks) at
-// w[(ct * ksteps + ks) * 64 + lane] = W[n = ct*16 + (lane & 15)][k = ks*4 + (lane >> 4)] (0 outside), so a wave
+// w[(ct * kpad + ks) * 64 + lane] = W[n = ct*16 + (lane & 15)][k = ks*4 + (lane >> 4)] (0 outside), so a wave
 // fetches a fragment with one coalesced 256-byte load; bias padded to ctiles * 16.
 struct PackedLinear {
     const float* w;
     const float* bias;
     int K, N;       // true sizes
     int ksteps;     // ceil(K / 4)
+    int kpad;       // ksteps rounded up to kSarlKChunk (zero fragments): the B prefetch never runs off the end
     int ctiles;     // ceil(N / 16)
 };
 
@@ -54,8 +61,9 @@ struct SarlNet {
     int in_dim;        // 13 or 13 + cell_num^2 * om_channel_size
     int with_global;   // sarl.py:17-21
     int H;
-    // LDS leading dimensions (floats); every ld is == 4 (mod 8) to spread the accumulator stores over banks
-    int ld_x, ld_a, ld_b, ld_c;
+    // k-steps per row tile of the LDS buffers (fragment order): X input, wide hidden (A), mlp1 output (B),
+    // per-human feature (C), scores (S)
+    int ks_x, ks_a, ks_b, ks_c, ks_s;
 };
 
 struct SarlCfg {
@@ -68,13 +76,13 @@ struct SarlCfg {
 
 // torch.nn.Linear weight [N][K] (row-major) -> MFMA B fragments
 __global__ void sarl_pack_kernel(const float* W, const float* bias, int N, int K, int k_offset, int k_count,
-                                 int ksteps, int ctiles, float* wp, float* bp) {
+                                 int kpad, int ctiles, float* wp, float* bp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = ctiles * ksteps * 64;
+    const int total = ctiles * kpad * 64;
     if (idx < total) {
         const int lane = idx & 63;
         const int frag = idx >> 6;
-        const int ct = frag / ksteps, ks = frag - ct * ksteps;
+        const int ct = frag / kpad, ks = frag - ct * kpad;
         const int n = ct * 16 + (lane & 15);
         const int k = ks * 4 + (lane >> 4);
         wp[idx] = (n < N && k < k_count) ? W[(size_t)n * K + k_offset + k] : 0.0f;
@@ -196,16 +204,24 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
 
 // ------------------------------------------------------------------------------------ features
 // X row of (env b, action a, human h): CADRL.rotate of the float32 joint row
-// [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written in MLP tile order:
-// group G = b * K + a -> tile G / 16, g = G % 16, row = h * 16 + g, X[(tile * 16 * H + row) * ld_x + feature].
-__global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ld_x, const double2* pos, const double2* goal,
+// [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written straight in the MLP
+// kernel's LDS order: group G = b * K + a -> tile G / 16, g = G % 16, row tile = h;
+// X[((tile * H + h) * ks_x + n / 4) * 64 + (n % 4) * 16 + g] = feature n.  Lanes run over g fastest, so every
+// store instruction writes 16 consecutive words per (tile, h).
+__global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
                                     const double2* rv, const double* actions, const double* next_obs,
-                                    const float* om, float* X) {
+                                    const float* om, float* X, size_t n_tiles) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t rows = (size_t)C.B * C.n_actions * C.H;
-    if (idx >= rows) return;
-    const int h = (int)(idx % C.H);
-    const size_t G = idx / C.H;
+    if (idx >= n_tiles * C.H * kSarlGroups) return;
+    const int g = (int)(idx % kSarlGroups);
+    const int h = (int)((idx / kSarlGroups) % C.H);
+    const size_t tile = idx / ((size_t)kSarlGroups * C.H);
+    const size_t G = tile * kSarlGroups + g;
+    float* x = X + ((tile * C.H + h) * ks_x) * 64 + g;
+    if (G >= (size_t)C.B * C.n_actions) {  // padding groups of the last tile: finite zeros
+        for (int n = 0; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+        return;
+    }
     const int a = (int)(G % C.n_actions);
     const int b = (int)(G / C.n_actions);
     const size_t g0 = (size_t)b * (C.H + 1);
@@ -237,149 +253,164 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ld_x, const doubl
     const float ex = px - px1, ey = py - py1;
     f[11] = sqrtf(ex * ex + ey * ey);
     f[12] = radius + radius1;
-    const size_t tile = G / kSarlGroups;
-    const int g = (int)(G % kSarlGroups);
-    float* x = X + ((tile * kSarlGroups * C.H) + (size_t)h * kSarlGroups + g) * ld_x;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) x[k] = f[k];
+    for (int k = 0; k < 13; ++k) x[(k >> 2) * 64 + (k & 3) * 16] = f[k];
     const int extra = in_dim - 13;
     const float* m = om + ((size_t)b * C.H + h) * (extra > 0 ? extra : 0);
-    for (int k = 0; k < extra; ++k) x[13 + k] = m[k];
-    for (int k = in_dim; k < ld_x; ++k) x[k] = 0.0f;
+    for (int k = 0; k < extra; ++k) x[((13 + k) >> 2) * 64 + ((13 + k) & 3) * 16] = m[k];
+    for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------ value network
-// Dense layer on MFMA: out[r][n] = act(bias[n] + extra[g][n] + sum_k in[r][k] W[n][k]) for r in [0, RT*16).
-// A wave owns whole column tiles (ct = wave, wave + 4, ...) and all RT row tiles of them: per k-step it reads
-// RT A fragments from LDS and ONE B fragment from L2 and issues RT independent MFMAs.
+// Dense layer on MFMA: out[r][n] = act(bias[n] + extra[g][n] + sum_k in[r][k] W[n][k]) for r in [0, RT*16), buffers in
+// fragment order (ks_in / ks_out k-steps per row tile).  A wave owns whole column tiles (ct = wave, wave + 4, ..)
+// and all RT row tiles of them: per k-step it reads RT A fragments from LDS (conflict-free) and issues RT
+// independent MFMAs; the B fragments of the NEXT 8 k-steps are already in flight from L2 (register double buffer).
 template <int RT>
-__device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* in, int ld_in, float* out, int ld_out,
-                                           bool relu, const float* extra, int ld_extra, int wave, int lane) {
+__device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* in, int ks_in, float* out, int ks_out,
+                                           bool relu, const float* extra, int wave, int lane) {
     const int col = lane & 15, quad = lane >> 4;
     for (int ct = wave; ct < P.ctiles; ct += kSarlThreads / 64) {
+        // this lane's 4 accumulator rows of column n = ct*16 + col sit at 4 consecutive words of the out buffer
+        const int frag_off = ((ct * 4 + (col >> 2)) * 64) + (col & 3) * 16 + quad * 4;
         f32x4 acc[RT];
         const float b0 = P.bias[ct * 16 + col];
+        f32x4 init = {b0, b0, b0, b0};
+        if (extra) {
+            const f32x4 e = *reinterpret_cast<const f32x4*>(extra + frag_off);
+            init += e;
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = init;
+
+        // Straight-line k loop, 4 k-steps per trip, no conditionals (kpad <= ks_in by construction: every buffer
+        // holds whole column tiles of its producer, zero beyond the true width, and the packed weights are zero
+        // there too).  The B fragments of the next trip are requested before this trip's MFMAs issue; the
+        // packed buffer carries one spare chunk so the last request stays in bounds.
+        const float* wfrag = P.w + (size_t)ct * P.kpad * 64 + lane;
+        const float* afrag = in + lane;
+        float bcur[kSarlKChunk], bnxt[kSarlKChunk];
+#pragma unroll
+        for (int j = 0; j < kSarlKChunk; ++j) bcur[j] = wfrag[j * 64];
+        for (int k0 = 0; k0 < P.kpad; k0 += kSarlKChunk) {
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j) bnxt[j] = wfrag[(k0 + kSarlKChunk + j) * 64];
+            __builtin_amdgcn_sched_barrier(0);  // keep the next trip's L2 requests ahead of this trip's MFMAs
+            float a[kSarlKChunk][RT];
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[j][rt] = afrag[(rt * ks_in + k0 + j) * 64];
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][rt], bcur[j], acc[rt], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j) bcur[j] = bnxt[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // columns >= N of the last column tile are exact zeros (zero weights, zero bias): they are the consumer's
+        // k padding, so they are stored too
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            // accumulator element i of this lane is row quad*4 + i of the tile = group quad*4 + i
+            f32x4 v = acc[rt];
+            if (relu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[rt][i] = b0 + (extra ? extra[(quad * 4 + i) * ld_extra + ct * 16 + col] : 0.0f);
-        }
-        const float* wfrag = P.w + (size_t)ct * P.ksteps * 64 + lane;
-        const float* arow = in + col * ld_in + quad;  // A[l & 15][k = l >> 4]
-        for (int ks = 0; ks < P.ksteps; ++ks) {
-            const float bfrag = wfrag[(size_t)ks * 64];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float afrag = arow[(rt * 16) * ld_in + ks * 4];
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag, bfrag, acc[rt], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
             }
-        }
-        const int n = ct * 16 + col;
-        if (n < P.N) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = acc[rt][i];
-                    if (relu) v = v > 0.0f ? v : 0.0f;
-                    out[(rt * 16 + quad * 4 + i) * ld_out + n] = v;
-                }
-            }
+            *reinterpret_cast<f32x4*>(out + rt * ks_out * 64 + frag_off) = v;
         }
     }
 }
 
-__host__ __device__ inline int sarl_ld(int n) {  // smallest ld >= n with ld % 8 == 4
-    int ld = (n + 3) / 4 * 4;
-    while (ld % 8 != 4) ld += 4;
-    return ld;
-}
-
-// Whole sarl.ValueNetwork.forward for one tile of 16 groups x H humans; X in tile order, V[group] out.
+// Whole sarl.ValueNetwork.forward for one tile of 16 groups x H humans; X in fragment order, V[group] out.
 template <int H>
 __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
     extern __shared__ float lds[];
-    constexpr int R = H * kSarlGroups;  // rows of the tile
-    float* bufA = lds;                       // [R][ld_a]  widest hidden layer
-    float* bufB = bufA + R * net.ld_a;       // [R][ld_b]  mlp1 output (h2) / X staging before that
-    float* bufC = bufB + R * net.ld_b;       // [R][ld_c]  mlp2 output (per-human feature)
-    float* gbuf = bufC + R * net.ld_c;       // [16][ld_b] mean over humans of h2, later its attention term
-    float* jbuf = gbuf + kSarlGroups * net.ld_b;  // [16][ld_a] joint state / mlp3 ping
-    float* kbuf = jbuf + kSarlGroups * net.ld_a;  // [16][ld_a] mlp3 pong
-    float* sbuf = kbuf + kSarlGroups * net.ld_a;  // [R] attention scores -> weights
+    float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
+    float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2
+    float* bufC = bufB + H * net.ks_b * 64;       // [H][ks_c][64]  mlp2 output (per-human feature)
+    float* gbuf = bufC + H * net.ks_c * 64;       // [ks_b][64]     mean over humans of h2
+    float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]     joint state / mlp3 ping
+    float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term / mlp3 pong
+    float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights, final value
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t tile = blockIdx.x;
 
-    // stage X (coalesced) into bufB's space with leading dimension ld_x
+    // stage X: a straight coalesced copy (the feature kernel wrote fragment order); X is staged with ks_x k-steps
     float* xs = bufB;
-    const float* xg = X + tile * R * net.ld_x;
-    for (int i = tid; i < R * net.ld_x; i += kSarlThreads) xs[i] = xg[i];
+    const float* xg = X + tile * H * net.ks_x * 64;
+    for (int i = tid; i < H * net.ks_x * 64; i += kSarlThreads) xs[i] = xg[i];
+    // k padding of the joint-state buffer (features 6 + nf .. ks*4) must be finite zeros
+    for (int i = tid; i < net.ks_a * 64; i += kSarlThreads) jbuf[i] = 0.0f;
     __syncthreads();
     // self_state = state[:, 0, :6] (sarl.py:36): features 0..5 of human 0's row of each group
-    if (tid < kSarlGroups * 6) jbuf[(tid / 6) * net.ld_a + (tid % 6)] = xs[(tid / 6) * net.ld_x + (tid % 6)];
+    if (tid < kSarlGroups * 6) {
+        const int g = tid & 15, n = tid >> 4;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];
+    }
 
-    dense_mfma<H>(net.L[kL_mlp1_0], xs, net.ld_x, bufA, net.ld_a, true, nullptr, 0, wave, lane);
+    dense_mfma<H>(net.L[kL_mlp1_0], xs, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<H>(net.L[kL_mlp1_2], bufA, net.ld_a, bufB, net.ld_b, true, nullptr, 0, wave, lane);  // h2
+    dense_mfma<H>(net.L[kL_mlp1_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);  // h2
     __syncthreads();
-    // global state: mean over the humans of a group (sarl.py:42), sum in human order then / H
-    const int n1 = net.L[kL_mlp1_2].N;
+    // global state: mean over the humans of a group (sarl.py:42) — elementwise over fragment offsets
     if (net.with_global) {
-        for (int i = tid; i < kSarlGroups * n1; i += kSarlThreads) {
-            const int g = i / n1, c = i - g * n1;
+        for (int i = tid; i < net.ks_b * 64; i += kSarlThreads) {
             float sum = 0.0f;
 #pragma unroll
-            for (int h = 0; h < H; ++h) sum += bufB[(h * kSarlGroups + g) * net.ld_b + c];
-            gbuf[g * net.ld_b + c] = sum / (float)H;
+            for (int h = 0; h < H; ++h) sum += bufB[h * net.ks_b * 64 + i];
+            gbuf[i] = sum / (float)H;
         }
     }
-    dense_mfma<H>(net.L[kL_mlp2_0], bufB, net.ld_b, bufA, net.ld_a, true, nullptr, 0, wave, lane);
+    dense_mfma<H>(net.L[kL_mlp2_0], bufB, net.ks_b, bufA, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<H>(net.L[kL_mlp2_2], bufA, net.ld_a, bufC, net.ld_c, false, nullptr, 0, wave, lane);  // features
+    dense_mfma<H>(net.L[kL_mlp2_2], bufA, net.ks_a, bufC, net.ks_c, false, nullptr, wave, lane);  // features
     // attention layer 0 on [h2 | global]: the global half is the same for every human of a group, so it is
     // one 16-row product (kbuf) added to every row tile's accumulator at the matching group row
-    if (net.with_global)
-        dense_mfma<1>(net.L[kL_att0_global], gbuf, net.ld_b, kbuf, net.ld_a, false, nullptr, 0, wave, lane);
+    if (net.with_global) dense_mfma<1>(net.L[kL_att0_global], gbuf, net.ks_b, kbuf, net.ks_a, false, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<H>(net.L[kL_att0_local], bufB, net.ld_b, bufA, net.ld_a, true, net.with_global ? kbuf : nullptr,
-                  net.ld_a, wave, lane);
+    dense_mfma<H>(net.L[kL_att0_local], bufB, net.ks_b, bufA, net.ks_a, true, net.with_global ? kbuf : nullptr, wave,
+                  lane);
     __syncthreads();
-    dense_mfma<H>(net.L[kL_att_2], bufA, net.ld_a, bufB, net.ld_b, true, nullptr, 0, wave, lane);
+    dense_mfma<H>(net.L[kL_att_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<H>(net.L[kL_att_4], bufB, net.ld_b, sbuf, 1, false, nullptr, 0, wave, lane);  // scores [R]
+    dense_mfma<H>(net.L[kL_att_4], bufB, net.ks_b, sbuf, net.ks_s, false, nullptr, wave, lane);  // score (h, g) at h*ks_s*64 + g
     __syncthreads();
-    // masked softmax without max subtraction (sarl.py:52-53) + weighted feature sum (sarl.py:60)
+    // masked softmax without max subtraction (sarl.py:52-53)
     if (tid < kSarlGroups) {
         float e[H], total = 0.0f;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const float sc = sbuf[h * kSarlGroups + tid];
+            const float sc = sbuf[h * net.ks_s * 64 + tid];
             e[h] = expf(sc) * (sc != 0.0f ? 1.0f : 0.0f);
             total += e[h];
         }
 #pragma unroll
-        for (int h = 0; h < H; ++h) sbuf[h * kSarlGroups + tid] = e[h] / total;
+        for (int h = 0; h < H; ++h) sbuf[h * net.ks_s * 64 + tid] = e[h] / total;
     }
     __syncthreads();
+    // weighted feature sum (sarl.py:60) -> joint state features 6 ..
     const int nf = net.L[kL_mlp2_2].N;
     for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
-        const int g = i / nf, c = i - g * nf;
+        const int g = i & 15, c = i >> 4;
+        const int src = (c >> 2) * 64 + (c & 3) * 16 + g;
         float sum = 0.0f;
 #pragma unroll
-        for (int h = 0; h < H; ++h) sum += sbuf[h * kSarlGroups + g] * bufC[(h * kSarlGroups + g) * net.ld_c + c];
-        jbuf[g * net.ld_a + 6 + c] = sum;
+        for (int h = 0; h < H; ++h) sum += sbuf[h * net.ks_s * 64 + g] * bufC[h * net.ks_c * 64 + src];
+        const int n = 6 + c;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = sum;
     }
     __syncthreads();
-    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ld_a, kbuf, net.ld_a, true, nullptr, 0, wave, lane);
+    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ld_a, jbuf, net.ld_a, true, nullptr, 0, wave, lane);
+    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ld_a, kbuf, net.ld_a, true, nullptr, 0, wave, lane);
+    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<1>(net.L[kL_mlp3_6], kbuf, net.ld_a, sbuf, 1, false, nullptr, 0, wave, lane);
+    dense_mfma<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
     __syncthreads();
     if (tid < kSarlGroups) {
         const size_t G = tile * kSarlGroups + tid;
@@ -388,8 +419,8 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
 }
 
 __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
-    const size_t R = (size_t)net.H * kSarlGroups;
-    return sizeof(float) * (R * (net.ld_a + net.ld_b + net.ld_c) + kSarlGroups * (net.ld_b + 2 * net.ld_a) + R + 64);
+    const size_t H = (size_t)net.H;
+    return sizeof(float) * 64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a);
 }
 
 // ------------------------------------------------------------------------------------ action selection

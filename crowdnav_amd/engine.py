@@ -226,17 +226,14 @@ def _sarl_export(self, name):
     elif name == 'om':
         t, which = self._new((self.B, H, self.sarl['in_dim'] - 13), torch.float32), 3
     elif name == 'X':
-        ld = (self.sarl['in_dim'] + 3) // 4 * 4
-        while ld % 8 != 4:
-            ld += 4
-        groups = self.B * K
-        tiles = (groups + 15) // 16
-        t, which = self._new((tiles, H, 16, ld), torch.float32), 4
+        ks = (self.sarl['in_dim'] + 15) // 16 * 4
+        tiles = (self.B * K + 15) // 16
+        t, which = self._new((tiles, H, ks, 4, 16), torch.float32), 4  # MFMA A-fragment order
     else:
         raise KeyError(name)
     check(self._lib.cn_sarl_export(self._h, which, _ptr(t), t.numel() * t.element_size()))
-    if name == 'X':  # tile order [tile][h][g][ld] -> [B, K, H, in_dim]
-        t = t.permute(0, 2, 1, 3).reshape(-1, H, t.shape[-1])[:self.B * K, :, :self.sarl['in_dim']]
+    if name == 'X':  # [tile][h][k-step][k % 4][g] -> [B, K, H, in_dim]
+        t = t.permute(0, 4, 1, 2, 3).reshape(-1, H, t.shape[2] * 4)[:self.B * K, :, :self.sarl['in_dim']]
         t = t.reshape(self.B, K, H, -1)
     return t
 
