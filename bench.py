@@ -31,6 +31,70 @@ def algorithmic_bytes_per_env_step(H):
     return 72 * (H + 1) + 26
 
 
+def pmc_traffic_bytes(envs, humans, steps_per_launch):
+    """HBM bytes per rollout launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md §HBM).  None when no profile matches this configuration."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch')) != (envs, humans, steps_per_launch):
+        return None
+    return (2 * rec['fetch_size_kb'] + rec['write_size_kb']) * 1024
+
+
+def bench_sarl(args, world, rank, local_rank):
+    """BASELINE configs[2]: 4096 envs x 5 humans, SARL value-network rollout (random-init weights), greedy phase.
+    A step = cn_sarl_select (81 lookaheads + value network per env) + cn_step + masked seeded reset."""
+    import numpy as np
+    import torch
+    import crowdnav_amd
+    from crowdnav_amd import distributed as cd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    from crowdnav_amd.sarl_rollout import SarlRollout
+    B, H = args.envs, args.humans
+    om = args.workload == 'om-sarl'
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                       robot_visible=1, device=local_rank)
+    torch.manual_seed(0)
+    net = ValueNetwork(13 + (48 if om else 0), 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    space, _, _ = build_action_space(1.0)
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=om)
+    eng.sarl_set_weights(net.state_dict())
+    off, stride = cd.shard(rank, world, B)
+    ro = SarlRollout(eng, 0.9, seed_base=2000, seed_mod=2 ** 32 - 2000, env_offset=off, env_stride=stride)
+    steps, warm = min(args.steps, 200), min(args.warmup, 20)
+    ro.run(warm)
+    torch.cuda.synchronize()
+    before = int(ro.transitions.item())
+    sel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ro.step()
+        e1.record()
+        sel_ms.append((e0, e1))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    transitions = int(ro.transitions.item()) - before
+    flop = 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B  # SURVEY.md §8(d)
+    step_s = sum(a.elapsed_time(b) for a, b in sel_ms) / 1e3 / steps
+    out = {
+        'metric': 'env-steps/sec, 4096 envs x 5 humans, %s value-net rollout (BASELINE configs[2])' % args.workload,
+        'value': transitions * world / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warm,
+        'ms_per_step': elapsed * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (FP32 MFMA value network, f64 lookahead rewards)', 'data': 'synthetic',
+        'config': {'workload': '%d envs x %d humans, 81 actions, %s, random-init weights' % (B, H, args.workload)},
+        'roofline': {'bound': 'mfma', 'achieved': flop / step_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                     'frac': flop / step_s / 1e12 / 157.3, 'traffic': None,
+                     'note': 'flops of the value network / whole batched step (select + step + reset + bookkeeping)'},
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def cpu_baseline(envs, humans, target_seconds=12.0):
     """The CPU oracle (oracle/crowd_oracle.cpp: same workload, same auto-reset rollout) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -64,12 +128,14 @@ def cpu_baseline(envs, humans, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4000)
-    ap.add_argument('--warmup', type=int, default=400)
+    ap.add_argument('--steps', type=int, default=8000)
+    ap.add_argument('--warmup', type=int, default=1000)
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--humans', type=int, default=5)
-    ap.add_argument('--chunk', type=int, default=200, help='steps fused into one kernel launch')
+    ap.add_argument('--chunk', type=int, default=1000, help='steps fused into one kernel launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
+                    help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
     args = ap.parse_args()
 
     import torch
@@ -90,6 +156,8 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     B, H = args.envs, args.humans
+    if args.workload != 'orca':
+        return bench_sarl(args, world, rank, local_rank)
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
                                        robot_visible=1, device=local_rank)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
@@ -138,7 +206,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     transitions = int(bufs['transitions'].item()) - before
-    assert transitions == B * args.steps, (transitions, B * args.steps)
+    # an env whose 48-deep scenario ring ran dry inside one launch pauses until the next launch; count what ran
+    paused_env_steps = B * args.steps - transitions
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,9 +229,10 @@ def main():
                    'envs_per_gpu': B, 'humans': H, 'steps_per_launch': args.chunk,
                    'parallelism': 'env-axis shards x%d, all-gather of episode summaries at the end' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(B, H, args.chunk),
                      'kernel': 'cn::rollout_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
+        'paused_env_steps': paused_env_steps,
         'episodes_finished': int(summary[0].item()),
         'mean_recorded_return': float(summary[1].item() / max(summary[2].item(), 1.0)),
     }

@@ -92,9 +92,9 @@ inline int grid_envs(const cn_engine* e) { return (e->P.B + e->P.E - 1) / e->P.E
 #define CN_LAUNCH_MAXL(e, kernel, grid, ...)                                                              \
     do {                                                                                                  \
         if ((e)->maxl == 5)                                                                               \
-            hipLaunchKernelGGL(cn::kernel<5>, dim3(grid), dim3(cn::kWave), (e)->smem, (e)->stream, __VA_ARGS__);  \
+            hipLaunchKernelGGL(cn::kernel<5>, dim3(grid), dim3((e)->P.threads), (e)->smem, (e)->stream, __VA_ARGS__);  \
         else                                                                                              \
-            hipLaunchKernelGGL(cn::kernel<10>, dim3(grid), dim3(cn::kWave), (e)->smem, (e)->stream, __VA_ARGS__); \
+            hipLaunchKernelGGL(cn::kernel<10>, dim3(grid), dim3((e)->P.threads), (e)->smem, (e)->stream, __VA_ARGS__); \
     } while (0)
 
 int env_int(const char* name, int fallback) {
@@ -140,14 +140,20 @@ int cn_create(const cn_config* c, cn_engine** out) {
     P.B = c->num_envs;
     P.A = c->num_humans + 1;
     P.NC = P.A - 1;
-    // envs per wave: the path is latency-bound, so spread the envs over ~2048+ waves (2 per SIMD) before
-    // packing more of them into one wave (CROWDNAV_AMD_ENVS_PER_WAVE overrides, for tuning)
+    // Workgroup geometry.  E envs per workgroup (agents = lanes of wave 0), W waves sharing the per-pair phases.
+    // Defaults from the MI355X sweep in DESIGN.md; CROWDNAV_AMD_ENVS_PER_WAVE / CROWDNAV_AMD_WAVES_PER_BLOCK
+    // override them for tuning.
     const int e_max = cn::kWave / P.A;
     int e_want = env_int("CROWDNAV_AMD_ENVS_PER_WAVE", (P.B + 2047) / 2048);
     P.E = e_want < 1 ? 1 : (e_want > e_max ? e_max : e_want);
+    int w_want = env_int("CROWDNAV_AMD_WAVES_PER_BLOCK", 1);
+    const int w_useful = (P.E * P.A * P.NC + cn::kWave - 1) / cn::kWave;  // more waves than pair passes is waste
+    if (w_want > w_useful) w_want = w_useful;
+    if (w_want > cn::kMaxBlock / cn::kWave) w_want = cn::kMaxBlock / cn::kWave;
+    P.threads = cn::kWave * (w_want < 1 ? 1 : w_want);
     P.nA = P.E * P.A;
     P.pairs = P.nA * P.NC;
-    P.ring_depth = env_int("CROWDNAV_AMD_RING_DEPTH", 16);
+    P.ring_depth = env_int("CROWDNAV_AMD_RING_DEPTH", 48);
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     e->smem = cn::smem_bytes(P.nA, P.pairs);

@@ -1,7 +1,9 @@
 // Device side of libcrowdnav_amd.so: the batched CrowdSim transition as a wave-level pipeline.
 //
-// One workgroup = one wave64 = E whole envs (E * A <= 64 agents).  A transition runs in phases that each
-// use the lanes differently (all separated by workgroup barriers, all data exchanged through LDS):
+// One workgroup = E whole envs (E * A <= 64 agents) on 1..8 waves.  A transition runs in phases that each use
+// the lanes differently (all separated by workgroup barriers, all data exchanged through LDS).  The per-agent
+// phases run on wave 0 only; the per-pair phases are spread over every wave of the workgroup, and the waves that
+// have nothing to do in a phase sleep at the barrier without taking issue slots from other workgroups:
 //   stage      lane = agent            float32 view of the agents as rvo2 is told them (orca.py:100-110)
 //   pairs-1    lane = (agent, cand.)   squared distance of every ordered pair            (Appendix A.2)
 //   pairs-2    lane = (agent, cand.)   stable rank among the agent's candidates -> neighbour slot; the
@@ -10,8 +12,8 @@
 //   collide    lane = human            float64 swept robot-human distance (crowd_sim.py:331-351)
 //   reduce     lane = robot            reward / done / info (crowd_sim.py:364-389)
 //   integrate  lane = agent            Agent.step (agent.py:127-135)
-// The chip is latency-bound on this path (4096 envs x 6 agents = 24.6 k agents on 1024 SIMDs), so E is kept
-// small (2 envs per wave at 4096 envs): more waves, fewer serial passes, less divergence per wave.
+// The chip is issue/latency-bound on this path (4096 envs x 6 agents = 24.6 k agents on 1024 SIMDs): E and the
+// workgroup size are tuning knobs chosen on the host (crowdnav_amd.hip: pick_geometry).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits>
@@ -22,9 +24,12 @@
 
 namespace cn {
 
+constexpr int kMaxBlock = 512;  // threads per workgroup of the transition kernels (1..8 waves)
+
 struct Params {
     int B, A;          // envs, agents per env
-    int E;             // envs per wave
+    int E;             // envs per workgroup (their E * A agents are lanes of wave 0)
+    int threads;       // workgroup size: wave 0 runs the per-agent phases, every wave the per-pair phases
     int nA;            // E * A agent lanes
     int NC;            // A - 1 candidate neighbours per agent
     int pairs;         // nA * NC
@@ -142,7 +147,7 @@ __device__ __forceinline__ void load_agent(const StateView& S, size_t gi, AgentR
 // (crowd_sim.py:325-327, orca.py:102-104); the robot's own sim holds every human.
 //   bits 0-7 agent lane, 8-15 lane of the candidate, 16-23 candidate slot, 24 pair exists, 25 agent is a robot
 __device__ __forceinline__ void build_pairs(const Params& P, const Smem& s) {
-    for (int p = threadIdx.x; p < P.pairs; p += kWave) {
+    for (int p = threadIdx.x; p < P.pairs; p += blockDim.x) {
         const int q = p / P.NC;
         const int c = p - q * P.NC;
         const int el = q / P.A;
@@ -202,7 +207,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     __syncthreads();
 
     // pairs-1: squared distances, self.pos - other.pos (Appendix A.2)
-    for (int p = L.lane; p < P.pairs; p += kWave) {
+    for (int p = L.lane; p < P.pairs; p += blockDim.x) {
         const int info = s.pinfo[p];
         const float4 me = s.kin[info & 0xff];
         const float4 ot = s.kin[(info >> 8) & 0xff];
@@ -214,7 +219,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     // pairs-2: neighbour slot = stable rank by (distSq, visit order) among the in-range candidates, which
     // is what RVO2's sorted insertion with strict '<' produces; slots >= maxNeighbors fall off the list.
     const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
-    for (int p = L.lane; p < P.pairs; p += kWave) {
+    for (int p = L.lane; p < P.pairs; p += blockDim.x) {
         const int info = s.pinfo[p];
         const int q = info & 0xff, c = (info >> 16) & 0xff;
         const float mine = s.d2[p];
@@ -352,7 +357,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
 // ---------------------------------------------------------------------------------------------- kernels
 
 template <int MAXL>
-__global__ __launch_bounds__(kWave) void orca_kernel(Params P, StateView S, float* out_vel) {
+__global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, float* out_vel) {
     const Smem s = carve(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(kWave) void orca_kernel(Params P, StateView S, floa
 }
 
 template <int MAXL>
-__global__ __launch_bounds__(kWave) void step_kernel(Params P, StateView S, StepIo io) {
+__global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, StepIo io) {
     const Smem s = carve(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
@@ -539,7 +544,7 @@ __device__ __forceinline__ int finish_episode(const RolloutView R, int env, int 
 // Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs
 // take their next scenario from the ring.
 template <int MAXL>
-__global__ __launch_bounds__(kWave) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps) {
+__global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps) {
     const Smem s = carve(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
