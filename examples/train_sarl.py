@@ -1,0 +1,93 @@
+"""BASELINE configs[4]: the reference's `train.py --policy sarl` schedule (crowd_nav/train.py:96-173) on the
+MI355X engine: imitation learning from ORCA demonstrations, then epsilon-greedy RL with a target network; rollouts
+and the SARL decision run in libcrowdnav_amd, replay memory and the SGD trainer are plain PyTorch-ROCm.
+
+    python examples/train_sarl.py --il-episodes 3000 --train-episodes 10000        # the shipped train.config
+    python examples/train_sarl.py --il-episodes 20 --il-epochs 2 --train-episodes 5 --val-size 5 --test-size 5
+"""
+import argparse
+import copy
+import logging
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import crowdnav_amd.compat as cn  # noqa: E402
+from crowdnav_amd.compat.sarl import default_policy_config  # noqa: E402
+from crowdnav_amd.compat.trainer import ReplayMemory, Trainer  # noqa: E402
+
+
+def run(args):
+    device = torch.device('cuda:0' if args.gpu and torch.cuda.is_available() else 'cpu')
+    env_cfg = cn.default_env_config({('env', 'val_size'): args.val_size, ('env', 'test_size'): args.test_size})
+    policy = cn.policy_factory['sarl']()
+    policy.configure(default_policy_config({('sarl', 'with_om'): 'true' if args.with_om else 'false'}))
+    policy.set_device(device)
+    env = cn.CrowdSim()
+    env.configure(env_cfg)
+    robot = cn.Robot(env_cfg, 'robot')
+    env.set_robot(robot)
+
+    memory = ReplayMemory(args.capacity)
+    model = policy.get_model()
+    trainer = Trainer(model, memory, device, args.batch_size)
+    explorer = cn.Explorer(env, robot, device, memory, policy.gamma, target_policy=policy)
+
+    # imitation learning from ORCA demonstrations (train.py:115-132)
+    trainer.set_learning_rate(args.il_learning_rate)
+    il_policy = cn.policy_factory['orca']()
+    il_policy.multiagent_training = policy.multiagent_training
+    il_policy.safety_space = 0 if robot.visible else args.safety_space
+    robot.set_policy(il_policy)
+    env.set_robot(robot)
+    explorer.run_k_episodes(args.il_episodes, 'train', update_memory=True, imitation_learning=True)
+    il_loss = trainer.optimize_epoch(args.il_epochs)
+    logging.info('Finish imitation learning. Experience set size: %d/%d', len(memory), memory.capacity)
+    explorer.update_target_model(model)
+
+    # reinforcement learning (train.py:134-170)
+    policy.set_env(env)
+    robot.set_policy(policy)
+    env.set_robot(robot)
+    trainer.set_learning_rate(args.rl_learning_rate)
+    episode, rl_loss = 0, None
+    while episode < args.train_episodes:
+        if episode < args.epsilon_decay:
+            epsilon = args.epsilon_start + (args.epsilon_end - args.epsilon_start) / args.epsilon_decay * episode
+        else:
+            epsilon = args.epsilon_end
+        robot.policy.set_epsilon(epsilon)
+        if episode % args.evaluation_interval == 0:
+            explorer.run_k_episodes(env.case_size['val'], 'val', episode=episode)
+        explorer.run_k_episodes(args.sample_episodes, 'train', update_memory=True, episode=episode)
+        rl_loss = trainer.optimize_batch(args.train_batches)
+        episode += 1
+        if episode % args.target_update_interval == 0:
+            explorer.update_target_model(model)
+        if args.output_dir and episode % args.checkpoint_interval == 0:
+            torch.save(model.state_dict(), os.path.join(args.output_dir, 'rl_model.pth'))
+    explorer.run_k_episodes(env.case_size['test'], 'test', episode=episode)
+    return dict(il_loss=il_loss, rl_loss=rl_loss, memory=len(memory), stats=copy.deepcopy(explorer.last_stats))
+
+
+def parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpu', action='store_true', help='keep the torch model / trainer on cuda:0 (rollouts always are)')
+    ap.add_argument('--with-om', action='store_true')
+    ap.add_argument('--output-dir', default=None)
+    for name, default in (('il-episodes', 3000), ('il-epochs', 50), ('train-episodes', 10000), ('train-batches', 100),
+                          ('sample-episodes', 1), ('target-update-interval', 50), ('evaluation-interval', 1000),
+                          ('checkpoint-interval', 1000), ('capacity', 100000), ('batch-size', 100),
+                          ('epsilon-decay', 4000), ('val-size', 100), ('test-size', 500)):
+        ap.add_argument('--' + name, type=int, default=default)
+    for name, default in (('il-learning-rate', 0.01), ('rl-learning-rate', 0.001), ('safety-space', 0.15),
+                          ('epsilon-start', 0.5), ('epsilon-end', 0.1)):
+        ap.add_argument('--' + name, type=float, default=default)
+    return ap
+
+
+if __name__ == '__main__':
+    logging.basicConfig(level=logging.INFO, format='%(asctime)s, %(levelname)s: %(message)s', datefmt='%Y-%m-%d %H:%M:%S')
+    print(run(parser().parse_args()))

@@ -179,3 +179,41 @@ def test_explorer_batched_sarl_equals_sequential():
         assert ex.last_stats[key] == batched[key], key
     assert abs(ex.last_stats['total_reward'] - batched['total_reward']) < 1e-6
     assert len(outcome) == 6 and all(o in (2, 3, 4) for o in outcome) and min(steps) >= 1
+
+
+def test_replay_memory_and_trainer_cpu():
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    from crowdnav_amd.compat.trainer import ReplayMemory, Trainer
+    torch.manual_seed(0)
+    mem = ReplayMemory(8)
+    for i in range(11):  # wraps: capacity 8
+        mem.push((torch.randn(5, 13), torch.tensor([0.1 * i])))
+    assert len(mem) == 8 and mem.is_full() and mem.position == 3 and float(mem[0][1]) == pytest.approx(0.8)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    tr = Trainer(net, mem, torch.device('cpu'), batch_size=4)
+    with pytest.raises(ValueError):
+        tr.optimize_batch(1)
+    tr.set_learning_rate(0.01)
+    first = tr.optimize_epoch(1)
+    later = tr.optimize_epoch(20)
+    assert later < first and tr.optimize_batch(3) >= 0.0
+
+
+@pytest.mark.gpu
+def test_train_schedule_smoke_config5():
+    """The reference's train.py schedule end to end on tiny sizes: IL from device ORCA demonstrations, RL with
+    epsilon-greedy device SARL decisions, torch trainer, batched val/test evaluation."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('train_sarl', os.path.join(ROOT, 'examples', 'train_sarl.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = mod.parser().parse_args(['--il-episodes', '6', '--il-epochs', '3', '--train-episodes', '3', '--train-batches',
+                                    '4', '--evaluation-interval', '2', '--val-size', '4', '--test-size', '4',
+                                    '--target-update-interval', '2', '--batch-size', '16'])
+    out = mod.run(args)
+    assert out['memory'] > 50 and out['il_loss'] is not None and out['rl_loss'] is not None
+    assert np.isfinite(out['il_loss']) and np.isfinite(out['rl_loss'])
+    s = out['stats']
+    assert 0.0 <= s['success_rate'] <= 1.0 and abs(s['success_rate'] + s['collision_rate'] - 1.0) <= 1.0
