@@ -64,6 +64,7 @@ struct cn_engine {
     int discount_len;
     uint32_t* probe_key;
     int maxl;          // half-planes held in VGPRs by the solve phase: 5 or 10
+    bool mt_in_lds;    // scenario generators keep their MT19937 state in LDS (long rejection chains) or HBM
     size_t smem;       // dynamic LDS bytes per workgroup
     std::vector<void*> allocs;
 };
@@ -157,6 +158,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     e->smem = cn::smem_bytes(P.nA, P.pairs);
+    e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", c->num_humans > 8 ? 1 : 0) != 0;
     P.robot_visible = c->robot_visible ? 1 : 0;
     P.robot_orca = c->robot_policy == CN_ROBOT_ORCA;
     P.dt = c->time_step;
@@ -192,7 +194,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.mt_pos, (size_t)P.B)) || (rc = dev_alloc(e, &e->probe_key, (size_t)624)) ||
         (rc = dev_alloc(e, &S.ring_pos, n * P.ring_depth)) || (rc = dev_alloc(e, &S.ring_goal, n * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_rv, n * P.ring_depth)) ||
-        (rc = dev_alloc(e, &S.ring_mt_key, (size_t)624 * P.B * P.ring_depth)) ||
+        (rc = dev_alloc(e, &S.ring_mt_key, e->mt_in_lds ? (size_t)64 : (size_t)624 * P.B * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1))) {
         cn_destroy(e);
@@ -290,8 +292,12 @@ int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t*
     int rc = bind(e);
     if (rc) return rc;
     if (!seeds) return fail(CN_ERR_INVALID, "cn_reset: seeds is NULL");
-    hipLaunchKernelGGL(cn::reset_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, seeds, mask,
-                       draws);
+    if (e->mt_in_lds)
+        hipLaunchKernelGGL(cn::reset_kernel<true>, dim3(grid_lanes(e)), dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P,
+                           e->C, e->S, seeds, mask, draws);
+    else
+        hipLaunchKernelGGL(cn::reset_kernel<false>, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S,
+                           seeds, mask, draws);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -362,7 +368,12 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     if (rc) return rc;
     if ((rc = check_io(e, io)) || (rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
-    hipLaunchKernelGGL(cn::rollout_begin_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+    if (e->mt_in_lds)
+        hipLaunchKernelGGL(cn::rollout_begin_kernel<true>, dim3(grid_lanes(e)), dim3(cn::kWave), cn::kMtLdsBytes, e->stream,
+                           e->P, e->C, e->S, R);
+    else
+        hipLaunchKernelGGL(cn::rollout_begin_kernel<false>, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C,
+                           e->S, R);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -377,8 +388,12 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     // top the scenario ring up to ring_depth episodes ahead of every env, then run the fused transitions
     const int fill_lanes = e->P.B * e->P.ring_depth;
-    hipLaunchKernelGGL(cn::ring_fill_kernel, dim3((fill_lanes + cn::kWave - 1) / cn::kWave), dim3(cn::kWave), 0,
-                       e->stream, e->P, e->C, e->S, R);
+    const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
+    if (e->mt_in_lds)
+        hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
+                           e->S, R);
+    else
+        hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
     CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps);
     CN_HIP(hipGetLastError());
