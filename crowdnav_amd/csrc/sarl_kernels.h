@@ -33,7 +33,7 @@ namespace cn {
 
 constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
 constexpr int kSarlMaxHumans = 8;    // LDS budget of the fused MLP kernel (H = 5 in every BASELINE config)
-constexpr int kSarlThreads = 256;    // 4 waves per MLP workgroup
+constexpr int kSarlThreads = 1024;   // 8 waves per MLP workgroup (2 per SIMD: one wave's LDS/L2 waits hide behind the other's MFMAs)
 constexpr int kSarlKChunk = 4;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time)
 constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
 
