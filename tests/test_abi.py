@@ -42,6 +42,7 @@ def test_struct_layouts_match_header(built):
     assert built.CnConfig.time_step.offset == 8 and built.CnConfig.neighbor_dist.offset == 80
     assert built.CnConfig.device.offset == C.sizeof(built.CnConfig) - 4
     assert C.sizeof(built.CnRolloutIo) == 8 + 8 + 8 + 8 + 8 + 13 * 8
+    assert C.sizeof(built.CnSarlConfig) == 16 + 16 + 4 + 8 + 8 + 12 + 16 + 4 + 4  # 88: ints, 2 doubles, dims, pad
 
 
 def test_no_cpu_fallback(built):
@@ -63,3 +64,32 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'crowd_oracle' not in text and 'rvo2_oracle' not in text, os.path.join(dirpath, f)
                 assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f
+
+
+def test_create_rejects_bad_configs_before_touching_the_device(built):
+    """Error convention (include/crowdnav_amd.h): negative cn_status + cn_last_error(), nothing thrown across the
+    ABI.  Config validation happens before the device is probed, so it is testable without a GPU."""
+    lib = built.load()
+    from crowdnav_amd.engine import default_config
+
+    def create(**kw):
+        cfg = built.CnConfig(**default_config(**kw))
+        h = C.c_void_p()
+        rc = lib.cn_create(C.byref(cfg), C.byref(h))
+        return rc, lib.cn_last_error().decode()
+
+    rc, msg = create(num_envs=0)
+    assert rc == built.CN_ERR_INVALID and 'num_envs' in msg
+    rc, msg = create(num_humans=64)
+    assert rc == built.CN_ERR_UNSUPPORTED and 'num_humans' in msg
+    rc, msg = create(max_neighbors=11)
+    assert rc == built.CN_ERR_UNSUPPORTED and 'max_neighbors' in msg
+    rc, msg = create(time_step=0.0)
+    assert rc == built.CN_ERR_INVALID and 'time_step' in msg
+    rc, msg = create(scenario_rule=2)
+    assert rc == built.CN_ERR_UNSUPPORTED and 'scenario_rule' in msg
+    rc, msg = create(robot_policy=7)
+    assert rc == built.CN_ERR_INVALID
+    assert lib.cn_create(None, None) == built.CN_ERR_INVALID
+    assert lib.cn_destroy(None) == built.CN_OK  # destroying NULL is a no-op
+    assert lib.cn_sync(None) == built.CN_ERR_INVALID and 'NULL' in lib.cn_last_error().decode()
