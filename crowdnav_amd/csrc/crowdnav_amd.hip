@@ -64,7 +64,8 @@ struct cn_engine {
     int discount_len;
     uint32_t* probe_key;
     int maxl;          // half-planes held in VGPRs by the solve phase: 5 or 10
-    bool mt_in_lds;    // scenario generators keep their MT19937 state in LDS (long rejection chains) or HBM
+    bool mt_in_lds;    // lane-per-scenario generators keep their MT19937 state in LDS instead of HBM
+    bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
     size_t smem;       // dynamic LDS bytes per workgroup
     std::vector<void*> allocs;
 };
@@ -158,7 +159,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     e->smem = cn::smem_bytes(P.nA, P.pairs);
-    e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", c->num_humans > 8 ? 1 : 0) != 0;
+    e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", 0) != 0;
+    e->gen_wave = env_int("CROWDNAV_AMD_WAVE_SCENARIOS", c->num_humans > 8 ? 1 : 0) != 0;
     P.robot_visible = c->robot_visible ? 1 : 0;
     P.robot_orca = c->robot_policy == CN_ROBOT_ORCA;
     P.dt = c->time_step;
@@ -183,6 +185,12 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->C.human_v_pref = c->human_v_pref;
     e->C.robot_radius = c->robot_radius;
     e->C.robot_v_pref = c->robot_v_pref;
+    // give-up threshold of the rejection sampling: ~seconds of GPU time in either generator family
+    int cap_log2 = env_int("CROWDNAV_AMD_MAX_ATTEMPTS_LOG2", c->num_humans > 8 ? 26 : 20);
+    if (cap_log2 < 6) cap_log2 = 6;
+    if (cap_log2 > 40) cap_log2 = 40;
+    e->C.max_attempts = 1ull << cap_log2;
+    e->C.error = nullptr;
 
     const size_t n = (size_t)P.B * P.A;
     int rc = CN_OK;
@@ -194,9 +202,9 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.mt_pos, (size_t)P.B)) || (rc = dev_alloc(e, &e->probe_key, (size_t)624)) ||
         (rc = dev_alloc(e, &S.ring_pos, n * P.ring_depth)) || (rc = dev_alloc(e, &S.ring_goal, n * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_rv, n * P.ring_depth)) ||
-        (rc = dev_alloc(e, &S.ring_mt_key, e->mt_in_lds ? (size_t)64 : (size_t)624 * P.B * P.ring_depth)) ||
+        (rc = dev_alloc(e, &S.ring_mt_key, (e->mt_in_lds || e->gen_wave) ? (size_t)64 : (size_t)624 * P.B * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
-        (rc = dev_alloc(e, &e->io_dev, (size_t)1))) {
+        (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1))) {
         cn_destroy(e);
         return rc;
     }
@@ -234,6 +242,16 @@ int cn_sync(cn_engine* e) {
     int rc = bind(e);
     if (rc) return rc;
     CN_HIP(hipStreamSynchronize(e->stream));
+    int gen_error = 0;
+    CN_HIP(hipMemcpy(&gen_error, e->C.error, sizeof(int), hipMemcpyDeviceToHost));
+    if (gen_error) {
+        CN_HIP(hipMemset(e->C.error, 0, sizeof(int)));
+        return fail(CN_ERR_INVALID,
+                    "scenario generation gave up on a human after %llu rejected placements (the reference's rejection "
+                    "sampling would not have terminated either: too many humans for this circle/square); the affected "
+                    "scenario holds an overlapping placement",
+                    e->C.max_attempts);
+    }
     return CN_OK;
 }
 
@@ -292,7 +310,10 @@ int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t*
     int rc = bind(e);
     if (rc) return rc;
     if (!seeds) return fail(CN_ERR_INVALID, "cn_reset: seeds is NULL");
-    if (e->mt_in_lds)
+    if (e->gen_wave)
+        hipLaunchKernelGGL(cn::reset_wave_kernel, dim3(e->P.B), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, seeds, mask,
+                           draws);
+    else if (e->mt_in_lds)
         hipLaunchKernelGGL(cn::reset_kernel<true>, dim3(grid_lanes(e)), dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P,
                            e->C, e->S, seeds, mask, draws);
     else
@@ -368,7 +389,9 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     if (rc) return rc;
     if ((rc = check_io(e, io)) || (rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
-    if (e->mt_in_lds)
+    if (e->gen_wave)
+        hipLaunchKernelGGL(cn::rollout_begin_wave_kernel, dim3(e->P.B), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+    else if (e->mt_in_lds)
         hipLaunchKernelGGL(cn::rollout_begin_kernel<true>, dim3(grid_lanes(e)), dim3(cn::kWave), cn::kMtLdsBytes, e->stream,
                            e->P, e->C, e->S, R);
     else
@@ -389,7 +412,9 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     // top the scenario ring up to ring_depth episodes ahead of every env, then run the fused transitions
     const int fill_lanes = e->P.B * e->P.ring_depth;
     const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
-    if (e->mt_in_lds)
+    if (e->gen_wave)
+        hipLaunchKernelGGL(cn::ring_fill_wave_kernel, dim3(fill_lanes), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+    else if (e->mt_in_lds)
         hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
                            e->S, R);
     else

@@ -58,6 +58,10 @@ struct ScenarioCfg {
     int randomize;
     double circle_radius, square_width, discomfort_dist;
     double human_radius, human_v_pref, robot_radius, robot_v_pref;
+    // Rejection sampling has no termination guarantee in the reference either (a crowded circle can be unsatisfiable);
+    // after this many attempts for one human the last candidate is taken and *error is set (cn_sync reports it).
+    unsigned long long max_attempts;
+    int* error;
 };
 
 // Writes agents [0, A) of one env into the SoA state (double2 planes indexed base + agent; vel may be NULL:
@@ -81,6 +85,7 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
             draws += 2;
         }
         double x, y, tx, ty;
+        unsigned long long attempts = 0;
         if (c.rule == 0) {
             for (;;) {
                 const double angle = rng.random() * kPi * 2;
@@ -99,6 +104,10 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
                     }
                 }
                 if (!collide) break;
+                if (++attempts >= c.max_attempts) {
+                    *c.error = 1;
+                    break;
+                }
             }
             tx = -x;
             ty = -y;
@@ -119,6 +128,10 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
                     }
                 }
                 if (!collide) break;
+                if (++attempts >= c.max_attempts) {
+                    *c.error = 1;
+                    break;
+                }
             }
             for (;;) {
                 tx = rng.random() * w * 0.5 * -sign;
@@ -133,6 +146,10 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
                     }
                 }
                 if (!collide) break;
+                if (++attempts >= c.max_attempts) {
+                    *c.error = 1;
+                    break;
+                }
             }
         }
         pos[base + i] = make_double2(x, y);

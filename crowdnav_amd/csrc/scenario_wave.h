@@ -1,0 +1,222 @@
+// Wave-cooperative seeded scenario generation: ONE wave64 builds ONE scenario.
+//
+// Same stream, same arithmetic and same accept/reject decisions as scenario_device.h (and therefore as
+// crowd_sim.py:155-207 on numpy's MT19937), but the reference's rejection sampling is evaluated 64 attempts at a
+// time: the tempered generator output is kept in an LDS window, every lane tests the attempt that starts at its own
+// stream offset, and the first accepted attempt (in stream order) wins — the words of the later attempts are simply
+// read again by the next human.  This is what tames the heavy tail of the reference's own defaults at H = 20
+// (circle radius 4: 28 k draws per scenario on average, 1.8 M worst case): a lane-serial
+// generator would hold its whole wave for the worst lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scenario_device.h"
+
+namespace cn {
+
+struct WaveRng {
+    uint32_t* key;   // [624] generator state (LDS)
+    uint32_t* out;   // [kWindow] tempered outputs, ring indexed by stream position % kWindow (LDS)
+    uint32_t produced;  // stream words generated so far (wave-uniform)
+    uint32_t cursor;    // next unread stream word (wave-uniform)
+    static constexpr uint32_t kWindow = 1248;
+
+    __device__ void seed(uint32_t s, int lane) {
+        if (lane == 0) {
+            for (int i = 0; i < 624; ++i) {
+                key[i] = s;
+                s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+            }
+        }
+        produced = 0;
+        cursor = 0;
+        __syncthreads();
+    }
+
+    __device__ static uint32_t twist(uint32_t a, uint32_t b) {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    __device__ static uint32_t temper(uint32_t v) {
+        v ^= (v >> 11);
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= (v >> 18);
+        return v;
+    }
+
+    // Regenerate the 624-word block in place, in the three dependency-free ranges of the recurrence
+    // new[i] = new_or_old[i + 397 mod 624] ^ twist(old[i], old[i + 1]), and append its tempered words to the window.
+    __device__ void next_block(int lane) {
+        for (int ph = 0; ph < 3; ++ph) {
+            const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454);
+            const int hi = ph == 0 ? 227 : (ph == 1 ? 454 : 623);
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lo + lane + 64 * k;
+                if (i < hi) {
+                    const int im = (i + 397 >= 624) ? i + 397 - 624 : i + 397;
+                    v[k] = key[im] ^ twist(key[i], key[i + 1]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lo + lane + 64 * k;
+                if (i < hi) key[i] = v[k];
+            }
+            __syncthreads();
+        }
+        if (lane == 0) key[623] = key[396] ^ twist(key[623], key[0]);
+        __syncthreads();
+        for (int i = lane; i < 624; i += 64) out[(produced + i) % kWindow] = temper(key[i]);
+        produced += 624;
+        __syncthreads();
+    }
+
+    // make stream words [cursor, cursor + n) readable (n <= 384)
+    __device__ void ensure(uint32_t n, int lane) {
+        while (produced < cursor + n) next_block(lane);
+    }
+    __device__ uint32_t word(uint32_t stream_index) const { return out[stream_index % kWindow]; }
+    // np.random.random() from the two words at stream_index
+    __device__ double random_at(uint32_t stream_index) const {
+        const uint32_t a = word(stream_index) >> 5, b = word(stream_index + 1) >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+};
+
+// Shared scratch of one generator wave
+struct WaveScratch {
+    uint32_t key[624];
+    uint32_t out[WaveRng::kWindow];
+    double2 ppos[64];
+    double2 pgoal[64];
+    double prad[64];
+};
+
+// Builds agents [0, A) at pos/vel/goal/rv[base + agent] (vel may be NULL); returns np.random.random() calls consumed.
+// Must be called by all 64 lanes of a one-wave workgroup.
+__device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScratch& s, uint32_t seed, size_t base,
+                                                  double2* pos, double2* vel, double2* goal, double2* rv) {
+    const double kPi = 3.141592653589793;
+    const int lane = threadIdx.x & 63;
+    WaveRng rng{s.key, s.out, 0, 0};
+    rng.seed(seed, lane);
+    const int A = c.num_agents;
+    const double R = c.circle_radius;
+    if (lane == 0) {
+        s.ppos[0] = make_double2(0.0, -R);
+        s.pgoal[0] = make_double2(0.0, R);
+        s.prad[0] = c.robot_radius;
+        pos[base] = s.ppos[0];
+        goal[base] = s.pgoal[0];
+        if (vel) vel[base] = make_double2(0.0, 0.0);
+        rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
+    }
+    __syncthreads();
+    for (int i = 1; i < A; ++i) {
+        double radius = c.human_radius, v_pref = c.human_v_pref;
+        if (c.randomize) {
+            rng.ensure(4, lane);
+            v_pref = 0.5 + (1.5 - 0.5) * rng.random_at(rng.cursor);
+            radius = 0.3 + (0.5 - 0.3) * rng.random_at(rng.cursor + 2);
+            rng.cursor += 4;
+        }
+        unsigned long long attempts = 0;
+        if (c.rule == 0) {
+            // circle crossing: attempt = (angle, px_noise, py_noise) = 6 words; reject if within min_dist of any placed
+            // agent's position or goal (crowd_sim.py:159-175)
+            for (;;) {
+                rng.ensure(6 * 64, lane);
+                const uint32_t at = rng.cursor + 6u * lane;
+                const double angle = rng.random_at(at) * kPi * 2;
+                const double nx = (rng.random_at(at + 2) - 0.5) * v_pref;
+                const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
+                const double x = R * cos(angle) + nx;
+                const double y = R * sin(angle) + ny;
+                bool collide = false;
+                for (int k = 0; k < i; ++k) {
+                    const double2 p = s.ppos[k], g = s.pgoal[k];
+                    const double min_dist = radius + s.prad[k] + c.discomfort_dist;
+                    if (norm2(x - p.x, y - p.y) < min_dist || norm2(x - g.x, y - g.y) < min_dist) {
+                        collide = true;
+                        break;
+                    }
+                }
+                unsigned long long ok = __ballot(!collide);
+                attempts += 64;
+                if (!ok && attempts >= c.max_attempts) {  // give up like nobody would: take the first candidate, flag it
+                    ok = 1;
+                    if (lane == 0) *c.error = 1;
+                }
+                if (ok) {
+                    const int first = __ffsll((long long)ok) - 1;
+                    if (lane == first) {
+                        s.ppos[i] = make_double2(x, y);
+                        s.pgoal[i] = make_double2(-x, -y);
+                    }
+                    rng.cursor += 6u * (first + 1);
+                    break;
+                }
+                rng.cursor += 6u * 64;
+            }
+        } else {
+            // square crossing (crowd_sim.py:181-205): sign, then start attempts (4 words), then goal attempts (4 words)
+            rng.ensure(2, lane);
+            const double sign = (rng.random_at(rng.cursor) > 0.5) ? -1.0 : 1.0;
+            rng.cursor += 2;
+            const double w = c.square_width;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (;;) {
+                    rng.ensure(4 * 64, lane);
+                    const uint32_t at = rng.cursor + 4u * lane;
+                    const double x = rng.random_at(at) * w * 0.5 * (pass == 0 ? sign : -sign);
+                    const double y = (rng.random_at(at + 2) - 0.5) * w;
+                    bool collide = false;
+                    for (int k = 0; k < i; ++k) {
+                        const double2 q = pass == 0 ? s.ppos[k] : s.pgoal[k];
+                        if (norm2(x - q.x, y - q.y) < radius + s.prad[k] + c.discomfort_dist) {
+                            collide = true;
+                            break;
+                        }
+                    }
+                    unsigned long long ok = __ballot(!collide);
+                    attempts += 64;
+                    if (!ok && attempts >= c.max_attempts) {
+                        ok = 1;
+                        if (lane == 0) *c.error = 1;
+                    }
+                    if (ok) {
+                        const int first = __ffsll((long long)ok) - 1;
+                        if (lane == first) {
+                            if (pass == 0) {
+                                s.ppos[i] = make_double2(x, y);
+                            } else {
+                                s.pgoal[i] = make_double2(x, y);
+                            }
+                        }
+                        rng.cursor += 4u * (first + 1);
+                        break;
+                    }
+                    rng.cursor += 4u * 64;
+                }
+                __syncthreads();
+            }
+        }
+        if (lane == 0) s.prad[i] = radius;
+        __syncthreads();
+        if (lane == 0) {
+            pos[base + i] = s.ppos[i];
+            goal[base + i] = s.pgoal[i];
+            if (vel) vel[base + i] = make_double2(0.0, 0.0);
+            rv[base + i] = make_double2(radius, v_pref);
+        }
+    }
+    __syncthreads();
+    return (uint64_t)(rng.cursor / 2);
+}
+
+}  // namespace cn

@@ -21,6 +21,7 @@
 #include "../../include/crowdnav_amd.h"
 #include "orca_device.h"
 #include "scenario_device.h"
+#include "scenario_wave.h"
 
 namespace cn {
 
@@ -533,6 +534,60 @@ __global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, ScenarioCfg 
     Mt19937 rng = make_rng<IN_LDS>(S.ring_mt_key + idx, P.B * D);
     generate_scenario(C, rng, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr, S.ring_goal,
                       S.ring_rv);
+}
+
+// ---- wave-cooperative variants (scenario_wave.h): one 64-lane workgroup per scenario -----------------------------
+__global__ __launch_bounds__(kWave) void reset_wave_kernel(Params P, ScenarioCfg C, StateView S, const uint32_t* seeds,
+                                                          const uint8_t* mask, uint64_t* draws) {
+    __shared__ WaveScratch scratch;
+    const int b = blockIdx.x;
+    if (mask && !mask[b]) return;
+    const uint64_t n = generate_scenario_wave(C, scratch, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+    if (threadIdx.x == 0) {
+        S.mt_pos[b] = -1;  // the env's own generator state is not kept by this path
+        S.gtime[b] = 0.0;
+        if (draws) draws[b] = n;
+    }
+}
+
+__global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
+    __shared__ WaveScratch scratch;
+    const int b = blockIdx.x;
+    const cn_rollout_io io = *R.io;
+    const int64_t c0 = episode_id(io, b, 0);
+    const bool on = io.episode_limit < 0 || c0 < io.episode_limit;
+    if (threadIdx.x == 0) {
+        io.active[b] = on ? kRunning : kRetired;
+        io.ep_count[b] = 0;
+        io.cur_steps[b] = 0;
+        io.cur_return[b] = 0.0;
+        if (io.cur_danger) io.cur_danger[b] = 0;
+        if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[b] = 0.0;
+        S.ring_filled_in[b] = 0;
+        S.ring_filled_out[b] = 0;
+        S.gtime[b] = 0.0;
+        S.mt_pos[b] = -1;
+    }
+    if (!on) return;
+    generate_scenario_wave(C, scratch, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+}
+
+__global__ __launch_bounds__(kWave) void ring_fill_wave_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
+    __shared__ WaveScratch scratch;
+    const int idx = blockIdx.x;  // (env, ring slot)
+    const int D = P.ring_depth;
+    const int b = idx / D, slot = idx - b * D;
+    const cn_rollout_io io = *R.io;
+    const int state = io.active[b];
+    const int next = io.ep_count[b] + (state == kWaitingScenario ? 0 : 1);
+    if (slot == 0 && threadIdx.x == 0) S.ring_filled_out[b] = next + D;
+    if (state == kRetired) return;
+    const int ordinal = next + ((slot - next % D) + D) % D;
+    if (ordinal < S.ring_filled_in[b]) return;
+    const int64_t c = episode_id(io, b, ordinal);
+    if (io.episode_limit >= 0 && c >= io.episode_limit) return;
+    generate_scenario_wave(C, scratch, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr,
+                           S.ring_goal, S.ring_rv);
 }
 
 __device__ __forceinline__ void load_from_ring(const Params& P, const StateView& S, const Lane& L, int slot,

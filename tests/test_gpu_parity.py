@@ -287,3 +287,52 @@ def test_config4_shard_size_4096x20(amd, oracle_mod):
     assert np.array_equal(_np(eng.get_state()[0]), o.get_state()[0])
     still = b_full['ep_count'][:n] == 0  # envs still in their first episode: device-generated scenario vs oracle
     assert still.sum() >= n // 2 and np.abs(s_full[:n][still] - o.get_state()[0][still]).max() <= 1e-9
+
+
+@pytest.fixture
+def wave_scenarios(monkeypatch):
+    """Force the wave-per-scenario generators (default only for H > 8) so that they are checked on every fixture."""
+    monkeypatch.setenv('CROWDNAV_AMD_WAVE_SCENARIOS', '1')
+
+
+@pytest.mark.parametrize('name', sorted(RESET_SPECS))
+def test_wave_cooperative_reset_vs_reference_generator(amd, oracle_mod, wave_scenarios, name):
+    g = load_golden('resets.npz')
+    want, seeds = g[name + '_states'], g[name + '_seeds']
+    eng = amd.BatchedCrowdSim(num_envs=len(seeds), **RESET_SPECS[name])
+    draws = _np(eng.reset(seeds))
+    got, gt = (_np(x) for x in eng.get_state())
+    assert np.all(gt == 0.0) and np.abs(got - want).max() <= 1e-12
+    assert np.array_equal(got[:, :, 6:], want[:, :, 6:]) and np.array_equal(got[:, 0], want[:, 0])
+    o = oracle_mod.CrowdOracle(num_envs=len(seeds), **RESET_SPECS[name])
+    assert np.array_equal(draws.astype(np.uint64), o.reset(seeds))  # identical stream consumption
+
+
+def test_wave_cooperative_equals_lane_generators_in_rollouts(amd, wave_scenarios, monkeypatch):
+    """Same fused rollout with both generator families (ring fill + begin): bit-identical states and records."""
+    def run():
+        eng = amd.BatchedCrowdSim(num_envs=96, robot_policy=amd.ROBOT_ORCA, robot_visible=1, randomize_attributes=1)
+        bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, record_capacity=8)
+        eng.rollout(120)
+        eng.sync()
+        return _np(eng.get_state()[0]), {k: _np(v) for k, v in bufs.items()}
+    s_wave, b_wave = run()
+    monkeypatch.setenv('CROWDNAV_AMD_WAVE_SCENARIOS', '0')
+    s_lane, b_lane = run()
+    assert np.array_equal(s_wave, s_lane)
+    for k in b_wave:
+        assert np.array_equal(b_wave[k], b_lane[k]), k
+    assert b_wave['ep_count'].sum() > 96
+
+
+@pytest.mark.parametrize('humans', [6, 12])
+def test_unsatisfiable_scenario_is_reported_not_hung(amd, monkeypatch, humans):
+    """A circle too small for the crowd makes the reference's rejection sampling loop forever; the engine gives up
+    after a bounded number of attempts and reports it at the next sync (both generator families)."""
+    monkeypatch.setenv('CROWDNAV_AMD_MAX_ATTEMPTS_LOG2', '10')
+    eng = amd.BatchedCrowdSim(num_envs=8, num_humans=humans, circle_radius=0.3)
+    with pytest.raises(amd.CrowdNavAmdError) as ei:
+        eng.reset(1000 + np.arange(8))
+    assert 'rejected placements' in str(ei.value)
+    eng.sync()  # the flag is cleared once reported
+    assert np.all(np.isfinite(_np(eng.get_state()[0])))
