@@ -186,7 +186,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->C.robot_radius = c->robot_radius;
     e->C.robot_v_pref = c->robot_v_pref;
     // give-up threshold of the rejection sampling: ~seconds of GPU time in either generator family
-    int cap_log2 = env_int("CROWDNAV_AMD_MAX_ATTEMPTS_LOG2", c->num_humans > 8 ? 26 : 20);
+    int cap_log2 = env_int("CROWDNAV_AMD_MAX_ATTEMPTS_LOG2", c->num_humans > 8 ? 23 : 20);
     if (cap_log2 < 6) cap_log2 = 6;
     if (cap_log2 > 40) cap_log2 = 40;
     e->C.max_attempts = 1ull << cap_log2;
