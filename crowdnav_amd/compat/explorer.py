@@ -46,7 +46,12 @@ class Explorer(object):
         batched = (on_device and not update_memory and hasattr(self.env, 'engine_config')
                    and self.env.case_counter[phase] >= 0
                    and self.env.case_counter[phase] + k <= self.env.case_size[phase])  # no wrap of the case table
-        if batched:
+        no_wrap = (self.env.case_counter[phase] >= 0 and self.env.case_counter[phase] + k <= self.env.case_size[phase])
+        batched_il = (is_device_orca(self.robot.policy) and update_memory and imitation_learning and no_wrap
+                      and hasattr(self.env, 'engine_config') and isinstance(self.target_policy, SARL))
+        if batched_il:
+            stats = self._run_batched_imitation(k, phase)
+        elif batched:
             stats = self._run_batched(k, phase)
         else:
             stats = self._run_sequential(k, phase, update_memory, imitation_learning)
@@ -142,6 +147,94 @@ class Explorer(object):
         dsum = float(sum(rec['ep_danger_dmin_sum'][b, j] for b, j in order))
         return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, too_close,
                 dsum / too_close if too_close else 0, returns)
+
+    def _run_batched_imitation(self, k, phase):
+        """Imitation-learning data collection (train.py:115-129): k ORCA-robot episodes in lock step on the device,
+        then update_memory(..., imitation_learning=True) for all of them at once — per-step joint states are turned
+        into the value network's input with the target policy's own transform (vectorised), values are the discounted
+        Monte-Carlo returns of explorer.py:100-105, and (state, value) pairs enter the memory in the reference's order."""
+        import numpy as np
+        env, policy = self.env, self.target_policy
+        self.robot.time_step = env.time_step
+        self.robot.policy.time_step = env.time_step
+        multi = getattr(self.robot.policy, 'multiagent_training', None)
+        if phase == 'test':
+            human_num, rule = env.human_num, env.test_sim
+        else:
+            human_num, rule = (env.human_num if multi else 1), ('circle_crossing' if not multi else env.train_val_sim)
+        offset = {'train': env.case_capacity['val'] + env.case_capacity['test'], 'val': 0,
+                  'test': env.case_capacity['val']}[phase]
+        start, dt, vp = env.case_counter[phase], env.time_step, self.robot.v_pref
+        max_steps = int(round(env.time_limit / dt)) + 2
+        outcome, length, rewards_all, states_all, danger_n, danger_sum = [], [], [], [], 0, 0.0
+        for c0 in range(0, k, self.max_envs):
+            B = min(self.max_envs, k - c0)
+            eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
+            eng.reset(offset + start + c0 + np.arange(B))
+            hist_s, hist_r, hist_i, hist_d = [], [], [], []
+            alive = torch.ones(B, dtype=torch.bool, device=eng.device)
+            for _ in range(max_steps):
+                hist_s.append(eng.get_state()[0])
+                out = eng.step(None, update=True, want_obs=False)
+                hist_r.append(out['reward'])
+                hist_i.append(out['info'])
+                hist_d.append(out['dmin'])
+                alive = alive & (out['done'] == 0)
+                if not bool(alive.any().item()):
+                    break
+            S = torch.stack(hist_s).cpu().numpy()      # [T, B, A, 8]
+            R = torch.stack(hist_r).cpu().numpy()      # [T, B]
+            I = torch.stack(hist_i).cpu().numpy()
+            D = torch.stack(hist_d).cpu().numpy()
+            for b in range(B):
+                T = int(np.argmax(I[:, b] >= _lib.REACH_GOAL)) + 1  # first terminal step
+                outcome.append(int(I[T - 1, b]))
+                length.append(T)
+                rewards_all.append(R[:T, b].tolist())
+                states_all.append(S[:T, b])
+                dang = I[:T, b] == _lib.DANGER
+                danger_n += int(dang.sum())
+                danger_sum += float(D[:T, b][dang].sum())
+        env.case_counter[phase] = (start + k) % env.case_size[phase]
+
+        # explorer.py:66-69, 92-125 for every ReachGoal / Collision episode, batched
+        keep = [e for e in range(k) if outcome[e] in (_lib.REACH_GOAL, _lib.COLLISION)]
+        if keep:
+            if self.memory is None or self.gamma is None:
+                raise ValueError('Memory or gamma value is not set!')
+            rows, values = [], []
+            for e in keep:
+                st, rw = states_all[e], rewards_all[e]
+                robot = st[:, 0]
+                me = np.stack([robot[:, 0], robot[:, 1], robot[:, 2], robot[:, 3], robot[:, 6], robot[:, 4], robot[:, 5],
+                               robot[:, 7], np.full(len(st), np.pi / 2)], axis=1)              # FullState order
+                hum = st[:, 1:][:, :, [0, 1, 2, 3, 6]]                                          # ObservableState order
+                rows.append(np.concatenate([np.repeat(me[:, None, :], hum.shape[1], axis=1), hum], axis=2))
+                for i in range(len(rw)):
+                    values.append(sum([pow(self.gamma, max(t - i, 0) * dt * vp) * r * (1 if t >= i else 0)
+                                       for t, r in enumerate(rw)]))
+            joint = torch.Tensor(np.concatenate(rows, axis=0))                                  # [N, H, 14] float32
+            n, h, _ = joint.shape
+            from .sarl import occupancy_maps, rotate
+            x = rotate(joint.reshape(n * h, 14)).reshape(n, h, 13)
+            if policy.with_om:
+                from .types import ObservableState
+                maps = [occupancy_maps([ObservableState(*row) for row in js[:, 9:14].double().tolist()], policy.cell_num,
+                                       policy.cell_size, policy.om_channel_size) for js in joint]
+                x = torch.cat([x, torch.stack(maps)], dim=2)
+            x = x.to(self.device)
+            for j in range(n):
+                self.memory.push((x[j], torch.Tensor([values[j]]).to(self.device)))
+
+        times = [length[e] * dt for e in range(k)]
+        success_times = [times[e] for e in range(k) if outcome[e] == _lib.REACH_GOAL]
+        collision_times = [times[e] for e in range(k) if outcome[e] == _lib.COLLISION]
+        timeout_times = [env.time_limit for e in range(k) if outcome[e] == _lib.TIMEOUT]
+        collision_cases = [e for e in range(k) if outcome[e] == _lib.COLLISION]
+        timeout_cases = [e for e in range(k) if outcome[e] == _lib.TIMEOUT]
+        returns = [sum([pow(self.gamma, t * dt * vp) * r for t, r in enumerate(rw)]) for rw in rewards_all]
+        return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, danger_n,
+                danger_sum / danger_n if danger_n else 0, returns)
 
     def _report(self, k, phase, episode, print_failure, success_times, collision_times, timeout_times,
                 collision_cases, timeout_cases, too_close, avg_min_dist, cumulative_rewards):

@@ -217,3 +217,47 @@ def test_train_schedule_smoke_config5():
     assert np.isfinite(out['il_loss']) and np.isfinite(out['rl_loss'])
     s = out['stats']
     assert 0.0 <= s['success_rate'] <= 1.0 and abs(s['success_rate'] + s['collision_rate'] - 1.0) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_om', [False, True])
+def test_batched_imitation_collection_equals_sequential(with_om):
+    """Explorer.run_k_episodes(k, 'train', update_memory=True, imitation_learning=True): the lock-step batched
+    collection fills the replay memory with the same (state, value) pairs, in the same order, as the reference loop."""
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config
+    from crowdnav_amd.compat.trainer import ReplayMemory
+
+    def collect(force_sequential):
+        cfg = c.default_env_config()
+        env = c.CrowdSim()
+        env.configure(cfg)
+        robot = c.Robot(cfg, 'robot')
+        target = c.policy_factory['sarl']()
+        target.configure(default_policy_config({('sarl', 'with_om'): 'true' if with_om else 'false'}))
+        target.set_device(torch.device('cpu'))
+        il = c.policy_factory['orca']()
+        il.multiagent_training, il.safety_space = target.multiagent_training, 0.15
+        robot.set_policy(il)
+        env.set_robot(robot)
+        mem = ReplayMemory(100000)
+        ex = c.Explorer(env, robot, torch.device('cpu'), mem, 0.9, target_policy=target)
+        if force_sequential:
+            robot.policy.set_phase('train')
+            stats = ex._run_sequential(7, 'train', True, True)
+            ex._report(7, 'train', None, False, *stats)
+        else:
+            ex.run_k_episodes(7, 'train', update_memory=True, imitation_learning=True)
+        return mem, dict(ex.last_stats), env.case_counter['train']
+
+    mem_b, stats_b, cc_b = collect(False)
+    mem_s, stats_s, cc_s = collect(True)
+    assert cc_b == cc_s == 7 and len(mem_b) == len(mem_s) > 50
+    for key in ('success_rate', 'collision_rate', 'too_close', 'collision_cases', 'timeout_cases'):
+        assert stats_b[key] == stats_s[key], key
+    xb = torch.stack([m[0] for m in mem_b.memory])
+    xs = torch.stack([m[0] for m in mem_s.memory])
+    vb = torch.cat([m[1] for m in mem_b.memory])
+    vs = torch.cat([m[1] for m in mem_s.memory])
+    assert xb.shape == xs.shape and (xb - xs).abs().max() <= 5e-6  # torch vectorised vs per-state atan2/cos/sin: 1 ulp at |x| ~ 8
+    assert torch.equal(vb, vs)
