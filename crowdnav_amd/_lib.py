@@ -63,7 +63,7 @@ class CnSarlConfig(C.Structure):
         ('n_actions', C.c_int32), ('with_om', C.c_int32), ('cell_num', C.c_int32), ('om_channel_size', C.c_int32),
         ('cell_size', C.c_double), ('gamma', C.c_double), ('with_global_state', C.c_int32),
         ('mlp1_dims', C.c_int32 * 2), ('mlp2_dims', C.c_int32 * 2), ('attention_dims', C.c_int32 * 3),
-        ('mlp3_dims', C.c_int32 * 4), ('reserved', C.c_int32),
+        ('mlp3_dims', C.c_int32 * 4), ('model', C.c_int32),
     ]
 
 

@@ -5,6 +5,7 @@ from .crowd_sim import CrowdSim, default_env_config
 from .explorer import Explorer
 from .policy import ORCA, Policy, policy_factory, _register_trainable
 from .sarl import SARL, ValueNetwork, build_action_space
+from .cadrl import CADRL
 from .types import (ActionRot, ActionXY, Collision, Danger, FullState, JointState, Nothing, ObservableState,
                     ReachGoal, Timeout)
 
@@ -17,6 +18,6 @@ def register():
     gym_register(id='CrowdSim-v0', entry_point='crowdnav_amd.compat:CrowdSim')
 
 
-__all__ = ['CrowdSim', 'Explorer', 'Robot', 'Human', 'ORCA', 'SARL', 'ValueNetwork', 'build_action_space', 'Policy', 'policy_factory', 'default_env_config',
+__all__ = ['CrowdSim', 'Explorer', 'Robot', 'Human', 'ORCA', 'SARL', 'CADRL', 'ValueNetwork', 'build_action_space', 'Policy', 'policy_factory', 'default_env_config',
            'register', 'ActionXY', 'ActionRot', 'ObservableState', 'FullState', 'JointState', 'Timeout',
            'ReachGoal', 'Danger', 'Collision', 'Nothing']

@@ -70,5 +70,7 @@ policy_factory = {'orca': ORCA, 'none': lambda: None}
 
 def _register_trainable():
     from .sarl import SARL  # late import: sarl.py imports this module
+    from .cadrl import CADRL
     policy_factory['sarl'] = SARL
+    policy_factory['cadrl'] = CADRL
 

@@ -183,6 +183,7 @@ def default_policy_config(overrides=None):
         'om': dict(cell_num=4, cell_size=1, om_channel_size=3),
         'action_space': dict(kinematics='holonomic', speed_samples=5, rotation_samples=16, sampling='exponential',
                              query_env='true'),
+        'cadrl': dict(mlp_dims='150, 100, 100, 1', multiagent_training='false'),
         'sarl': dict(mlp1_dims='150, 100', mlp2_dims='100, 50', attention_dims='100, 100, 1',
                      mlp3_dims='150, 100, 100, 1', multiagent_training='true', with_om='false',
                      with_global_state='true'),

@@ -418,6 +418,39 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
     }
 }
 
+// cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row, then the minimum over the humans
+// of a group (cadrl.py:162-163).  Layers live in L[kL_mlp3_0 .. kL_mlp3_6]; buffers as in the SARL kernel.
+template <int H>
+__global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+    extern __shared__ float lds[];
+    float* bufA = lds;
+    float* bufB = bufA + H * net.ks_a * 64;
+    float* sbuf = bufB + H * net.ks_b * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t tile = blockIdx.x;
+    const float* xg = X + tile * H * net.ks_x * 64;
+    for (int i = tid; i < H * net.ks_x * 64; i += kSarlThreads) bufB[i] = xg[i];
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_mlp3_0], bufB, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_mlp3_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_mlp3_4], bufB, net.ks_b, bufA, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<H>(net.L[kL_mlp3_6], bufA, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
+    __syncthreads();
+    if (tid < kSarlGroups) {
+        float m = sbuf[tid];
+#pragma unroll
+        for (int h = 1; h < H; ++h) {
+            const float v = sbuf[h * net.ks_s * 64 + tid];
+            m = v < m ? v : m;  // torch.min over dim 0: the first minimum's value
+        }
+        const size_t G = tile * kSarlGroups + tid;
+        if (G < (size_t)n_groups) V[G] = m;
+    }
+}
+
 __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
     const size_t H = (size_t)net.H;
     return sizeof(float) * 64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a);

@@ -162,6 +162,13 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
 /* ------------------------------------------------------------------------------------------------------
  * SARL robot decision (crowd_nav/policy/sarl.py:9-86 on top of multi_human_rl.py:11-63, cadrl.py:82-222).
  * Needs robot_policy == CN_ROBOT_EXTERNAL: the chosen action is then applied with cn_step(action). */
+/* value network behind cn_sarl_select:
+ *   CN_MODEL_SARL   sarl.ValueNetwork (attention over humans, sarl.py:9-65)
+ *   CN_MODEL_CADRL  cadrl.ValueNetwork: one MLP per (robot, human) pair, value = min over humans
+ *                   (crowd_nav/policy/cadrl.py:22-29, 156-168); only mlp3_dims (= [cadrl] mlp_dims), n_actions, gamma
+ *                   are read; cn_sarl_set_weights then takes 8 pointers (value_network.{0,2,4,6}.{weight,bias}) */
+enum { CN_MODEL_SARL = 0, CN_MODEL_CADRL = 1 };
+
 typedef struct cn_sarl_config {
     int32_t n_actions;          /* 81 = speed_samples * rotation_samples + 1 (cadrl.py:82-102) */
     int32_t with_om;            /* [sarl] with_om: append the occupancy map (multi_human_rl.py:109-163) */
@@ -173,8 +180,8 @@ typedef struct cn_sarl_config {
     int32_t mlp1_dims[2];       /* [sarl] mlp1_dims      (150, 100) */
     int32_t mlp2_dims[2];       /* [sarl] mlp2_dims      (100, 50) */
     int32_t attention_dims[3];  /* [sarl] attention_dims (100, 100, 1) */
-    int32_t mlp3_dims[4];       /* [sarl] mlp3_dims      (150, 100, 100, 1) */
-    int32_t reserved;
+    int32_t mlp3_dims[4];       /* [sarl] mlp3_dims      (150, 100, 100, 1); CN_MODEL_CADRL: [cadrl] mlp_dims */
+    int32_t model;              /* CN_MODEL_SARL (0) or CN_MODEL_CADRL (1) */
 } cn_sarl_config;
 
 /* replaces SARL.configure + CADRL.build_action_space: actions_host = double [n_actions][2] (ActionXY table, HOST

@@ -25,11 +25,11 @@ def snapshot(env):
     return np.array([[a.px, a.py, a.vx, a.vy, a.gx, a.gy, a.radius, a.v_pref] for a in [env.robot] + env.humans])
 
 
-def generate(name, with_om, robot_visible, cases, max_steps):
+def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl'):
     rh.activate()
     torch.manual_seed(0)
     pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false'})
-    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name='sarl', policy_config=pcfg)
+    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
     policy.set_device(torch.device('cpu'))
     policy.set_phase('test')
     policy.set_env(env)
@@ -60,7 +60,8 @@ def generate(name, with_om, robot_visible, cases, max_steps):
                     x = torch.cat([x, om], dim=2)
                 rewards.append(float(reward))
                 inputs.append(x[0].numpy().copy())
-                outs.append(float(model(x).data.item()))
+                outs.append(float(model(x).data.item()) if policy_name == 'sarl' else
+                            float(torch.min(model(x[0]), 0)[0].data.item()))  # cadrl.py:162-163
                 if nobs is None:
                     nobs = np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in nh], dtype=np.float64)
             chosen = [i for i, a in enumerate(policy.action_space) if a == action]
@@ -90,3 +91,4 @@ if __name__ == '__main__':
     assert rh.available()
     generate('sarl_plain.npz', with_om=False, robot_visible=False, cases=[0, 1, 2], max_steps=8)
     generate('sarl_om.npz', with_om=True, robot_visible=True, cases=[3, 4, 5], max_steps=8)
+    generate('cadrl_plain.npz', with_om=False, robot_visible=True, cases=[6, 7], max_steps=8, policy_name='cadrl')

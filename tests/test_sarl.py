@@ -261,3 +261,42 @@ def test_batched_imitation_collection_equals_sequential(with_om):
     vs = torch.cat([m[1] for m in mem_s.memory])
     assert xb.shape == xs.shape and (xb - xs).abs().max() <= 5e-6  # torch vectorised vs per-state atan2/cos/sin: 1 ulp at |x| ~ 8
     assert torch.equal(vb, vs)
+
+
+def _cadrl_mirror(g):
+    from crowdnav_amd.compat.cadrl import ValueNetwork
+    net = ValueNetwork(13, [150, 100, 100, 1])
+    net.load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param_')})
+    return net
+
+
+def test_cadrl_value_network_mirror_cpu():
+    g = load_golden('cadrl_plain.npz')
+    net = _cadrl_mirror(g)
+    x = torch.from_numpy(g['inputs'])  # [decisions, 81, H, 13]
+    with torch.no_grad():
+        out = net(x).squeeze(-1).min(dim=2)[0].numpy()  # min over humans (cadrl.py:162)
+    assert np.abs(out - g['net_out']).max() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_cadrl_select_vs_reference():
+    """§8(f): the CADRL head on the same device pipeline, vs the unmodified reference CADRL.predict."""
+    import crowdnav_amd
+    g = load_golden('cadrl_plain.npz')
+    n = len(g['states'])
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.set_state(g['states'], g['gtime'])
+    eng.sarl_configure(actions=g['action_space'], gamma=0.9, model='cadrl', mlp3_dims=(150, 100, 100, 1))
+    eng.sarl_set_weights(_cadrl_mirror(g).state_dict())
+    out = eng.sarl_select()
+    eng.sync()
+    cpu = lambda t: t.cpu().numpy()  # noqa: E731
+    assert np.array_equal(cpu(eng.sarl_export('reward')), g['rewards'])
+    assert np.abs(cpu(eng.sarl_export('X')) - g['inputs']).max() <= 5e-6
+    assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
+    assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
+    top2 = np.sort(g['values'], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 4e-6
+    assert clear.sum() >= n // 2 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
+    assert np.array_equal(cpu(out['action'])[clear], g['action'][clear])
