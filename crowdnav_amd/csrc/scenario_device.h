@@ -47,6 +47,53 @@ struct Mt19937 {
         return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     }
     __device__ double uniform(double lo, double hi) { return lo + (hi - lo) * random(); }
+    __device__ bool dead() const { return false; }
+};
+
+// Register-only generator for the FIRST 227 words of a freshly seeded stream: output i of the first block is
+//   temper(key[i + 397] ^ twist(key[i], key[i + 1]))  with key[] straight from init_genrand,
+// so two running copies of the seeding recurrence (at i and at i + 397) produce it without any memory.  Enough for
+// 113 np.random.random() calls — nearly every H <= 8 scenario (23 calls on average at H = 5); a stream that needs
+// more reports dead() and the caller regenerates the scenario with the memory-backed generator.
+struct Mt19937Head {
+    uint32_t lo0, lo1, hi;  // key[i], key[i + 1], key[i + 397]
+    int i;
+    bool exhausted;
+
+    __device__ static uint32_t advance(uint32_t s, uint32_t index) { return 1812433253u * (s ^ (s >> 30)) + index; }
+    __device__ void seed(uint32_t s) {
+        lo0 = s;
+        lo1 = advance(s, 1u);
+        uint32_t k = lo1;
+        for (uint32_t j = 2; j <= 397; ++j) k = advance(k, j);
+        hi = k;
+        i = 0;
+        exhausted = false;
+    }
+    __device__ uint32_t next32() {
+        if (i >= 227) {
+            exhausted = true;
+            return 0u;
+        }
+        const uint32_t y = (lo0 & 0x80000000u) | (lo1 & 0x7fffffffu);
+        uint32_t v = hi ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        lo0 = lo1;
+        lo1 = advance(lo1, (uint32_t)i + 2u);
+        hi = advance(hi, (uint32_t)i + 398u);  // key[624] is never used: i stops at 226
+        ++i;
+        v ^= (v >> 11);
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= (v >> 18);
+        return v;
+    }
+    __device__ double random() {
+        const uint32_t a = next32() >> 5;
+        const uint32_t b = next32() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ double uniform(double lo, double hi_) { return lo + (hi_ - lo) * random(); }
+    __device__ bool dead() const { return exhausted; }
 };
 
 // numpy's 2-vector norm on the reference image: sqrt(fma(y, y, x*x))
@@ -66,7 +113,8 @@ struct ScenarioCfg {
 
 // Writes agents [0, A) of one env into the SoA state (double2 planes indexed base + agent; vel may be NULL:
 // every agent starts at rest) and returns the number of np.random.random() calls consumed.
-__device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng, uint32_t seed, size_t base,
+template <class Rng>
+__device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Rng& rng, uint32_t seed, size_t base,
                                              double2* pos, double2* vel, double2* goal, double2* rv) {
     const double kPi = 3.141592653589793;
     rng.seed(seed);
@@ -104,6 +152,7 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
                     }
                 }
                 if (!collide) break;
+                if (rng.dead()) return draws;
                 if (++attempts >= c.max_attempts) {
                     *c.error = 1;
                     break;
@@ -128,6 +177,7 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
                     }
                 }
                 if (!collide) break;
+                if (rng.dead()) return draws;
                 if (++attempts >= c.max_attempts) {
                     *c.error = 1;
                     break;
@@ -146,6 +196,7 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Mt19937& rng,
                     }
                 }
                 if (!collide) break;
+                if (rng.dead()) return draws;
                 if (++attempts >= c.max_attempts) {
                     *c.error = 1;
                     break;

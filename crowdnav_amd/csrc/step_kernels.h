@@ -447,6 +447,27 @@ __device__ __forceinline__ void persist_mt(const Mt19937& rng, uint32_t* dst, in
     for (int i = 0; i < 624; ++i) dst[(size_t)i * stride] = rng.key[(size_t)i * rng.stride];
 }
 
+// Lane-per-scenario generation: try the register-only head generator first (no memory traffic), redo the scenario
+// with the memory-backed one in the rare case its 227 words do not suffice.  Returns random() calls consumed.
+template <bool IN_LDS>
+__device__ __forceinline__ uint64_t generate_scenario_lane(const ScenarioCfg& C, uint32_t seed, size_t base,
+                                                           double2* pos, double2* vel, double2* goal, double2* rv,
+                                                           uint32_t* hbm_column, int hbm_stride, bool keep_state,
+                                                           int* pos_out) {
+    if (!keep_state) {
+        Mt19937Head head;
+        const uint64_t n = generate_scenario(C, head, seed, base, pos, vel, goal, rv);
+        if (!head.dead()) return n;
+    }
+    Mt19937 rng = make_rng<IN_LDS>(hbm_column, hbm_stride);
+    const uint64_t n = generate_scenario(C, rng, seed, base, pos, vel, goal, rv);
+    if (keep_state) {
+        if (IN_LDS) persist_mt(rng, hbm_column, hbm_stride);
+        if (pos_out) *pos_out = rng.pos;
+    }
+    return n;
+}
+
 // np.random.seed(seed) + scenario of one env per lane (lane = env)
 template <bool IN_LDS>
 __global__ __launch_bounds__(kWave) void reset_kernel(Params P, ScenarioCfg C, StateView S, const uint32_t* seeds,
@@ -454,10 +475,8 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Params P, ScenarioCfg C, S
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
     if (mask && !mask[b]) return;
-    Mt19937 rng = make_rng<IN_LDS>(S.mt_key + b, P.B);
-    const uint64_t n = generate_scenario(C, rng, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
-    if (IN_LDS) persist_mt(rng, S.mt_key + b, P.B);
-    S.mt_pos[b] = rng.pos;
+    const uint64_t n = generate_scenario_lane<IN_LDS>(C, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv,
+                                                      S.mt_key + b, P.B, true, &S.mt_pos[b]);
     S.gtime[b] = 0.0;
     if (draws) draws[b] = n;
 }
@@ -505,10 +524,9 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, Scenario
     S.ring_filled_in[b] = 0;
     S.ring_filled_out[b] = 0;
     if (!on) return;
-    Mt19937 rng = make_rng<IN_LDS>(S.mt_key + b, P.B);
-    generate_scenario(C, rng, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
-    if (IN_LDS) persist_mt(rng, S.mt_key + b, P.B);
-    S.mt_pos[b] = rng.pos;
+    generate_scenario_lane<IN_LDS>(C, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv, S.mt_key + b,
+                                   P.B, false, nullptr);
+    S.mt_pos[b] = -1;
     S.gtime[b] = 0.0;
 }
 
@@ -531,9 +549,8 @@ __global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, ScenarioCfg 
     if (ordinal < S.ring_filled_in[b]) return;  // still resident from an earlier fill
     const int64_t c = episode_id(io, b, ordinal);
     if (io.episode_limit >= 0 && c >= io.episode_limit) return;
-    Mt19937 rng = make_rng<IN_LDS>(S.ring_mt_key + idx, P.B * D);
-    generate_scenario(C, rng, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr, S.ring_goal,
-                      S.ring_rv);
+    generate_scenario_lane<IN_LDS>(C, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr,
+                                   S.ring_goal, S.ring_rv, S.ring_mt_key + idx, P.B * D, false, nullptr);
 }
 
 // ---- wave-cooperative variants (scenario_wave.h): one 64-lane workgroup per scenario -----------------------------
