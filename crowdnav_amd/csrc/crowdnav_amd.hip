@@ -351,6 +351,9 @@ int cn_set_gamma(cn_engine* e, double gamma) {
     int rc = bind(e);
     if (rc) return rc;
     const int len = (int)std::ceil(e->cfg.time_limit / e->cfg.time_step) + 8;
+    if (len > cn::kMaxDiscount)
+        return fail(CN_ERR_UNSUPPORTED, "time_limit / time_step = %d steps per episode exceeds the %d the rollout kernel tabulates",
+                    len - 8, cn::kMaxDiscount - 8);
     std::vector<double> table((size_t)len);
     for (int t = 0; t < len; ++t) table[(size_t)t] = std::pow(gamma, t * e->cfg.time_step * e->cfg.robot_v_pref);
     CN_HIP(hipStreamSynchronize(e->stream));

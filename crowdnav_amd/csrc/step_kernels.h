@@ -88,10 +88,14 @@ struct Smem {
     int* pinfo;       // [pairs] packed pair descriptor
     int* count;       // [nA] neighbours kept
     int* flag;        // [nA] (robot lanes) per-env flag broadcast
+    double* disc;     // [kMaxDiscount] discount table gamma^(t dt v_pref) (rollout kernel only)
 };
 
+constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
+
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs) {
-    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64;
+    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 +
+           sizeof(double) * kMaxDiscount;
 }
 
 __device__ __forceinline__ Smem carve(const Params& P) {
@@ -111,7 +115,8 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.count = reinterpret_cast<int*>(p), p += 4 * nA;
     s.flag = reinterpret_cast<int*>(p), p += 4 * nA;
     s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
-    s.pinfo = reinterpret_cast<int*>(p);
+    s.pinfo = reinterpret_cast<int*>(p), p += 4 * P.pairs;
+    s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
     return s;
 }
 
@@ -677,6 +682,8 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
     __syncthreads();
     if (L.valid && s.flag[L.ebase] >= 2) load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
     unsigned int transitions = 0;
+    for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
+    __syncthreads();
 
     for (int step = 0; step < n_steps; ++step) {
         Lane Ls = L;
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
         if (robot && state == kRunning) {
             int next_flag = 1;
             ++transitions;
-            const double disc = cur_steps < R.discount_len ? R.discount[cur_steps] : 0.0;
+            const double disc = cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0;
             cur_return = cur_return + disc * res.reward;  // python sum(): left to right
             ++cur_steps;
             if (res.info == CN_DANGER) {
