@@ -230,7 +230,8 @@ def main():
                    'parallelism': 'env-axis shards x%d, all-gather of episode summaries at the end' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(B, H, args.chunk),
-                     'kernel': 'cn::rollout_kernel', 'avg_launch_ms': avg_launch_s * 1e3,
+                     'kernel': 'cn::rollout_kernel (+ cn::ring_fill_kernel, ~2 % of the launch: one cn_rollout call)',
+                     'avg_launch_ms': avg_launch_s * 1e3,
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
         'paused_env_steps': paused_env_steps,
         'episodes_finished': int(summary[0].item()),
