@@ -350,3 +350,44 @@ def test_head_generator_overflow_falls_back_exactly(amd, oracle_mod):
     assert np.array_equal(draws.astype(np.uint64), want_draws)
     assert (want_draws > 113).sum() >= 3 and (want_draws <= 113).sum() >= 3  # both paths taken
     assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-12
+
+
+@pytest.mark.parametrize('humans,radius', [(1, 4.0), (63, 40.0)])
+def test_minimum_and_maximum_crowd_sizes(amd, oracle_mod, humans, radius):
+    """H = 1 (one candidate neighbour) and H = 63 (64 agents fill the wave; 4032 ordered pairs, 10 of 63 candidates
+    kept): ORCA velocities and transitions bit-identical to the oracle (which walks RVO2's kd-tree at 64 agents)."""
+    n = 6
+    cfg = dict(num_humans=humans, robot_visible=1, circle_radius=radius)
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=1, **cfg)
+    o.reset(1000 + np.arange(n))
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_ORCA, **cfg)
+    eng.set_state(o.get_state()[0], np.zeros(n))
+    for _ in range(12):
+        got = eng.step(None, update=True, want_obs=False)
+        want = o.step(None, update=True)
+        assert np.array_equal(_np(got['orca_vel']).view(np.uint32), want['orca_vel'].view(np.uint32))
+        assert np.array_equal(_np(got['reward']), want['reward']) and np.array_equal(_np(got['done']), want['done'])
+    assert np.array_equal(_np(eng.get_state()[0]), o.get_state()[0])
+
+
+@pytest.mark.parametrize('envs_per_wave,waves', [(3, 1), (4, 2), (10, 5)])
+def test_ragged_last_workgroup_and_geometry_knobs(amd, oracle_mod, monkeypatch, envs_per_wave, waves):
+    """B not a multiple of the envs per workgroup (last workgroup partly empty) and multi-wave workgroups: the
+    geometry is a pure performance knob — results identical to the oracle whatever it is."""
+    monkeypatch.setenv('CROWDNAV_AMD_ENVS_PER_WAVE', str(envs_per_wave))
+    monkeypatch.setenv('CROWDNAV_AMD_WAVES_PER_BLOCK', str(waves))
+    n = 23
+    cfg = dict(num_humans=5, robot_visible=1)
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_ORCA, **cfg)
+    bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, record_capacity=8)
+    eng.rollout(90)
+    eng.sync()
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=1, **cfg)
+    o.reset(1000 + np.arange(n))
+    total, rec = o.rollout(90, 1000, 500, 8, np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float64))
+    assert int(_np(bufs['transitions'])[0]) == total == n * 90
+    assert np.array_equal(_np(bufs['ep_count']), rec['count'])
+    k = int(rec['count'].max())
+    assert np.array_equal(_np(bufs['ep_outcome'])[:, :k] * (np.arange(k)[None] < rec['count'][:, None]),
+                          rec['outcome'][:, :k] * (np.arange(k)[None] < rec['count'][:, None]))
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
