@@ -273,15 +273,14 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
     for (int ct = wave; ct < P.ctiles; ct += kSarlThreads / 64) {
         // this lane's 4 accumulator rows of column n = ct*16 + col sit at 4 consecutive words of the out buffer
         const int frag_off = ((ct * 4 + (col >> 2)) * 64) + (col & 3) * 16 + quad * 4;
+        // accumulators start at zero; bias (L2) and the per-group extra term (LDS) are requested now and added in the
+        // epilogue, so their latency hides behind the k loop instead of opening the column tile
         f32x4 acc[RT];
         const float b0 = P.bias[ct * 16 + col];
-        f32x4 init = {b0, b0, b0, b0};
-        if (extra) {
-            const f32x4 e = *reinterpret_cast<const f32x4*>(extra + frag_off);
-            init += e;
-        }
+        f32x4 addend = {b0, b0, b0, b0};
+        if (extra) addend += *reinterpret_cast<const f32x4*>(extra + frag_off);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = init;
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
         // Straight-line k loop, 4 k-steps per trip, no conditionals (kpad <= ks_in by construction: every buffer
         // holds whole column tiles of its producer, zero beyond the true width, and the packed weights are zero
@@ -314,7 +313,7 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
         // k padding, so they are stored too
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            f32x4 v = acc[rt];
+            f32x4 v = acc[rt] + addend;
             if (relu) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
