@@ -111,3 +111,36 @@ def test_explorer_sequential_equals_batched():
         assert ex.last_stats[key] == batched[key], key
     assert abs(ex.last_stats['nav_time'] - batched['nav_time']) < 1e-12
     assert abs(ex.last_stats['total_reward'] - batched['total_reward']) < 1e-9
+
+
+@pytest.mark.gpu
+def test_debug_case_minus_one_and_square_crossing_through_gym_surface():
+    """reset('test', -1): the reference's fixed 3-human layout (exact distance ties, crowd_sim.py:286-292); and
+    env.test_sim = 'square_crossing' as test.py --square sets it (test.py:66-67)."""
+    c, env, robot = _setup(robot_visible=False)
+    g = load_golden('traj_debug_case.npz')
+    e = episodes_of(g)[0]
+    ob = env.reset('test', -1)
+    assert env.human_num == 3 and len(ob) == 3
+    assert np.array_equal(np.array([[h.px, h.py, h.gx, h.gy] for h in env.humans]), e['states'][0][1:, [0, 1, 4, 5]])
+    for t in range(len(e['actions'])):
+        action = robot.act(ob)
+        assert (action.vx, action.vy) == tuple(e['actions'][t])
+        ob, reward, done, info = env.step(action)
+        assert reward == e['rewards'][t]
+        assert np.array_equal(np.array([[h.px, h.py, h.vx, h.vy] for h in env.humans]), e['states'][t + 1][1:, :4])
+
+    c, env, robot = _setup(robot_visible=True)
+    env.test_sim = 'square_crossing'
+    g = load_golden('traj_visible_h5_square.npz')
+    e = episodes_of(g)[0]
+    ob = env.reset('test', int(g['cases'][0]))
+    got0 = np.array([[h.px, h.py, h.gx, h.gy] for h in env.humans])
+    assert np.abs(got0 - e['states'][0][1:, [0, 1, 4, 5]]).max() <= 1e-12  # no trigonometry in this rule: exact
+    assert np.array_equal(got0, e['states'][0][1:, [0, 1, 4, 5]])
+    for t in range(len(e['actions'])):
+        action = robot.act(ob)
+        assert (action.vx, action.vy) == tuple(e['actions'][t])
+        ob, reward, done, info = env.step(action)
+        assert reward == e['rewards'][t] and done == bool(e['dones'][t])
+    assert done
