@@ -226,7 +226,12 @@ class CrowdSim(_Base):
         eng = self._eng
         if getattr(eng, 'sarl', None) is None:
             eng.sarl_configure(**policy.engine_kwargs())
-        eng.sarl_set_weights(policy.model.state_dict())  # the Trainer may have stepped since the last call
+        # re-upload the parameters only when the Trainer (or a load_state_dict) has changed them: torch bumps a
+        # tensor's _version on every in-place update
+        stamp = (id(policy.model),) + tuple(p._version for p in policy.model.parameters())
+        if getattr(eng, '_sarl_weights_stamp', None) != stamp:
+            eng.sarl_set_weights(policy.model.state_dict())
+            eng._sarl_weights_stamp = stamp
         out = eng.sarl_select()
         return int(out['best'].cpu()[0]), out['values'].cpu().numpy()[0].tolist()
 

@@ -300,3 +300,21 @@ def test_cadrl_select_vs_reference():
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= n // 2 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
     assert np.array_equal(cpu(out['action'])[clear], g['action'][clear])
+
+
+@pytest.mark.gpu
+def test_policy_weights_are_reuploaded_only_when_they_change():
+    g = load_golden('sarl_plain.npz')
+    c, env, robot, policy = _sarl_setup(g)
+    ob = env.reset('test', 0)
+    a0 = robot.act(ob)
+    stamp = env._eng._sarl_weights_stamp
+    assert robot.act(ob) == a0 and env._eng._sarl_weights_stamp == stamp  # nothing changed: no re-upload
+    with torch.no_grad():
+        for p in policy.model.parameters():
+            p.mul_(-1.0)  # what an optimizer step does: in-place update
+    robot.act(ob)
+    assert env._eng._sarl_weights_stamp != stamp
+    vals_flipped = np.array(policy.action_values)
+    policy.model.load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param_')})
+    assert robot.act(ob) == a0 and not np.allclose(vals_flipped, np.array(policy.action_values))
