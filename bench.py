@@ -95,7 +95,7 @@ def bench_sarl(args, world, rank, local_rank):
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(envs, humans, target_seconds=12.0):
+def cpu_baseline(envs, humans, target_seconds=8.0):
     """The CPU oracle (oracle/crowd_oracle.cpp: same workload, same auto-reset rollout) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import numpy as np
@@ -113,7 +113,8 @@ def cpu_baseline(envs, humans, target_seconds=12.0):
     cores = crowd_oracle.CrowdOracle.max_threads()
     n, dt = run(cores, 4)  # calibration
     steps = max(4, min(2000, int(target_seconds * 0.6 / max(dt / 4, 1e-6))))
-    n_all, dt_all = run(cores, steps)
+    # the host is shared: keep the faster of two runs so that the CPU side is not under-reported
+    n_all, dt_all = min((run(cores, steps) for _ in range(2)), key=lambda r: r[1] / r[0])
     steps1 = max(2, int(steps / max(cores, 1) * 0.6))
     n_one, dt_one = run(1, steps1)
     crowd_oracle.CrowdOracle.set_threads(cores)
