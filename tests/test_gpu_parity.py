@@ -391,3 +391,36 @@ def test_ragged_last_workgroup_and_geometry_knobs(amd, oracle_mod, monkeypatch, 
     assert np.array_equal(_np(bufs['ep_outcome'])[:, :k] * (np.arange(k)[None] < rec['count'][:, None]),
                           rec['outcome'][:, :k] * (np.arange(k)[None] < rec['count'][:, None]))
     assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_randomised_configurations_vs_oracle(amd, oracle_mod, seed):
+    """Configuration fuzz: time step, limits, rewards, radii, preferred speeds, safety spaces, ORCA horizon /
+    neighbour parameters, visibility, crowd size, attribute randomisation, both scenario rules — 48 envs stepped
+    40 times with device-side ORCA robot, every output bit-identical to the oracle."""
+    rng = np.random.RandomState(100 + seed)
+    cfg = dict(
+        num_humans=int(rng.choice([2, 3, 5, 7, 9, 12])), robot_visible=int(rng.rand() < 0.5),
+        time_step=float(rng.choice([0.1, 0.2, 0.25, 0.5])), time_limit=float(rng.choice([6.0, 10.0, 25.0])),
+        success_reward=float(rng.uniform(0.5, 2.0)), collision_penalty=float(-rng.uniform(0.1, 1.0)),
+        discomfort_dist=float(rng.uniform(0.1, 0.4)), discomfort_penalty_factor=float(rng.uniform(0.2, 1.0)),
+        robot_safety_space=float(rng.choice([0.0, 0.15])), human_safety_space=float(rng.choice([0.0, 0.05])),
+        neighbor_dist=float(rng.choice([3.0, 10.0])), max_neighbors=int(rng.choice([3, 10])),
+        time_horizon=float(rng.choice([2.0, 5.0])), circle_radius=float(rng.uniform(4.0, 7.0)),
+        square_width=float(rng.uniform(10.0, 14.0)), scenario_rule=int(rng.rand() < 0.3),
+        human_radius=float(rng.uniform(0.2, 0.4)), human_v_pref=float(rng.uniform(0.6, 1.4)),
+        robot_radius=float(rng.uniform(0.2, 0.4)), robot_v_pref=float(rng.uniform(0.6, 1.4)),
+        randomize_attributes=int(rng.rand() < 0.4))
+    n = 48
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=1, **cfg)
+    o.reset(7000 + np.arange(n))
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_ORCA, **cfg)
+    eng.set_state(o.get_state()[0], np.zeros(n))
+    for _ in range(40):
+        got = eng.step(None, update=True, want_obs=False)
+        want = o.step(None, update=True)
+        assert np.array_equal(_np(got['orca_vel']).view(np.uint32), want['orca_vel'].view(np.uint32))
+        for k in ('reward', 'done', 'info', 'dmin', 'action'):
+            assert np.array_equal(_np(got[k]), want[k]), (k, cfg)
+    s, g = (_np(x) for x in eng.get_state())
+    assert np.array_equal(s, o.get_state()[0]) and np.array_equal(g, o.get_state()[1])
