@@ -6,6 +6,7 @@ from .explorer import Explorer
 from .policy import ORCA, Policy, policy_factory, _register_trainable
 from .sarl import SARL, ValueNetwork, build_action_space
 from .cadrl import CADRL
+from .lstm_rl import LstmRL
 from .types import (ActionRot, ActionXY, Collision, Danger, FullState, JointState, Nothing, ObservableState,
                     ReachGoal, Timeout)
 
@@ -18,6 +19,6 @@ def register():
     gym_register(id='CrowdSim-v0', entry_point='crowdnav_amd.compat:CrowdSim')
 
 
-__all__ = ['CrowdSim', 'Explorer', 'Robot', 'Human', 'ORCA', 'SARL', 'CADRL', 'ValueNetwork', 'build_action_space', 'Policy', 'policy_factory', 'default_env_config',
+__all__ = ['CrowdSim', 'Explorer', 'Robot', 'Human', 'ORCA', 'SARL', 'CADRL', 'LstmRL', 'ValueNetwork', 'build_action_space', 'Policy', 'policy_factory', 'default_env_config',
            'register', 'ActionXY', 'ActionRot', 'ObservableState', 'FullState', 'JointState', 'Timeout',
            'ReachGoal', 'Danger', 'Collision', 'Nothing']

@@ -71,6 +71,8 @@ policy_factory = {'orca': ORCA, 'none': lambda: None}
 def _register_trainable():
     from .sarl import SARL  # late import: sarl.py imports this module
     from .cadrl import CADRL
+    from .lstm_rl import LstmRL
     policy_factory['sarl'] = SARL
     policy_factory['cadrl'] = CADRL
+    policy_factory['lstm_rl'] = LstmRL
 

@@ -184,6 +184,8 @@ def default_policy_config(overrides=None):
         'action_space': dict(kinematics='holonomic', speed_samples=5, rotation_samples=16, sampling='exponential',
                              query_env='true'),
         'cadrl': dict(mlp_dims='150, 100, 100, 1', multiagent_training='false'),
+        'lstm_rl': dict(global_state_dim=50, mlp1_dims='150, 100, 100, 50', mlp2_dims='150, 100, 100, 1',
+                        multiagent_training='true', with_om='false', with_interaction_module='false'),
         'sarl': dict(mlp1_dims='150, 100', mlp2_dims='100, 50', attention_dims='100, 100, 1',
                      mlp3_dims='150, 100, 100, 1', multiagent_training='true', with_om='false',
                      with_global_state='true'),

@@ -450,6 +450,71 @@ __global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, co
     }
 }
 
+// lstm_rl.ValueNetwork1 (lstm_rl.py:9-33): an LSTM over the humans of a group (in the order the lookahead returns
+// them), its final hidden state joined with the robot's 6 self features into the value head.  Layers: L[kL_mlp1_0] =
+// weight_ih / bias_ih, L[kL_mlp1_2] = weight_hh / bias_hh (torch gate order i, f, g, o), L[kL_mlp3_*] = the head.
+// Row tile t of X is human t of the 16 groups = LSTM time step t, so each step is a 16-row product.
+template <int H>
+__global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+    extern __shared__ float lds[];
+    const int hid = net.L[kL_mlp1_2].K;                   // hidden width (50)
+    const int ks_h = (hid + 15) / 16 * 4, ks_g = net.L[kL_mlp1_0].ctiles * 4;
+    float* xs = lds;                                       // [H][ks_x][64]
+    float* gates = xs + H * net.ks_x * 64;                 // [ks_g][64]   i | f | g | o pre-activations
+    float* hbuf = gates + ks_g * 64;                       // [ks_h][64]   hidden state (A operand of the next step)
+    float* cbuf = hbuf + ks_h * 64;                        // [hid][16]    cell state
+    float* jbuf = cbuf + hid * kSarlGroups;                // [ks_a][64]
+    float* kbuf = jbuf + net.ks_a * 64;                    // [ks_a][64]
+    float* sbuf = kbuf + net.ks_a * 64;                    // [ks_s][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t tile = blockIdx.x;
+    const float* xg = X + tile * H * net.ks_x * 64;
+    for (int i = tid; i < H * net.ks_x * 64; i += kSarlThreads) xs[i] = xg[i];
+    for (int i = tid; i < ks_h * 64; i += kSarlThreads) hbuf[i] = 0.0f;   // h0 = 0
+    for (int i = tid; i < hid * kSarlGroups; i += kSarlThreads) cbuf[i] = 0.0f;  // c0 = 0
+    for (int i = tid; i < net.ks_a * 64; i += kSarlThreads) jbuf[i] = 0.0f;
+    __syncthreads();
+    if (tid < kSarlGroups * 6) {
+        const int g = tid & 15, n = tid >> 4;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];  // self_state = state[:, 0, :6]
+    }
+    for (int t = 0; t < H; ++t) {
+        dense_mfma<1>(net.L[kL_mlp1_0], xs + t * net.ks_x * 64, net.ks_x, gates, ks_g, false, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<1>(net.L[kL_mlp1_2], hbuf, ks_h, gates, ks_g, false, gates, wave, lane);  // + (W_hh h + b_hh)
+        __syncthreads();
+        for (int i = tid; i < hid * kSarlGroups; i += kSarlThreads) {
+            const int g = i & 15, j = i >> 4;
+            auto at = [&](int n) { return gates[(n >> 2) * 64 + (n & 3) * 16 + g]; };
+            const float ig = 1.0f / (1.0f + expf(-at(j)));
+            const float fg = 1.0f / (1.0f + expf(-at(hid + j)));
+            const float gg = tanhf(at(2 * hid + j));
+            const float og = 1.0f / (1.0f + expf(-at(3 * hid + j)));
+            const float c = fg * cbuf[i] + ig * gg;
+            cbuf[i] = c;
+            hbuf[(j >> 2) * 64 + (j & 3) * 16 + g] = og * tanhf(c);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < hid * kSarlGroups; i += kSarlThreads) {
+        const int g = i & 15, j = i >> 4, n = 6 + j;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = hbuf[(j >> 2) * 64 + (j & 3) * 16 + g];
+    }
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
+    __syncthreads();
+    if (tid < kSarlGroups) {
+        const size_t G = tile * kSarlGroups + tid;
+        if (G < (size_t)n_groups) V[G] = sbuf[tid];
+    }
+}
+
 __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
     const size_t H = (size_t)net.H;
     return sizeof(float) * 64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a);

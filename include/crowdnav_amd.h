@@ -166,8 +166,12 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
  *   CN_MODEL_SARL   sarl.ValueNetwork (attention over humans, sarl.py:9-65)
  *   CN_MODEL_CADRL  cadrl.ValueNetwork: one MLP per (robot, human) pair, value = min over humans
  *                   (crowd_nav/policy/cadrl.py:22-29, 156-168); only mlp3_dims (= [cadrl] mlp_dims), n_actions, gamma
- *                   are read; cn_sarl_set_weights then takes 8 pointers (value_network.{0,2,4,6}.{weight,bias}) */
-enum { CN_MODEL_SARL = 0, CN_MODEL_CADRL = 1 };
+ *                   are read; cn_sarl_set_weights then takes 8 pointers (value_network.{0,2,4,6}.{weight,bias})
+ *   CN_MODEL_LSTM_RL lstm_rl.ValueNetwork1 (LSTM over the humans + value head, lstm_rl.py:9-33; the variant the shipped
+ *                   policy.config selects, with_interaction_module = false): mlp1_dims[0] = [lstm_rl] global_state_dim,
+ *                   mlp3_dims = [lstm_rl] mlp2_dims, with_om as configured; cn_sarl_set_weights takes 12 pointers
+ *                   (mlp.{0,2,4,6}.{weight,bias}, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0) */
+enum { CN_MODEL_SARL = 0, CN_MODEL_CADRL = 1, CN_MODEL_LSTM_RL = 2 };
 
 typedef struct cn_sarl_config {
     int32_t n_actions;          /* 81 = speed_samples * rotation_samples + 1 (cadrl.py:82-102) */
@@ -181,7 +185,7 @@ typedef struct cn_sarl_config {
     int32_t mlp2_dims[2];       /* [sarl] mlp2_dims      (100, 50) */
     int32_t attention_dims[3];  /* [sarl] attention_dims (100, 100, 1) */
     int32_t mlp3_dims[4];       /* [sarl] mlp3_dims      (150, 100, 100, 1); CN_MODEL_CADRL: [cadrl] mlp_dims */
-    int32_t model;              /* CN_MODEL_SARL (0) or CN_MODEL_CADRL (1) */
+    int32_t model;              /* CN_MODEL_SARL (0), CN_MODEL_CADRL (1) or CN_MODEL_LSTM_RL (2) */
 } cn_sarl_config;
 
 /* replaces SARL.configure + CADRL.build_action_space: actions_host = double [n_actions][2] (ActionXY table, HOST

@@ -28,7 +28,8 @@ def snapshot(env):
 def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl'):
     rh.activate()
     torch.manual_seed(0)
-    pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false'})
+    pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
+                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false'})
     env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
     policy.set_device(torch.device('cpu'))
     policy.set_phase('test')
@@ -60,7 +61,7 @@ def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl')
                     x = torch.cat([x, om], dim=2)
                 rewards.append(float(reward))
                 inputs.append(x[0].numpy().copy())
-                outs.append(float(model(x).data.item()) if policy_name == 'sarl' else
+                outs.append(float(model(x).data.item()) if policy_name != 'cadrl' else
                             float(torch.min(model(x[0]), 0)[0].data.item()))  # cadrl.py:162-163
                 if nobs is None:
                     nobs = np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in nh], dtype=np.float64)
@@ -92,3 +93,4 @@ if __name__ == '__main__':
     generate('sarl_plain.npz', with_om=False, robot_visible=False, cases=[0, 1, 2], max_steps=8)
     generate('sarl_om.npz', with_om=True, robot_visible=True, cases=[3, 4, 5], max_steps=8)
     generate('cadrl_plain.npz', with_om=False, robot_visible=True, cases=[6, 7], max_steps=8, policy_name='cadrl')
+    generate('lstm_rl_om.npz', with_om=True, robot_visible=True, cases=[8, 9], max_steps=8, policy_name='lstm_rl')
