@@ -9,13 +9,14 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
 NOTHING, DANGER, REACH_GOAL, COLLISION, TIMEOUT = range(5)
 ROBOT_EXTERNAL, ROBOT_ORCA = 0, 1
 CIRCLE_CROSSING, SQUARE_CROSSING = 0, 1
+HOLONOMIC, UNICYCLE = 0, 1
 
 
 class CrowdNavAmdError(RuntimeError):
@@ -40,6 +41,7 @@ class CnConfig(C.Structure):
         ('human_radius', C.c_double), ('human_v_pref', C.c_double),
         ('robot_radius', C.c_double), ('robot_v_pref', C.c_double),
         ('randomize_attributes', C.c_int32), ('device', C.c_int32),
+        ('robot_kinematics', C.c_int32), ('reserved', C.c_int32),
     ]
 
 
@@ -78,6 +80,8 @@ SYMBOLS = {
     'cn_sync': (C.c_int, [_P]),
     'cn_set_state': (C.c_int, [_P, _P, _P]),
     'cn_get_state': (C.c_int, [_P, _P, _P]),
+    'cn_set_theta': (C.c_int, [_P, _P]),
+    'cn_get_theta': (C.c_int, [_P, _P]),
     'cn_drop_robot_sim': (C.c_int, [_P]),
     'cn_reset': (C.c_int, [_P, _P, _P, _P]),
     'cn_orca': (C.c_int, [_P, _P]),

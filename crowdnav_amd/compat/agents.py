@@ -54,13 +54,18 @@ class Agent(object):
         return self.vx, self.vy
 
     def compute_position(self, action, delta_t):
-        if self.kinematics != 'holonomic':
-            raise NotImplementedError('unicycle kinematics are outside the accelerated path')
-        return self.px + action.vx * delta_t, self.py + action.vy * delta_t
+        if self.kinematics == 'holonomic':
+            return self.px + action.vx * delta_t, self.py + action.vy * delta_t
+        theta = self.theta + action.r
+        return self.px + np.cos(theta) * action.v * delta_t, self.py + np.sin(theta) * action.v * delta_t
 
     def step(self, action):
         self.px, self.py = self.compute_position(action, self.time_step)
-        self.vx, self.vy = action.vx, action.vy
+        if self.kinematics == 'holonomic':
+            self.vx, self.vy = action.vx, action.vy
+        else:
+            self.theta = (self.theta + action.r) % (2 * np.pi)
+            self.vx, self.vy = action.v * np.cos(self.theta), action.v * np.sin(self.theta)
 
     def reached_destination(self):
         d = np.array(self.get_position()) - np.array(self.get_goal_position())

@@ -5,7 +5,7 @@
 
 Every transition (the humans' ORCA solves, collision / reward / done, integration) and every seeded reset runs
 in libcrowdnav_amd on the GPU; this class only moves the results into the objects the reference's callers read.
-Not covered (raise NotImplementedError): render, get_human_times, the 'mixed' scenario rule, unicycle robots —
+Not covered (raise NotImplementedError): render, get_human_times, the 'mixed' scenario rule —
 out of the accelerated path."""
 import configparser
 import logging
@@ -101,8 +101,11 @@ class CrowdSim(_Base):
         """cn_config for this env's settings (used for the 1-env engine and by Explorer's batched rollouts)."""
         if rule not in _RULES:
             raise NotImplementedError("scenario rule %r is outside the accelerated path" % rule)
-        if getattr(self.robot, 'kinematics', 'holonomic') != 'holonomic':
-            raise NotImplementedError('unicycle robots are outside the accelerated path')
+        kin = getattr(self.robot, 'kinematics', 'holonomic')
+        if kin not in ('holonomic', 'unicycle'):
+            raise NotImplementedError('robot kinematics %r' % (kin,))
+        if kin == 'unicycle' and robot_policy == _lib.ROBOT_ORCA:
+            raise NotImplementedError('the device ORCA robot is holonomic')
         pol = self.robot.policy
         return dict(
             num_envs=num_envs, num_humans=human_num, time_step=self.time_step, time_limit=float(self.time_limit),
@@ -113,7 +116,8 @@ class CrowdSim(_Base):
             scenario_rule=_RULES[rule], circle_radius=self.circle_radius, square_width=self.square_width,
             human_radius=self.config.getfloat('humans', 'radius'), human_v_pref=self.config.getfloat('humans', 'v_pref'),
             robot_radius=float(self.robot.radius), robot_v_pref=float(self.robot.v_pref),
-            randomize_attributes=int(bool(self.randomize_attributes)), device=self.device)
+            randomize_attributes=int(bool(self.randomize_attributes)), device=self.device,
+            robot_kinematics=_lib.UNICYCLE if kin == 'unicycle' else _lib.HOLONOMIC)
 
     def _engine(self, human_num, rule):
         cfg = self.engine_config(1, human_num, rule, _lib.ROBOT_EXTERNAL)
@@ -129,6 +133,7 @@ class CrowdSim(_Base):
         self.global_time = float(g.cpu()[0])
         r = s[0]
         self.robot.px, self.robot.py, self.robot.vx, self.robot.vy = (float(x) for x in r[:4])
+        self.robot.theta = float(self._eng.get_theta().cpu()[0])
         for h, row in zip(self.humans, s[1:]):
             h.set(*(float(row[i]) for i in (0, 1, 4, 5, 2, 3)), theta=0.0, radius=float(row[6]), v_pref=float(row[7]))
 
@@ -190,15 +195,17 @@ class CrowdSim(_Base):
         return self.step(action, update=False)
 
     def step(self, action, update=True):
-        if not isinstance(action, tuple) or not hasattr(action, 'vx'):
-            raise NotImplementedError('only holonomic ActionXY actions are on the accelerated path')
+        unicycle = getattr(self.robot, 'kinematics', 'holonomic') == 'unicycle'
+        if not isinstance(action, tuple) or not hasattr(action, 'v' if unicycle else 'vx'):
+            raise TypeError('expected %s for a %s robot' % ('ActionRot' if unicycle else 'ActionXY',
+                                                           'unicycle' if unicycle else 'holonomic'))
         if update:
             self.states.append([self.robot.get_full_state(), [h.get_full_state() for h in self.humans]])
             if hasattr(self.robot.policy, 'action_values'):
                 self.action_values.append(self.robot.policy.action_values)
             if hasattr(self.robot.policy, 'get_attention_weights'):
                 self.attention_weights.append(self.robot.policy.get_attention_weights())
-        out = self._eng.step(np.array([[action.vx, action.vy]], dtype=np.float64), update=update)
+        out = self._eng.step(np.array([list(action)], dtype=np.float64), update=update)  # (vx, vy) or (v, r)
         reward = float(out['reward'].cpu()[0])
         done = bool(out['done'].cpu()[0])
         info = info_from_code(out['info'].cpu()[0], out['dmin'].cpu()[0])

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .policy import Policy
-from .types import ActionXY
+from .types import ActionRot, ActionXY
 
 
 def mlp(input_dim, mlp_dims, last_relu=False):
@@ -60,13 +60,21 @@ class ValueNetwork(nn.Module):
         return self.mlp3(torch.cat([self_state, weighted], dim=1))
 
 
-def build_action_space(v_pref, speed_samples=5, rotation_samples=16):
-    """Holonomic action table of CADRL.build_action_space (cadrl.py:82-102): stop + rotations x speeds."""
+def build_action_space(v_pref, speed_samples=5, rotation_samples=16, kinematics='holonomic'):
+    """Action table of CADRL.build_action_space (cadrl.py:82-102): stop + rotations x speeds; ActionXY for a holonomic
+    robot, ActionRot(v, r) with r in [-pi/4, pi/4] for a unicycle one."""
+    holonomic = kinematics == 'holonomic'
     speeds = [(np.exp((i + 1) / speed_samples) - 1) / (np.e - 1) * v_pref for i in range(speed_samples)]
-    rotations = np.linspace(0, 2 * np.pi, rotation_samples, endpoint=False)
-    space = [ActionXY(0, 0)]
+    if holonomic:
+        rotations = np.linspace(0, 2 * np.pi, rotation_samples, endpoint=False)
+    else:
+        rotations = np.linspace(-np.pi / 4, np.pi / 4, rotation_samples)
+    space = [ActionXY(0, 0) if holonomic else ActionRot(0, 0)]
     for rotation, speed in itertools.product(rotations, speeds):
-        space.append(ActionXY(speed * np.cos(rotation), speed * np.sin(rotation)))
+        if holonomic:
+            space.append(ActionXY(speed * np.cos(rotation), speed * np.sin(rotation)))
+        else:
+            space.append(ActionRot(speed, rotation))
     return space, speeds, rotations
 
 
@@ -107,8 +115,8 @@ class SARL(Policy):
                 for k in ('mlp1_dims', 'mlp2_dims', 'mlp3_dims', 'attention_dims')}
         self.with_om = config.getboolean('sarl', 'with_om')
         with_global_state = config.getboolean('sarl', 'with_global_state')
-        if self.kinematics != 'holonomic' or not self.query_env:
-            raise NotImplementedError('only holonomic, query_env=true SARL is on the accelerated path')
+        if self.kinematics not in ('holonomic', 'unicycle') or not self.query_env:
+            raise NotImplementedError('only query_env=true SARL is on the accelerated path')
         self.model = ValueNetwork(self.input_dim(), self.self_state_dim, dims['mlp1_dims'], dims['mlp2_dims'],
                                   dims['mlp3_dims'], dims['attention_dims'], with_global_state, self.cell_size,
                                   self.cell_num)
@@ -134,10 +142,10 @@ class SARL(Policy):
 
     def build_action_space(self, v_pref):
         self.action_space, self.speeds, self.rotations = build_action_space(v_pref, self.speed_samples,
-                                                                          self.rotation_samples)
+                                                                          self.rotation_samples, self.kinematics)
 
     def action_table(self):
-        return np.array([[a.vx, a.vy] for a in self.action_space], dtype=np.float64)
+        return np.array([list(a) for a in self.action_space], dtype=np.float64)  # (vx, vy) or (v, r)
 
     def engine_kwargs(self):
         """Arguments of BatchedCrowdSim.sarl_configure for this policy."""
@@ -154,7 +162,7 @@ class SARL(Policy):
         if env is None or not hasattr(env, 'sarl_action'):
             raise RuntimeError('crowdnav_amd SARL needs policy.set_env(<crowdnav_amd CrowdSim>)')
         if self.reach_destination(state):
-            return ActionXY(0, 0)
+            return ActionXY(0, 0) if self.kinematics == 'holonomic' else ActionRot(0, 0)
         probability = np.random.random()  # drawn in every phase (multi_human_rl.py:28)
         if self.phase == 'train' and probability < self.epsilon:
             action = self.action_space[np.random.choice(len(self.action_space))]
@@ -195,14 +203,15 @@ def default_policy_config(overrides=None):
     return cfg
 
 
-def rotate(state):
-    """Agent-centric 13-vector rows from 14-float joint rows (CADRL.rotate, cadrl.py:187-222), holonomic."""
+def rotate(state, kinematics='holonomic'):
+    """Agent-centric 13-vector rows from 14-float joint rows (CADRL.rotate, cadrl.py:187-222)."""
     dx, dy = state[:, 5] - state[:, 0], state[:, 6] - state[:, 1]
     rot = torch.atan2(dy, dx)
     c, s = torch.cos(rot), torch.sin(rot)
     dg = torch.norm(torch.stack([dx, dy], dim=1), 2, dim=1)
     ex, ey = state[:, 9] - state[:, 0], state[:, 10] - state[:, 1]
-    cols = [dg, state[:, 7], torch.zeros_like(dg), state[:, 4],
+    theta = state[:, 8] - rot if kinematics == 'unicycle' else torch.zeros_like(dg)
+    cols = [dg, state[:, 7], theta, state[:, 4],
             state[:, 2] * c + state[:, 3] * s, state[:, 3] * c - state[:, 2] * s,
             ex * c + ey * s, ey * c - ex * s,
             state[:, 11] * c + state[:, 12] * s, state[:, 12] * c - state[:, 11] * s,
@@ -249,7 +258,7 @@ def occupancy_maps(human_states, cell_num, cell_size, channels):
 def _transform(self, state):
     """Replay-memory view of a joint state (MultiHumanRL.transform, multi_human_rl.py:90-104)."""
     rows = torch.cat([torch.Tensor([state.self_state + h]).to(self.device) for h in state.human_states], dim=0)
-    x = rotate(rows)
+    x = rotate(rows, self.kinematics)
     if self.with_om:
         om = occupancy_maps(state.human_states, self.cell_num, self.cell_size, self.om_channel_size)
         x = torch.cat([x, om.to(self.device)], dim=1)

@@ -110,7 +110,7 @@ inline int grid_lanes(const cn_engine* e) { return (e->P.B + cn::kWave - 1) / cn
 extern "C" {
 
 const char* cn_last_error(void) { return g_err; }
-int cn_abi_version(void) { return 1; }
+int cn_abi_version(void) { return 2; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
     if (!c || !out) return fail(CN_ERR_INVALID, "cn_create: NULL argument");
@@ -125,6 +125,10 @@ int cn_create(const cn_config* c, cn_engine** out) {
         return fail(CN_ERR_UNSUPPORTED, "scenario_rule %d not supported", c->scenario_rule);
     if (c->robot_policy != CN_ROBOT_EXTERNAL && c->robot_policy != CN_ROBOT_ORCA)
         return fail(CN_ERR_INVALID, "robot_policy %d unknown", c->robot_policy);
+    if (c->robot_kinematics != CN_HOLONOMIC && c->robot_kinematics != CN_UNICYCLE)
+        return fail(CN_ERR_INVALID, "robot_kinematics %d unknown", c->robot_kinematics);
+    if (c->robot_kinematics == CN_UNICYCLE && c->robot_policy == CN_ROBOT_ORCA)
+        return fail(CN_ERR_INVALID, "the ORCA robot policy is holonomic (orca.py:59); a unicycle robot needs CN_ROBOT_EXTERNAL");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -163,6 +167,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->gen_wave = env_int("CROWDNAV_AMD_WAVE_SCENARIOS", c->num_humans > 8 ? 1 : 0) != 0;
     P.robot_visible = c->robot_visible ? 1 : 0;
     P.robot_orca = c->robot_policy == CN_ROBOT_ORCA;
+    P.robot_unicycle = c->robot_kinematics == CN_UNICYCLE;
     P.dt = c->time_step;
     P.time_limit = c->time_limit;
     P.success_reward = c->success_reward;
@@ -197,6 +202,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     cn::StateView& S = e->S;
     if ((rc = dev_alloc(e, &S.pos, n)) || (rc = dev_alloc(e, &S.vel, n)) || (rc = dev_alloc(e, &S.goal, n)) ||
         (rc = dev_alloc(e, &S.rv, n)) || (rc = dev_alloc(e, &S.gtime, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &S.theta, (size_t)P.B)) ||
         (rc = dev_alloc(e, &S.rsim_radius, n)) || (rc = dev_alloc(e, &S.rsim_max_speed, (size_t)P.B)) ||
         (rc = dev_alloc(e, &S.rsim_valid, (size_t)P.B)) || (rc = dev_alloc(e, &S.mt_key, (size_t)624 * P.B)) ||
         (rc = dev_alloc(e, &S.mt_pos, (size_t)P.B)) || (rc = dev_alloc(e, &e->probe_key, (size_t)624)) ||
@@ -296,6 +302,22 @@ int cn_get_state(cn_engine* e, double* state8, double* global_time) {
     if (global_time)
         CN_HIP(hipMemcpyAsync(global_time, e->S.gtime, sizeof(double) * e->P.B, hipMemcpyDeviceToDevice, e->stream));
     CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
+int cn_set_theta(cn_engine* e, const double* theta) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if (!theta) return fail(CN_ERR_INVALID, "cn_set_theta: NULL");
+    CN_HIP(hipMemcpyAsync(e->S.theta, theta, sizeof(double) * e->P.B, hipMemcpyDeviceToDevice, e->stream));
+    return CN_OK;
+}
+
+int cn_get_theta(cn_engine* e, double* theta) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if (!theta) return fail(CN_ERR_INVALID, "cn_get_theta: NULL");
+    CN_HIP(hipMemcpyAsync(theta, e->S.theta, sizeof(double) * e->P.B, hipMemcpyDeviceToDevice, e->stream));
     return CN_OK;
 }
 

@@ -69,6 +69,7 @@ struct SarlNet {
 struct SarlCfg {
     int B, H, n_actions;
     int with_om, cell_num, om_channels;
+    int unicycle;  // actions are ActionRot(v, r): cadrl.py:119-125, crowd_sim.py:339-341
     double cell_size;
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double gamma_bar;  // pow(gamma, time_step * v_pref), computed on the host like multi_human_rl.py:52
@@ -150,14 +151,19 @@ __global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const doubl
 
 // Reward of onestep_lookahead(action) for every (env, action) (crowd_sim.py:331-389, update = False).
 __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* goal,
-                                   const double2* rv, const double* gtime, const double* actions /*[K][2]*/,
-                                   double* reward /*[B][K]*/) {
+                                   const double2* rv, const double* gtime, const double* theta,
+                                   const double* actions /*[K][2]*/, double* reward /*[B][K]*/) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= C.B * C.n_actions) return;
     const int b = idx / C.n_actions, a = idx - b * C.n_actions;
     const int A = C.H + 1;
     const size_t g0 = (size_t)b * A;
-    const double ax = actions[2 * a], ay = actions[2 * a + 1];
+    double ax = actions[2 * a], ay = actions[2 * a + 1];
+    const double rot_v = ax, rot_r = ay;
+    if (C.unicycle) {
+        ax = rot_v * cos(rot_r + theta[b]);
+        ay = rot_v * sin(rot_r + theta[b]);
+    }
     const double2 rp = pos[g0];
     const double rrad = rv[g0].x;
     double dmin = __builtin_inf();
@@ -184,7 +190,12 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
             dmin = c;
         }
     }
-    const double endx = rp.x + ax * C.dt, endy = rp.y + ay * C.dt;
+    double endx = rp.x + ax * C.dt, endy = rp.y + ay * C.dt;
+    if (C.unicycle) {
+        const double th = theta[b] + rot_r;
+        endx = rp.x + cos(th) * rot_v * C.dt;
+        endy = rp.y + sin(th) * rot_v * C.dt;
+    }
     const double2 gl = goal[g0];
     const bool reaching = norm2(endx - gl.x, endy - gl.y) < rrad;
     double r;
@@ -209,8 +220,8 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
 // X[((tile * H + h) * ks_x + n / 4) * 64 + (n % 4) * 16 + g] = feature n.  Lanes run over g fastest, so every
 // store instruction writes 16 consecutive words per (tile, h).
 __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
-                                    const double2* rv, const double* actions, const double* next_obs,
-                                    const float* om, float* X, size_t n_tiles) {
+                                    const double2* rv, const double* theta, const double* actions,
+                                    const double* next_obs, const float* om, float* X, size_t n_tiles) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_tiles * C.H * kSarlGroups) return;
     const int g = (int)(idx % kSarlGroups);
@@ -226,7 +237,14 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     const int b = (int)(G / C.n_actions);
     const size_t g0 = (size_t)b * (C.H + 1);
     // propagate(self_state, action) in float64 (cadrl.py:113-118), then torch.Tensor([...]) narrows to float32
-    const double ax = actions[2 * a], ay = actions[2 * a + 1];
+    double ax = actions[2 * a], ay = actions[2 * a + 1];
+    float theta_f = 0.0f;
+    if (C.unicycle) {  // cadrl.py:119-125: next_theta = theta + r, velocity v (cos, sin)(next_theta)
+        const double th = theta[b] + ay, v = ax;
+        ax = v * cos(th);
+        ay = v * sin(th);
+        theta_f = (float)th;
+    }
     const float px = (float)(pos[g0].x + ax * C.dt), py = (float)(pos[g0].y + ay * C.dt);
     const float vx = (float)ax, vy = (float)ay;
     const float radius = (float)rv[g0].x, v_pref = (float)rv[g0].y;
@@ -241,7 +259,7 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     float f[13];
     f[0] = dg;
     f[1] = v_pref;
-    f[2] = 0.0f;  // theta: unused for holonomic robots
+    f[2] = C.unicycle ? theta_f - rot : 0.0f;  // cadrl.py:207-211
     f[3] = radius;
     f[4] = vx * c + vy * s;
     f[5] = vy * c - vx * s;

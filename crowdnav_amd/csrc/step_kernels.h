@@ -36,6 +36,7 @@ struct Params {
     int pairs;         // nA * NC
     int ring_depth;    // scenarios kept ahead per env
     int robot_visible, robot_orca;
+    int robot_unicycle;  // external robot actions are ActionRot(v, r) (agent.py:115-135)
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double robot_safety, human_safety;
     OrcaParams orca;
@@ -47,6 +48,7 @@ struct StateView {
     double2* goal;
     double2* rv;  // (radius, v_pref)
     double* gtime;
+    double* theta;          // [B] robot heading (only a unicycle robot changes it)
     float* rsim_radius;     // [B*A] radii captured by the robot's persistent ORCA policy (orca.py:98-104)
     float* rsim_max_speed;  // [B]
     uint8_t* rsim_valid;    // [B]
@@ -278,18 +280,34 @@ struct StepResult {  // meaningful on the robot lane
 // One transition for the lane's agent (crowd_sim.py:317-420).  `r` is updated in place when update != 0.
 // new_vx/new_vy: the velocity this lane's agent chose (float32 for ORCA agents, the action for the robot).
 // Must be called by all 64 lanes (contains workgroup barriers).
+__device__ __forceinline__ double python_fmod(double x, double y) {  // python's float %: result takes the sign of y
+    double m = fmod(x, y);
+    if (m != 0.0 && ((m < 0.0) != (y < 0.0))) m += y;
+    return m;
+}
+
 template <int MAXL>
 __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
                                           double& gtime, float robot_max_speed, const double* ext_action,
-                                          int update, StepResult& res, double& new_vx, double& new_vy) {
+                                          int update, StepResult& res, double& new_vx, double& new_vy,
+                                          double* theta_io = nullptr) {
     float ovx, ovy;
     orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy);
     new_vx = ovx;
     new_vy = ovy;
+    // unicycle robot (ActionRot v, r): the collision test uses v (cos, sin)(r + theta) (crowd_sim.py:339-341), the
+    // move is compute_position's (agent.py:115-118)
+    const bool unicycle = P.robot_unicycle && !P.robot_orca && L.valid && L.a == 0;
+    double rot_v = 0.0, rot_r = 0.0, theta0 = 0.0;
     if (L.valid && L.a == 0) {
         if (!P.robot_orca) {
             new_vx = ext_action[2 * (size_t)L.env];
             new_vy = ext_action[2 * (size_t)L.env + 1];
+        }
+        if (unicycle) {
+            rot_v = new_vx, rot_r = new_vy, theta0 = *theta_io;
+            new_vx = rot_v * cos(rot_r + theta0);
+            new_vy = rot_v * sin(rot_r + theta0);
         }
         s.act[L.lane] = make_double2(new_vx, new_vy);
     }
@@ -314,7 +332,12 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
         const bool degenerate = (sx == 0.0 && sy == 0.0);  // utils.py:11-13
         const double cx = degenerate ? 0.0 - x1 : (x1 + u * sx) - 0.0;
         const double cy = degenerate ? 0.0 - y1 : (y1 + u * sy) - 0.0;
-        const double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+        double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+        if (unicycle) {
+            const double th = theta0 + rot_r;
+            endx = r.px + cos(th) * rot_v * P.dt;
+            endy = r.py + sin(th) * rot_v * P.dt;
+        }
         const double d = norm2(human ? cx : endx - r.gx, human ? cy : endy - r.gy);
         if (human) {
             s.closest[L.lane] = d - r.rad - s.rad[L.ebase];
@@ -349,14 +372,24 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
             res.reward = 0.0, res.done = 0, res.info = CN_NOTHING;
         }
         res.dmin = dmin;
-        res.ax = new_vx, res.ay = new_vy;
+        res.ax = unicycle ? rot_v : new_vx, res.ay = unicycle ? rot_r : new_vy;
         if (update) gtime += P.dt;
     }
     if (update && L.valid) {  // Agent.step (agent.py:127-135)
-        r.px = r.px + new_vx * P.dt;
-        r.py = r.py + new_vy * P.dt;
-        r.vx = new_vx;
-        r.vy = new_vy;
+        if (unicycle) {
+            const double th = theta0 + rot_r;
+            r.px = r.px + cos(th) * rot_v * P.dt;
+            r.py = r.py + sin(th) * rot_v * P.dt;
+            const double theta1 = python_fmod(theta0 + rot_r, 2 * 3.141592653589793);
+            r.vx = rot_v * cos(theta1);
+            r.vy = rot_v * sin(theta1);
+            *theta_io = theta1;
+        } else {
+            r.px = r.px + new_vx * P.dt;
+            r.py = r.py + new_vy * P.dt;
+            r.vx = new_vx;
+            r.vy = new_vy;
+        }
     }
 }
 
@@ -392,9 +425,10 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
     double gtime = (L.valid && L.a == 0) ? S.gtime[L.env] : 0.0;
     const AgentRegs before = r;
 
+    double theta = (L.valid && L.a == 0) ? S.theta[L.env] : 0.0;
     StepResult res;
     double nvx, nvy;
-    step_core<MAXL>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy);
+    step_core<MAXL>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta);
     if (!L.valid) return;
 
     if (L.a == 0) {
@@ -406,7 +440,10 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
             io.action_out[2 * (size_t)L.env] = res.ax;
             io.action_out[2 * (size_t)L.env + 1] = res.ay;
         }
-        if (io.update) S.gtime[L.env] = gtime;
+        if (io.update) {
+            S.gtime[L.env] = gtime;
+            S.theta[L.env] = theta;
+        }
         if (P.robot_orca) S.rsim_valid[L.env] = 1;
     }
     if (io.orca_vel) {
@@ -483,6 +520,7 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Params P, ScenarioCfg C, S
     const uint64_t n = generate_scenario_lane<IN_LDS>(C, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv,
                                                       S.mt_key + b, P.B, true, &S.mt_pos[b]);
     S.gtime[b] = 0.0;
+    S.theta[b] = 1.5707963267948966;  // robot.set(..., np.pi / 2)
     if (draws) draws[b] = n;
 }
 
@@ -568,6 +606,7 @@ __global__ __launch_bounds__(kWave) void reset_wave_kernel(Params P, ScenarioCfg
     if (threadIdx.x == 0) {
         S.mt_pos[b] = -1;  // the env's own generator state is not kept by this path
         S.gtime[b] = 0.0;
+        S.theta[b] = 1.5707963267948966;
         if (draws) draws[b] = n;
     }
 }

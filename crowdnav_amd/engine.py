@@ -22,7 +22,7 @@ _DEFAULTS = dict(
     robot_policy=_lib.ROBOT_ORCA, robot_safety_space=0.0, human_safety_space=0.0, neighbor_dist=10.0,
     max_neighbors=10, scenario_rule=_lib.CIRCLE_CROSSING, time_horizon=5.0, time_horizon_obst=5.0,
     circle_radius=4.0, square_width=10.0, human_radius=0.3, human_v_pref=1.0, robot_radius=0.3,
-    robot_v_pref=1.0, randomize_attributes=0, device=0)
+    robot_v_pref=1.0, randomize_attributes=0, device=0, robot_kinematics=_lib.HOLONOMIC, reserved=0)
 
 
 def default_config(**overrides):
@@ -96,6 +96,17 @@ class BatchedCrowdSim(object):
         g = self._new((self.B,), torch.float64)
         check(self._lib.cn_get_state(self._h, _ptr(s), _ptr(g)))
         return s, g
+
+    def set_theta(self, theta):
+        """Robot heading per env, [B] float64 (FullState.theta)."""
+        t = self._dev(theta, torch.float64, (self.B,))
+        check(self._lib.cn_set_theta(self._h, _ptr(t)))
+        self.sync()
+
+    def get_theta(self):
+        t = self._new((self.B,), torch.float64)
+        check(self._lib.cn_get_theta(self._h, _ptr(t)))
+        return t
 
     def drop_robot_sim(self):
         check(self._lib.cn_drop_robot_sim(self._h))

@@ -41,6 +41,8 @@ typedef enum cn_status {
 enum { CN_NOTHING = 0, CN_DANGER = 1, CN_REACH_GOAL = 2, CN_COLLISION = 3, CN_TIMEOUT = 4 };
 /* robot_policy */
 enum { CN_ROBOT_EXTERNAL = 0, CN_ROBOT_ORCA = 1 };
+/* robot_kinematics */
+enum { CN_HOLONOMIC = 0, CN_UNICYCLE = 1 };
 /* scenario_rule (crowd_sim.py:84-153) */
 enum { CN_CIRCLE_CROSSING = 0, CN_SQUARE_CROSSING = 1 };
 
@@ -72,6 +74,9 @@ typedef struct cn_config {
     double robot_v_pref;
     int32_t randomize_attributes; /* agent.py:39-45 */
     int32_t device;               /* HIP device ordinal */
+    int32_t robot_kinematics;     /* CN_HOLONOMIC: actions are ActionXY(vx, vy); CN_UNICYCLE: ActionRot(v, r)
+                                     (agent.py:115-135; CN_ROBOT_EXTERNAL only - the ORCA policy is holonomic) */
+    int32_t reserved;
 } cn_config;
 
 typedef struct cn_engine cn_engine;
@@ -94,6 +99,9 @@ int cn_sync(cn_engine* e);
  * replaces Agent.set / get_full_state (agent.py:47-108). */
 int cn_set_state(cn_engine* e, const double* state8, const double* global_time);
 int cn_get_state(cn_engine* e, double* state8, double* global_time);
+/* robot heading theta, double [B] (FullState.theta; reset sets pi/2, crowd_sim.py:274; only a unicycle robot changes it) */
+int cn_set_theta(cn_engine* e, const double* theta);
+int cn_get_theta(cn_engine* e, double* theta);
 /* forget the robot ORCA policy's captured radii (a new policy object; orca.py:95-104) */
 int cn_drop_robot_sim(cn_engine* e);
 
@@ -108,7 +116,8 @@ int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t*
 int cn_orca(cn_engine* e, float* out_vel);
 
 /* replaces CrowdSim.step(action, update) / onestep_lookahead (crowd_sim.py:314-420).
- *   action      double [B][2] (ActionXY), NULL iff robot_policy == CN_ROBOT_ORCA
+ *   action      double [B][2] (ActionXY vx, vy - or ActionRot v, r for a CN_UNICYCLE robot), NULL iff robot_policy ==
+ *               CN_ROBOT_ORCA
  *   reward      double [B]; done uint8 [B]; info uint8 [B] (CN_*); dmin double [B] (+inf if no human checked)
  *   action_out  double [B][2] action actually applied (optional)
  *   orca_vel    float [B][A][2] velocity chosen by every agent (optional)

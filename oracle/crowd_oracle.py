@@ -30,7 +30,7 @@ class CoConfig(C.Structure):
         ('circle_radius', C.c_double), ('square_width', C.c_double),
         ('human_radius', C.c_double), ('human_v_pref', C.c_double),
         ('robot_radius', C.c_double), ('robot_v_pref', C.c_double),
-        ('randomize_attributes', C.c_int32), ('reserved', C.c_int32),
+        ('randomize_attributes', C.c_int32), ('robot_kinematics', C.c_int32),
     ]
 
 
@@ -40,7 +40,7 @@ DEFAULTS = dict(
     robot_policy=1, robot_safety_space=0.0, human_safety_space=0.0, neighbor_dist=10.0,
     max_neighbors=10, scenario_rule=0, time_horizon=5.0, time_horizon_obst=5.0, circle_radius=4.0,
     square_width=10.0, human_radius=0.3, human_v_pref=1.0, robot_radius=0.3, robot_v_pref=1.0,
-    randomize_attributes=0, reserved=0)
+    randomize_attributes=0, robot_kinematics=0)
 
 
 def build(quiet=True):
@@ -70,6 +70,8 @@ def lib():
         L.co_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 9
         L.co_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 9
         L.co_drop_sims.argtypes = [C.c_void_p]
+        L.co_set_theta.argtypes = [C.c_void_p, C.c_void_p]
+        L.co_get_theta.argtypes = [C.c_void_p, C.c_void_p]
         L.co_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.co_orca.argtypes = [C.c_void_p, C.c_void_p]
         L.co_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
@@ -124,6 +126,15 @@ class CrowdOracle(object):
         gt = np.empty(self.B, dtype=np.float64)
         lib().co_get_state(self._h, *[_p(c) for c in cols], _p(gt))
         return np.stack(cols, axis=2), gt
+
+    def set_theta(self, theta):
+        t = np.ascontiguousarray(theta, dtype=np.float64).reshape(self.B)
+        lib().co_set_theta(self._h, _p(t))
+
+    def get_theta(self):
+        t = np.empty(self.B, dtype=np.float64)
+        lib().co_get_theta(self._h, _p(t))
+        return t
 
     def drop_sims(self):
         lib().co_drop_sims(self._h)

@@ -25,22 +25,25 @@ def snapshot(env):
     return np.array([[a.px, a.py, a.vx, a.vy, a.gx, a.gy, a.radius, a.v_pref] for a in [env.robot] + env.humans])
 
 
-def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl'):
+def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl', kinematics='holonomic'):
     rh.activate()
     torch.manual_seed(0)
     pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
-                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false'})
+                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false',
+                                            ('action_space', 'kinematics'): kinematics})
     env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
     policy.set_device(torch.device('cpu'))
     policy.set_phase('test')
     policy.set_env(env)
     model = policy.get_model()
-    rec = dict(states=[], gtime=[], values=[], best=[], action=[], rewards=[], inputs=[], net_out=[], next_obs=[])
+    rec = dict(states=[], gtime=[], values=[], best=[], action=[], rewards=[], inputs=[], net_out=[], next_obs=[],
+               theta=[], step_reward=[], step_done=[], step_info=[], next_states=[], next_theta=[])
+    info_code = {'Nothing': 0, 'Danger': 1, 'ReachGoal': 2, 'Collision': 3, 'Timeout': 4}
     for case in cases:
         ob = env.reset('test', case)
         done, t = False, 0
         while not done and t < max_steps:
-            state8, gt = snapshot(env), env.global_time
+            state8, gt, th = snapshot(env), env.global_time, float(robot.theta)
             action = robot.act(ob)  # MultiHumanRL.predict: fills policy.action_values
             if policy.reach_destination(robot.policy.last_state) if False else False:
                 pass
@@ -70,15 +73,21 @@ def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl')
             rec['gtime'].append(gt)
             rec['values'].append(values)
             rec['best'].append(chosen[0] if len(values) else -1)
-            rec['action'].append([action.vx, action.vy])
+            rec['action'].append(list(action))  # (vx, vy) or (v, r)
+            rec['theta'].append(th)
             rec['rewards'].append(rewards)
             rec['inputs'].append(np.array(inputs, dtype=np.float32))
             rec['net_out'].append(np.array(outs, dtype=np.float32))
             rec['next_obs'].append(nobs)
-            ob, _, done, _ = env.step(action)
+            ob, sr, done, sinfo = env.step(action)
+            rec['step_reward'].append(float(sr))
+            rec['step_done'].append(bool(done))
+            rec['step_info'].append(info_code[type(sinfo).__name__])
+            rec['next_states'].append(snapshot(env))
+            rec['next_theta'].append(float(robot.theta))
             t += 1
     out = {k: np.array(v) for k, v in rec.items()}
-    out['action_space'] = np.array([[a.vx, a.vy] for a in policy.action_space], dtype=np.float64)
+    out['action_space'] = np.array([list(a) for a in policy.action_space], dtype=np.float64)
     for k, v in model.state_dict().items():
         out['param_' + k] = v.numpy()
     out['with_om'] = np.array(int(with_om))
@@ -94,3 +103,4 @@ if __name__ == '__main__':
     generate('sarl_om.npz', with_om=True, robot_visible=True, cases=[3, 4, 5], max_steps=8)
     generate('cadrl_plain.npz', with_om=False, robot_visible=True, cases=[6, 7], max_steps=8, policy_name='cadrl')
     generate('lstm_rl_om.npz', with_om=True, robot_visible=True, cases=[8, 9], max_steps=8, policy_name='lstm_rl')
+    generate('sarl_unicycle.npz', with_om=False, robot_visible=True, cases=[10, 11, 12], max_steps=10, kinematics='unicycle')

@@ -37,10 +37,11 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_layouts_match_header(built):
-    # cn_config: 2 i32, 6 f64, 2 i32, 3 f64, 2 i32, 8 f64, 2 i32 -> 24 x 8 bytes, no padding surprises
-    assert C.sizeof(built.CnConfig) == 8 + 48 + 8 + 24 + 8 + 64 + 8
+    # cn_config: 2 i32, 6 f64, 2 i32, 3 f64, 2 i32, 8 f64, 4 i32 -> 25 x 8 bytes, no padding surprises
+    assert C.sizeof(built.CnConfig) == 8 + 48 + 8 + 24 + 8 + 64 + 16
     assert built.CnConfig.time_step.offset == 8 and built.CnConfig.neighbor_dist.offset == 80
-    assert built.CnConfig.device.offset == C.sizeof(built.CnConfig) - 4
+    assert built.CnConfig.device.offset == C.sizeof(built.CnConfig) - 12
+    assert built.CnConfig.robot_kinematics.offset == C.sizeof(built.CnConfig) - 8
     assert C.sizeof(built.CnRolloutIo) == 8 + 8 + 8 + 8 + 8 + 13 * 8
     assert C.sizeof(built.CnSarlConfig) == 16 + 16 + 4 + 8 + 8 + 12 + 16 + 4 + 4  # 88: ints, 2 doubles, dims, pad
 
@@ -93,3 +94,12 @@ def test_create_rejects_bad_configs_before_touching_the_device(built):
     assert lib.cn_create(None, None) == built.CN_ERR_INVALID
     assert lib.cn_destroy(None) == built.CN_OK  # destroying NULL is a no-op
     assert lib.cn_sync(None) == built.CN_ERR_INVALID and 'NULL' in lib.cn_last_error().decode()
+
+
+def test_unicycle_needs_external_robot_policy(built):
+    lib = built.load()
+    from crowdnav_amd.engine import default_config
+    cfg = built.CnConfig(**default_config(robot_kinematics=built.UNICYCLE, robot_policy=built.ROBOT_ORCA))
+    h = C.c_void_p()
+    assert lib.cn_create(C.byref(cfg), C.byref(h)) == built.CN_ERR_INVALID
+    assert 'holonomic' in lib.cn_last_error().decode()

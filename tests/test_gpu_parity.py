@@ -424,3 +424,38 @@ def test_randomised_configurations_vs_oracle(amd, oracle_mod, seed):
             assert np.array_equal(_np(got[k]), want[k]), (k, cfg)
     s, g = (_np(x) for x in eng.get_state())
     assert np.array_equal(s, o.get_state()[0]) and np.array_equal(g, o.get_state()[1])
+
+
+def test_unicycle_robot_vs_reference_and_oracle(amd, oracle_mod):
+    """ActionRot kinematics through cn_step (crowd_sim.py:339-341, agent.py:115-135): transitions of the unmodified
+    reference driven by a unicycle SARL policy; device cos/sin vs numpy's: 1e-12, done/info exact; then 30 free-running
+    steps against the oracle with random (v, r) actions."""
+    g = load_golden('sarl_unicycle.npz')
+    n = len(g['states'])
+    cfg = dict(num_humans=5, robot_visible=1, robot_kinematics=amd.UNICYCLE)
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_EXTERNAL, **cfg)
+    eng.set_state(g['states'], g['gtime'])
+    eng.set_theta(g['theta'])
+    out = {k: _np(v) for k, v in eng.step(g['action'], update=True, want_obs=False).items() if v is not None}
+    assert np.array_equal(out['done'], g['step_done']) and np.array_equal(out['info'], g['step_info'])
+    assert np.abs(out['reward'] - g['step_reward']).max() <= 1e-12
+    assert np.array_equal(out['action'], g['action'])  # reported as given: (v, r)
+    state = _np(eng.get_state()[0])
+    assert np.abs(state - g['next_states']).max() <= 1e-12
+    assert np.array_equal(state[:, 1:], g['next_states'][:, 1:])
+    assert np.abs(_np(eng.get_theta()) - g['next_theta']).max() <= 1e-12
+
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=0, robot_visible=1, robot_kinematics=1)
+    o.set_state(g['states'], g['gtime'])
+    o.set_theta(g['theta'])
+    eng.set_state(g['states'], g['gtime'])
+    eng.set_theta(g['theta'])
+    rng = np.random.RandomState(5)
+    for _ in range(30):
+        act = np.stack([rng.uniform(0, 1, n), rng.uniform(-np.pi / 4, np.pi / 4, n)], axis=1)
+        got = eng.step(act, update=True, want_obs=False)
+        want = o.step(act, update=True)
+        assert np.array_equal(_np(got['done']), want['done']) and np.array_equal(_np(got['info']), want['info'])
+        assert np.abs(_np(got['reward']) - want['reward']).max() <= 1e-9
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+    assert np.abs(_np(eng.get_theta()) - o.get_theta()).max() <= 1e-9

@@ -101,3 +101,20 @@ def test_rollout_reproduces_500_case_anchor(oracle_mod):
     assert int(g['invisible_steps'].sum()) == 15190
     assert np.bincount(g['visible_info'], minlength=5).tolist() == [0, 0, 500, 0, 0]
     assert int(g['visible_steps'].sum()) == 20037
+
+
+def test_unicycle_robot_steps_vs_reference(oracle_mod):
+    """ActionRot kinematics (crowd_sim.py:339-341, agent.py:115-135): the oracle's unicycle robot against transitions
+    of the unmodified reference driven by a unicycle SARL policy (sarl_unicycle.npz).  numpy's cos/sin vs libm: 1e-12."""
+    g = load_golden('sarl_unicycle.npz')
+    n = len(g['states'])
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=0, robot_visible=1, robot_kinematics=1)
+    o.set_state(g['states'], g['gtime'])
+    o.set_theta(g['theta'])
+    out = o.step(g['action'], update=True)
+    assert np.array_equal(out['done'], g['step_done']) and np.array_equal(out['info'], g['step_info'])
+    assert np.abs(out['reward'] - g['step_reward']).max() <= 1e-12
+    state, _ = o.get_state()
+    assert np.abs(state - g['next_states']).max() <= 1e-12
+    assert np.abs(o.get_theta() - g['next_theta']).max() <= 1e-12
+    assert np.array_equal(state[:, 1:], g['next_states'][:, 1:])  # humans do not depend on the robot's kinematics
