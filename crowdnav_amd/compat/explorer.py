@@ -260,20 +260,24 @@ class Explorer(object):
 
     # ------------------------------------------------------------------ explorer.py:92-125
     def update_memory(self, states, actions, rewards, imitation_learning=False):
+        """(state, value) pairs of one episode into the replay memory (explorer.py:92-125).  The TD targets of the RL
+        branch need the target network's value of every next state: they are evaluated in ONE batched forward instead of
+        one per step."""
         if self.memory is None or self.gamma is None:
             raise ValueError('Memory or gamma value is not set!')
+        dt_vp = self.robot.time_step * self.robot.v_pref
+        next_values = None
+        if not imitation_learning and len(states) > 1:
+            with torch.no_grad():
+                next_values = self.target_model(torch.stack(list(states[1:]))).reshape(-1).tolist()
         for i, state in enumerate(states):
             reward = rewards[i]
             if imitation_learning:
                 state = self.target_policy.transform(state)
-                value = sum([pow(self.gamma, max(t - i, 0) * self.robot.time_step * self.robot.v_pref) * reward
-                             * (1 if t >= i else 0) for t, reward in enumerate(rewards)])
+                value = sum([pow(self.gamma, max(t - i, 0) * dt_vp) * reward * (1 if t >= i else 0)
+                             for t, reward in enumerate(rewards)])
+            elif i == len(states) - 1:
+                value = reward  # terminal state
             else:
-                if i == len(states) - 1:
-                    value = reward
-                else:
-                    next_state = states[i + 1]
-                    gamma_bar = pow(self.gamma, self.robot.time_step * self.robot.v_pref)
-                    value = reward + gamma_bar * self.target_model(next_state.unsqueeze(0)).data.item()
-            value = torch.Tensor([value]).to(self.device)
-            self.memory.push((state, value))
+                value = reward + pow(self.gamma, dt_vp) * next_values[i]
+            self.memory.push((state, torch.Tensor([value]).to(self.device)))

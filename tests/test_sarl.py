@@ -436,3 +436,29 @@ def test_gym_surface_with_unicycle_sarl_follows_reference_episode():
         assert abs(robot.px - g['next_states'][d][0, 0]) <= 1e-12 and abs(robot.vy - g['next_states'][d][0, 3]) <= 1e-12
         if done:
             break
+
+
+def test_batched_td_targets_equal_per_step_forward_cpu():
+    """Explorer.update_memory (RL branch, explorer.py:107-113): one batched target-network forward for all next states
+    gives the per-step values of the reference loop."""
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    from crowdnav_amd.compat.trainer import ReplayMemory
+    torch.manual_seed(1)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    cfg = c.default_env_config()
+    env = c.CrowdSim()
+    env.configure(cfg)
+    robot = c.Robot(cfg, 'robot')
+    robot.time_step = 0.25
+    mem = ReplayMemory(100)
+    ex = c.Explorer(env, robot, torch.device('cpu'), mem, 0.9)
+    ex.update_target_model(net)
+    states = [torch.randn(5, 13) for _ in range(9)]
+    rewards = [0.0, -0.01, 0.0, 0.0, -0.02, 0.0, 0.0, 0.0, 1.0]
+    ex.update_memory(states, [None] * 9, rewards, imitation_learning=False)
+    assert len(mem) == 9
+    gamma_bar = pow(0.9, 0.25 * robot.v_pref)
+    for i in range(9):
+        want = rewards[i] if i == 8 else rewards[i] + gamma_bar * ex.target_model(states[i + 1].unsqueeze(0)).data.item()
+        assert torch.equal(mem[i][0], states[i]) and abs(float(mem[i][1]) - want) <= 1e-6
