@@ -89,6 +89,7 @@ SYMBOLS = {
     'cn_set_gamma': (C.c_int, [_P, C.c_double]),
     'cn_rollout_begin': (C.c_int, [_P, C.POINTER(CnRolloutIo)]),
     'cn_rollout': (C.c_int, [_P, C.POINTER(CnRolloutIo), C.c_int]),
+    'cn_rollout_step': (C.c_int, [_P, C.POINTER(CnRolloutIo), _P]),
     'cn_sarl_configure': (C.c_int, [_P, C.POINTER(CnSarlConfig), _P]),
     'cn_sarl_set_weights': (C.c_int, [_P, C.POINTER(_P)]),
     'cn_sarl_select': (C.c_int, [_P, _P, _P, _P]),

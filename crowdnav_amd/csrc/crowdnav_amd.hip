@@ -59,6 +59,7 @@ struct cn_engine {
     cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
     cn_rollout_io* io_dev;   // device copy the rollout kernels read through
     bool io_valid;
+    int steps_since_fill;    // cn_rollout_step calls since the scenario ring was last topped up
     struct cn_sarl* sarl;    // SARL decision state (sarl_abi.inc), NULL until cn_sarl_configure
     double* discount;
     int discount_len;
@@ -141,6 +142,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->cfg = *c;
     e->stream = nullptr;
     e->io_valid = false;
+    e->steps_since_fill = 0;
     e->sarl = nullptr;
     cn::Params& P = e->P;
     P.B = c->num_envs;
@@ -397,9 +399,8 @@ static int upload_io(cn_engine* e, const cn_rollout_io* io) {
 }
 
 static int check_io(const cn_engine* e, const cn_rollout_io* io) {
+    (void)e;
     if (!io) return fail(CN_ERR_INVALID, "rollout io is NULL");
-    if (!e->P.robot_orca)
-        return fail(CN_ERR_UNSUPPORTED, "cn_rollout needs an on-device robot policy (robot_policy == CN_ROBOT_ORCA)");
     if (io->seed_mod == 0) return fail(CN_ERR_INVALID, "seed_mod must be >= 1");
     if (!io->ep_count || !io->cur_steps || !io->cur_return || !io->active)
         return fail(CN_ERR_INVALID, "rollout io: ep_count, cur_steps, cur_return and active are required");
@@ -432,6 +433,9 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     if ((rc = check_io(e, io))) return rc;
     if (n_steps < 0) return fail(CN_ERR_INVALID, "n_steps must be >= 0");
     if (n_steps == 0) return CN_OK;
+    if (!e->P.robot_orca)
+        return fail(CN_ERR_UNSUPPORTED, "cn_rollout needs an on-device robot policy (robot_policy == CN_ROBOT_ORCA); with "
+                                        "CN_ROBOT_EXTERNAL use cn_rollout_step(action)");
     if ((rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     // top the scenario ring up to ring_depth episodes ahead of every env, then run the fused transitions
@@ -445,7 +449,36 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     else
         hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
-    CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps);
+    CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
+    CN_HIP(hipGetLastError());
+    e->steps_since_fill = 0;
+    return CN_OK;
+}
+
+int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if ((rc = check_io(e, io))) return rc;
+    if (e->P.robot_orca) return fail(CN_ERR_INVALID, "cn_rollout_step is for CN_ROBOT_EXTERNAL engines (use cn_rollout)");
+    if (!action) return fail(CN_ERR_INVALID, "cn_rollout_step: action is NULL");
+    if ((rc = upload_io(e, io))) return rc;
+    cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
+    // an env consumes at most one ring scenario per transition: refill every ring_depth / 2 calls
+    if (e->steps_since_fill == 0 || e->steps_since_fill >= e->P.ring_depth / 2) {
+        const int fill_lanes = e->P.B * e->P.ring_depth;
+        const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
+        if (e->gen_wave)
+            hipLaunchKernelGGL(cn::ring_fill_wave_kernel, dim3(fill_lanes), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+        else if (e->mt_in_lds)
+            hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
+                               e->S, R);
+        else
+            hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+        std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
+        e->steps_since_fill = 0;
+    }
+    ++e->steps_since_fill;
+    CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, 1, action);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }

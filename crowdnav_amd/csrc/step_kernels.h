@@ -688,16 +688,18 @@ __device__ __forceinline__ int finish_episode(const RolloutView R, int env, int 
 // Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs
 // take their next scenario from the ring.
 template <int MAXL>
-__global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps) {
+__global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps,
+                                                            const double* ext_action) {
     const Smem s = carve(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);
     float robot_max_speed = 0.0f;
-    load_robot_view(P, S, s, L, r, robot_max_speed);
+    if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
     build_pairs(P, s);
 
     const bool robot = L.valid && L.a == 0;
+    double theta = robot ? S.theta[L.env] : 0.0;  // heading of a unicycle robot (external actions only)
     double gtime = 0.0, cur_return = 0.0, cur_dsum = 0.0;
     int cur_steps = 0, cur_danger = 0, ep_count = 0, ring_filled = 0, state = kRetired;
     if (robot) {
@@ -719,7 +721,10 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
         s.flag[L.lane] = f;
     }
     __syncthreads();
-    if (L.valid && s.flag[L.ebase] >= 2) load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+    if (L.valid && s.flag[L.ebase] >= 2) {
+        load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+        theta = 1.5707963267948966;
+    }
     unsigned int transitions = 0;
     for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
     __syncthreads();
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
 
         StepResult res;
         double nvx, nvy;
-        step_core<MAXL>(P, s, Ls, r, gtime, robot_max_speed, nullptr, 1, res, nvx, nvy);
+        step_core<MAXL>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta);
 
         if (robot && state == kRunning) {
             int next_flag = 1;
@@ -751,7 +756,10 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
             s.flag[L.lane] = next_flag;
         }
         __syncthreads();
-        if (L.valid && s.flag[L.ebase] >= 2) load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+        if (L.valid && s.flag[L.ebase] >= 2) {
+            load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+            theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
+        }
     }
 
     if (L.valid) {
@@ -763,7 +771,8 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
     if (robot) {
         const cn_rollout_io io = *R.io;
         S.gtime[L.env] = gtime;
-        S.rsim_valid[L.env] = 1;
+        S.theta[L.env] = theta;
+        if (P.robot_orca) S.rsim_valid[L.env] = 1;
         io.active[L.env] = (uint8_t)state;
         io.ep_count[L.env] = ep_count;
         io.cur_steps[L.env] = cur_steps;

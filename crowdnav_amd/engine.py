@@ -180,6 +180,17 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_rollout(self._h, C.byref(self._rollout[0]), int(n_steps)))
         return self._rollout[1]
 
+    def rollout_step(self, action):
+        """One bookkept transition of every running env with caller-supplied actions ([B, 2] float64 device tensor):
+        the external-policy counterpart of rollout() (robot_policy == ROBOT_EXTERNAL)."""
+        if self._rollout is None:
+            raise RuntimeError('call rollout_begin() first')
+        a = self._dev(action, torch.float64, (self.B, 2))
+        check(self._lib.cn_rollout_step(self._h, C.byref(self._rollout[0]), _ptr(a)))
+        if not (torch.is_tensor(action) and a.data_ptr() == action.data_ptr()):
+            self.sync()
+        return self._rollout[1]
+
     def mt_random(self, seed, n):
         out = self._new((n,), torch.float64)
         check(self._lib.cn_mt_random(self._h, int(seed), int(n), _ptr(out)))

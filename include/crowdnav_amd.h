@@ -217,6 +217,12 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action);
  *   4 X f32 in MLP tile order (see sarl_kernels.h) */
 int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes);
 
+/* The same episode loop for a robot whose policy lives OUTSIDE the engine (robot_policy == CN_ROBOT_EXTERNAL, e.g. the
+ * SARL decision of cn_sarl_select): ONE transition of every running env with action double [B][2], plus all of
+ * cn_rollout's bookkeeping and seeded auto-reset from the scenario ring — `action = robot.act(ob); env.step(action)`
+ * of explorer.py:41-48 without leaving the device. */
+int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action);
+
 /* numpy legacy RNG probe (np.random.seed(seed); n × np.random.random()): out double [n].  For tests. */
 int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out);
 

@@ -459,3 +459,39 @@ def test_unicycle_robot_vs_reference_and_oracle(amd, oracle_mod):
         assert np.abs(_np(got['reward']) - want['reward']).max() <= 1e-9
     assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
     assert np.abs(_np(eng.get_theta()) - o.get_theta()).max() <= 1e-9
+
+
+def test_rollout_step_with_external_actions_vs_oracle(amd, oracle_mod):
+    """cn_rollout_step: the bookkept transition for a robot policy outside the engine.  Random actions, 70 steps,
+    auto-reset from the scenario ring (refilled every ring_depth / 2 calls), vs the oracle stepped and reset by hand."""
+    n, cfg = 40, dict(num_humans=5, robot_visible=1)
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_EXTERNAL, **cfg)
+    bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, record_capacity=8)
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=0, **cfg)
+    o.reset(1000 + np.arange(n))
+    ep = np.zeros(n, np.int64)
+    steps = np.zeros(n, np.int64)
+    rec_steps, rec_outcome = [[] for _ in range(n)], [[] for _ in range(n)]
+    rng = np.random.RandomState(11)
+    import torch
+    for _ in range(70):
+        act = rng.uniform(-0.8, 0.8, size=(n, 2))
+        eng.rollout_step(torch.from_numpy(act))
+        out = o.step(act, update=True)
+        steps += 1
+        done = out['done'] != 0
+        for b in np.nonzero(done)[0]:
+            rec_steps[b].append(int(steps[b]))
+            rec_outcome[b].append(int(out['info'][b]))
+        ep += done
+        steps[done] = 0
+        if done.any():
+            o.reset(1000 + (np.arange(n) + ep * n) % 500, mask=done.astype(np.uint8))
+    eng.sync()
+    assert int(_np(bufs['transitions'])[0]) == n * 70
+    assert np.array_equal(_np(bufs['ep_count']), ep) and np.array_equal(_np(bufs['cur_steps']), steps)
+    got_steps, got_out = _np(bufs['ep_steps']), _np(bufs['ep_outcome'])
+    for b in range(n):
+        k = min(len(rec_steps[b]), 8)
+        assert got_steps[b, :k].tolist() == rec_steps[b][:k] and got_out[b, :k].tolist() == rec_outcome[b][:k]
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
