@@ -134,6 +134,7 @@ def main():
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--humans', type=int, default=5)
     ap.add_argument('--chunk', type=int, default=1000, help='steps fused into one kernel launch')
+    ap.add_argument('--circle-radius', type=float, default=4.0, help='scenario circle radius (reference default 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
                     help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
@@ -160,7 +161,7 @@ def main():
     if args.workload != 'orca':
         return bench_sarl(args, world, rank, local_rank)
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
-                                       robot_visible=1, device=local_rank)
+                                       robot_visible=1, device=local_rank, circle_radius=args.circle_radius)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
     bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, episode_limit=-1, record_capacity=4,
                              env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1])

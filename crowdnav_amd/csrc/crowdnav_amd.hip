@@ -152,7 +152,11 @@ int cn_create(const cn_config* c, cn_engine** out) {
     // Defaults from the MI355X sweep in DESIGN.md; CROWDNAV_AMD_ENVS_PER_WAVE / CROWDNAV_AMD_WAVES_PER_BLOCK
     // override them for tuning.
     const int e_max = cn::kWave / P.A;
-    int e_want = env_int("CROWDNAV_AMD_ENVS_PER_WAVE", (P.B + 2047) / 2048);
+    // <= 5 half-planes per agent: 2048 workgroups (2 waves per SIMD) were fastest; the 10-half-plane kernels hold
+    // 187 VGPRs (2 resident waves per SIMD) and loop over many more pairs, so they get one env per wave up to
+    // 4096 workgroups (H = 20: E = 1 48 M, E = 2 31 M env-steps/s)
+    const bool small_lp = (P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5;
+    int e_want = env_int("CROWDNAV_AMD_ENVS_PER_WAVE", small_lp ? (P.B + 2047) / 2048 : (P.B + 4095) / 4096);
     P.E = e_want < 1 ? 1 : (e_want > e_max ? e_max : e_want);
     int w_want = env_int("CROWDNAV_AMD_WAVES_PER_BLOCK", 1);
     const int w_useful = (P.E * P.A * P.NC + cn::kWave - 1) / cn::kWave;  // more waves than pair passes is waste
