@@ -100,6 +100,20 @@ inline int grid_envs(const cn_engine* e) { return (e->P.B + e->P.E - 1) / e->P.E
             hipLaunchKernelGGL(cn::kernel<10>, dim3(grid), dim3((e)->P.threads), (e)->smem, (e)->stream, __VA_ARGS__); \
     } while (0)
 
+// ... and for the robot kinematics (the unicycle code only exists in the <.., true> instantiations)
+#define CN_LAUNCH_MAXL_UNI(e, kernel, grid, ...)                                                                        \
+    do {                                                                                                                \
+        const dim3 g__(grid), b__((e)->P.threads);                                                                      \
+        if ((e)->maxl == 5 && !(e)->P.robot_unicycle)                                                                   \
+            hipLaunchKernelGGL((cn::kernel<5, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                   \
+        else if ((e)->maxl == 5)                                                                                        \
+            hipLaunchKernelGGL((cn::kernel<5, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                    \
+        else if (!(e)->P.robot_unicycle)                                                                                \
+            hipLaunchKernelGGL((cn::kernel<10, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((cn::kernel<10, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                   \
+    } while (0)
+
 int env_int(const char* name, int fallback) {
     const char* v = std::getenv(name);
     return (v && *v) ? std::atoi(v) : fallback;
@@ -370,7 +384,7 @@ int cn_step(cn_engine* e, const double* action, int update, double* reward, uint
     if (!e->P.robot_orca && !action)
         return fail(CN_ERR_INVALID, "cn_step: action is required when robot_policy == CN_ROBOT_EXTERNAL");
     cn::StepIo io{action, reward, done, info, dmin, action_out, orca_vel, obs, update ? 1 : 0};
-    CN_LAUNCH_MAXL(e, step_kernel, grid_envs(e), e->P, e->S, io);
+    CN_LAUNCH_MAXL_UNI(e, step_kernel, grid_envs(e), e->P, e->S, io);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -453,7 +467,7 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     else
         hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
-    CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
+    CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
     CN_HIP(hipGetLastError());
     e->steps_since_fill = 0;
     return CN_OK;
@@ -482,7 +496,7 @@ int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action)
         e->steps_since_fill = 0;
     }
     ++e->steps_since_fill;
-    CN_LAUNCH_MAXL(e, rollout_kernel, grid_envs(e), e->P, e->S, R, 1, action);
+    CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, 1, action);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
