@@ -49,8 +49,13 @@ class Explorer(object):
         no_wrap = (self.env.case_counter[phase] >= 0 and self.env.case_counter[phase] + k <= self.env.case_size[phase])
         batched_il = (is_device_orca(self.robot.policy) and update_memory and imitation_learning and no_wrap
                       and hasattr(self.env, 'engine_config') and isinstance(self.target_policy, SARL))
+        batched_rl = (type(self.robot.policy) is SARL and phase == 'train' and update_memory
+                      and not imitation_learning and no_wrap and hasattr(self.env, 'engine_config')
+                      and getattr(self.robot.policy, 'env', None) is self.env)
         if batched_il:
             stats = self._run_batched_imitation(k, phase)
+        elif batched_rl:
+            stats = self._run_batched_rl(k, phase)
         elif batched:
             stats = self._run_batched(k, phase)
         else:
@@ -222,10 +227,9 @@ class Explorer(object):
                 maps = [occupancy_maps([ObservableState(*row) for row in js[:, 9:14].double().tolist()], policy.cell_num,
                                        policy.cell_size, policy.om_channel_size) for js in joint]
                 x = torch.cat([x, torch.stack(maps)], dim=2)
-            x = x.to(self.device)
-            for j in range(n):
-                self.memory.push((x[j], torch.Tensor([values[j]]).to(self.device)))
+            self._push_all(x, torch.Tensor(values))
 
+        self.last_batch = dict(outcome=outcome, steps=length, env_steps=int(sum(length)))
         times = [length[e] * dt for e in range(k)]
         success_times = [times[e] for e in range(k) if outcome[e] == _lib.REACH_GOAL]
         collision_times = [times[e] for e in range(k) if outcome[e] == _lib.COLLISION]
@@ -233,6 +237,138 @@ class Explorer(object):
         collision_cases = [e for e in range(k) if outcome[e] == _lib.COLLISION]
         timeout_cases = [e for e in range(k) if outcome[e] == _lib.TIMEOUT]
         returns = [sum([pow(self.gamma, t * dt * vp) * r for t, r in enumerate(rw)]) for rw in rewards_all]
+        return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, danger_n,
+                danger_sum / danger_n if danger_n else 0, returns)
+
+    def _scenario_of(self, phase):
+        env = self.env
+        multi = getattr(self.robot.policy, 'multiagent_training', None)
+        if phase == 'test':
+            human_num, rule = env.human_num, env.test_sim
+        else:  # crowd_sim.py:266-267, 277-279
+            human_num, rule = (env.human_num if multi else 1), ('circle_crossing' if not multi else env.train_val_sim)
+        offset = {'train': env.case_capacity['val'] + env.case_capacity['test'], 'val': 0,
+                  'test': env.case_capacity['val']}[phase]
+        return human_num, rule, offset
+
+    def _rl_engine(self, B, human_num, rule):
+        """The batched engine of the RL sampling phase, kept between calls (train.py calls run_k_episodes once per
+        training episode: 10 000 times in the shipped schedule)."""
+        policy = self.robot.policy
+        cfg = self.env.engine_config(B, human_num, rule, _lib.ROBOT_EXTERNAL)
+        key = (tuple(sorted(cfg.items())), id(policy), policy.action_table().tobytes())
+        cached = getattr(self, '_rl_engine_cache', None)
+        if cached is None or cached[0] != key:
+            eng = BatchedCrowdSim(**cfg)
+            eng.sarl_configure(**policy.engine_kwargs())
+            self._rl_engine_cache = cached = (key, eng)
+        return cached[1]
+
+    def _push_all(self, states, values):
+        """(state, value) pairs into the replay memory in the given order (explorer.py:125)."""
+        if hasattr(self.memory, 'push_batch'):
+            self.memory.push_batch(states, values)
+        else:
+            states, values = states.to(self.device), values.to(self.device)
+            for j in range(states.shape[0]):
+                self.memory.push((states[j], values[j].reshape(1)))
+
+    def _run_batched_rl(self, k, phase):
+        """RL-phase sampling (train.py:147-157: run_k_episodes(sample_episodes, 'train', update_memory=True)) with the
+        epsilon-greedy value-network robot, k episodes in lock step on the device.  Per batched step:
+        cn_sarl_select (greedy action of every env) -> cn_sarl_explore (the epsilon branch of
+        multi_human_rl.py:28-31 on each env's own numpy stream, continued after its scenario draws) ->
+        cn_sarl_transform (policy.last_state, written straight into the trajectory tensor) -> cn_step.  Then
+        update_memory (explorer.py:92-125) for all ReachGoal / Collision episodes at once: the TD targets
+        r + gamma^(dt v_pref) * target_model(next state) come from ONE batched forward of the target network, and the
+        (state, value) pairs enter the memory in the reference's order (episode by episode, step by step)."""
+        import numpy as np
+        env, policy = self.env, self.robot.policy
+        if self.memory is None or self.gamma is None:
+            raise ValueError('Memory or gamma value is not set!')
+        if policy.epsilon is None:
+            raise AttributeError('Epsilon attribute has to be set in training phase')
+        self.robot.time_step = env.time_step  # CrowdSim.reset does this (crowd_sim.py:296-298)
+        policy.time_step = env.time_step
+        if policy.action_space is None:
+            policy.build_action_space(self.robot.v_pref)
+        human_num, rule, offset = self._scenario_of(phase)
+        start, dt, vp = env.case_counter[phase], env.time_step, self.robot.v_pref
+        max_steps = int(round(env.time_limit / dt)) + 2
+        gamma_bar = pow(self.gamma, dt * vp)
+        D = policy.input_dim()
+        outcome, length, returns, danger_n, danger_sum = [], [], [], 0, 0.0
+        n_steps, actions_taken = 0, []
+        for c0 in range(0, k, self.max_envs):
+            B = min(self.max_envs, k - c0)
+            eng = self._rl_engine(B, human_num, rule)
+            eng.sarl_set_weights(policy.model.state_dict())
+            eng.reset(offset + start + c0 + np.arange(B))
+            traj = torch.zeros(B, max_steps, human_num, D, dtype=torch.float32, device=eng.device)
+            rew = torch.zeros(max_steps, B, dtype=torch.float64, device=eng.device)
+            inf = torch.zeros(max_steps, B, dtype=torch.uint8, device=eng.device)
+            dmn = torch.zeros(max_steps, B, dtype=torch.float64, device=eng.device)
+            act = torch.zeros(max_steps, B, dtype=torch.int32, device=eng.device)
+            alive = torch.ones(B, dtype=torch.uint8, device=eng.device)
+            bad = torch.zeros(B, dtype=torch.bool, device=eng.device)
+            T = 0
+            for t in range(max_steps):
+                sel = eng.sarl_select(want_values=False)
+                bad |= (sel['best'] == -2) & (alive != 0)
+                eng.sarl_explore(sel, policy.epsilon, mask=alive, want_explored=False)
+                eng.sarl_transform(out=traj[:, t], env_stride=max_steps * human_num * D)
+                out = eng.step(sel['action'], update=True, want_obs=False)
+                rew[t], inf[t], dmn[t], act[t] = out['reward'], out['info'], out['dmin'], sel['best']
+                alive = alive & (out['done'] == 0).to(torch.uint8)
+                T = t + 1
+                if t % 8 == 7 and not bool(alive.any().item()):
+                    break
+            eng.sync()
+            if bool(bad.any().item()):
+                raise ValueError('Value network is not well trained. ')  # multi_human_rl.py:57-58
+            R, I, Dm = rew[:T].cpu().numpy(), inf[:T].cpu().numpy(), dmn[:T].cpu().numpy()
+            Ac = act[:T].cpu().numpy()
+            terminal = I >= _lib.REACH_GOAL
+            if not terminal.any(axis=0).all():
+                raise ValueError('Invalid end signal from environment')
+            Tb = terminal.argmax(axis=0) + 1                                   # steps of every episode
+            n_steps += int(Tb.sum())
+            last = I[Tb - 1, np.arange(B)]
+            keep = np.flatnonzero((last == _lib.REACH_GOAL) | (last == _lib.COLLISION))
+            if len(keep):
+                # rows in push order: episode by episode, step by step
+                b_idx = np.repeat(keep, Tb[keep])
+                i_idx = np.concatenate([np.arange(Tb[b]) for b in keep])
+                bt = torch.as_tensor(b_idx, device=eng.device)
+                it = torch.as_tensor(i_idx, device=eng.device)
+                states = traj[bt, it]                                         # [N, H, D]
+                is_last = torch.as_tensor(i_idx == Tb[b_idx] - 1, device=eng.device)
+                nxt = traj[bt, torch.clamp(it + 1, max=max_steps - 1)]
+                with torch.no_grad():
+                    tm_device = next(self.target_model.parameters()).device
+                    v_next = self.target_model(nxt.to(tm_device)).reshape(-1).to(eng.device).double()
+                r = rew[it, bt]
+                values = torch.where(is_last, r, r + gamma_bar * v_next).float()
+                self._push_all(states, values)
+            for b in range(B):
+                n = int(Tb[b])
+                outcome.append(int(last[b]))
+                length.append(n)
+                rw = R[:n, b].tolist()
+                actions_taken.append(Ac[:n, b].tolist())
+                returns.append(sum([pow(self.gamma, t * dt * vp) * r_ for t, r_ in enumerate(rw)]))
+                dang = I[:n, b] == _lib.DANGER
+                danger_n += int(dang.sum())
+                danger_sum += float(Dm[:n, b][dang].sum())
+        env.case_counter[phase] = (start + k) % env.case_size[phase]
+        self.last_batch = dict(outcome=outcome, steps=length, discounted_return=returns,
+                               nav_time=[n * dt for n in length], env_steps=n_steps, actions=actions_taken)
+        times = [n * dt for n in length]
+        success_times = [times[e] for e in range(k) if outcome[e] == _lib.REACH_GOAL]
+        collision_times = [times[e] for e in range(k) if outcome[e] == _lib.COLLISION]
+        timeout_times = [env.time_limit for e in range(k) if outcome[e] == _lib.TIMEOUT]
+        collision_cases = [e for e in range(k) if outcome[e] == _lib.COLLISION]
+        timeout_cases = [e for e in range(k) if outcome[e] == _lib.TIMEOUT]
         return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, danger_n,
                 danger_sum / danger_n if danger_n else 0, returns)
 

@@ -40,7 +40,13 @@ class ValueNetwork(nn.Module):
         self.cell_size = cell_size
         self.cell_num = cell_num
         self.mlp3 = mlp(mlp2_dims[-1] + self_state_dim, mlp3_dims)
-        self.attention_weights = None
+        self._attention_row = None
+
+    @property
+    def attention_weights(self):
+        """Attention weights of batch element 0 of the last forward (sarl.py:54), fetched from the device on demand —
+        a host copy inside forward() would cost one device sync per SGD step and forbid graph capture."""
+        return None if self._attention_row is None else self._attention_row.cpu().numpy()
 
     def forward(self, state):
         n, h, d = state.shape
@@ -55,7 +61,7 @@ class ValueNetwork(nn.Module):
         scores = self.attention(att_in).view(n, h)
         scores_exp = torch.exp(scores) * (scores != 0).float()  # masked, no max-subtraction (sarl.py:52-53)
         weights = (scores_exp / scores_exp.sum(dim=1, keepdim=True)).unsqueeze(2)
-        self.attention_weights = weights[0, :, 0].data.cpu().numpy()
+        self._attention_row = weights[0, :, 0].detach()
         weighted = (weights * feats.view(n, h, -1)).sum(dim=1)
         return self.mlp3(torch.cat([self_state, weighted], dim=1))
 

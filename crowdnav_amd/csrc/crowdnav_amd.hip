@@ -272,6 +272,10 @@ int cn_sync(cn_engine* e) {
     CN_HIP(hipMemcpy(&gen_error, e->C.error, sizeof(int), hipMemcpyDeviceToHost));
     if (gen_error) {
         CN_HIP(hipMemset(e->C.error, 0, sizeof(int)));
+        if (gen_error & 2)
+            return fail(CN_ERR_INVALID,
+                        "cn_sarl_explore needs each env's numpy stream: (re)start the episodes with cn_reset (the scenario "
+                        "ring of cn_rollout_* and the wave generator used for more than 8 humans do not keep it)");
         return fail(CN_ERR_INVALID,
                     "scenario generation gave up on a human after %llu rejected placements (the reference's rejection "
                     "sampling would not have terminated either: too many humans for this circle/square); the affected "

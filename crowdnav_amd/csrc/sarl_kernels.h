@@ -92,8 +92,63 @@ __global__ void sarl_pack_kernel(const float* W, const float* bias, int N, int K
 }
 
 // ------------------------------------------------------------------------------------ lookahead / reward
+// Occupancy map human i sees among the H humans of one env (multi_human_rl.py:109-163; the robot is not in it).
+// state_of(j, px, py, vx, vy) yields human j's state; m receives cells * channels float32 values.
+template <class StateOf>
+__device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf state_of, float* m) {
+    const int cells = C.cell_num * C.cell_num;
+    const int ch = C.om_channels;
+    double px, py, vx, vy;
+    state_of(i, px, py, vx, vy);
+    const double my_angle = atan2(vy, vx);
+    // every other human's cell and rotated velocity once (kSarlMaxHumans slots in registers) ...
+    int cell_of[kSarlMaxHumans];
+    double rvx[kSarlMaxHumans], rvy[kSarlMaxHumans];
+#pragma unroll
+    for (int j = 0; j < kSarlMaxHumans; ++j) {
+        cell_of[j] = -1;
+        rvx[j] = rvy[j] = 0.0;
+        if (j >= C.H || j == i) continue;
+        double qx, qy, wx, wy;
+        state_of(j, qx, qy, wx, wy);
+        const double ox = qx - px, oy = qy - py;
+        const double rotation = atan2(oy, ox) - my_angle;
+        const double dist = sqrt(ox * ox + oy * oy);
+        const double rx = cos(rotation) * dist, ry = sin(rotation) * dist;
+        const double xi = floor(rx / C.cell_size + C.cell_num / 2.0);
+        const double yi = floor(ry / C.cell_size + C.cell_num / 2.0);
+        if (xi < 0 || xi >= C.cell_num || yi < 0 || yi >= C.cell_num) continue;
+        cell_of[j] = (int)(C.cell_num * yi + xi);
+        const double vrot = atan2(wy, wx) - my_angle;
+        const double speed = sqrt(wx * wx + wy * wy);
+        rvx[j] = cos(vrot) * speed;
+        rvy[j] = sin(vrot) * speed;
+    }
+    // ... then per cell: count, sum vx', sum vy' in visit order (python sum(): 0 + x1 + x2 ...)
+    for (int cell = 0; cell < cells; ++cell) {
+        double cnt = 0.0, svx = 0.0, svy = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSarlMaxHumans; ++j) {
+            if (cell_of[j] != cell) continue;
+            cnt += 1.0;
+            svx += rvx[j];
+            svy += rvy[j];
+        }
+        if (ch == 1) {
+            m[cell] = cnt > 0.0 ? 1.0f : 0.0f;
+        } else if (ch == 2) {
+            m[2 * cell] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
+            m[2 * cell + 1] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
+        } else {
+            m[3 * cell] = cnt > 0.0 ? (float)(cnt / cnt) : 0.0f;
+            m[3 * cell + 1] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
+            m[3 * cell + 2] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
+        }
+    }
+}
+
 // Next observable state of every human (get_next_observable_state, agent.py:63-74) from the ORCA velocities,
-// and (with_om) the occupancy map each human would see (multi_human_rl.py:109-163; robot excluded).
+// and (with_om) the occupancy map each human would see among those next states.
 __global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const double2* rv, const float* orca_vel,
                                       double* next_obs /*[B][H][5]*/, float* om /*[B][H][cells*ch]*/) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,44 +164,7 @@ __global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const doubl
     next_of(i, px, py, vx, vy);
     double* o = next_obs + (size_t)idx * 5;
     o[0] = px, o[1] = py, o[2] = vx, o[3] = vy, o[4] = rv[(size_t)b * A + 1 + i].x;
-    if (!C.with_om) return;
-
-    const int cells = C.cell_num * C.cell_num;
-    const int ch = C.om_channels;
-    float* m = om + (size_t)idx * cells * ch;
-    const double my_angle = atan2(vy, vx);
-    // per cell: count, sum vx', sum vy' in visit order (python sum(): 0 + x1 + x2 ...)
-    for (int cell = 0; cell < cells; ++cell) {
-        double cnt = 0.0, svx = 0.0, svy = 0.0;
-        for (int j = 0; j < C.H; ++j) {
-            if (j == i) continue;
-            double qx, qy, wx, wy;
-            next_of(j, qx, qy, wx, wy);
-            const double ox = qx - px, oy = qy - py;
-            const double rotation = atan2(oy, ox) - my_angle;
-            const double dist = sqrt(ox * ox + oy * oy);
-            const double rx = cos(rotation) * dist, ry = sin(rotation) * dist;
-            const double xi = floor(rx / C.cell_size + C.cell_num / 2.0);
-            const double yi = floor(ry / C.cell_size + C.cell_num / 2.0);
-            if (xi < 0 || xi >= C.cell_num || yi < 0 || yi >= C.cell_num) continue;
-            if ((int)(C.cell_num * yi + xi) != cell) continue;
-            const double vrot = atan2(wy, wx) - my_angle;
-            const double speed = sqrt(wx * wx + wy * wy);
-            cnt += 1.0;
-            svx += cos(vrot) * speed;
-            svy += sin(vrot) * speed;
-        }
-        if (ch == 1) {
-            m[cell] = cnt > 0.0 ? 1.0f : 0.0f;
-        } else if (ch == 2) {
-            m[2 * cell] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
-            m[2 * cell + 1] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
-        } else {
-            m[3 * cell] = cnt > 0.0 ? (float)(cnt / cnt) : 0.0f;
-            m[3 * cell + 1] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
-            m[3 * cell + 2] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
-        }
-    }
+    if (C.with_om) occupancy_map(C, i, next_of, om + (size_t)idx * C.cell_num * C.cell_num * C.om_channels);
 }
 
 // Reward of onestep_lookahead(action) for every (env, action) (crowd_sim.py:331-389, update = False).
@@ -214,6 +232,30 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
 }
 
 // ------------------------------------------------------------------------------------ features
+// CADRL.rotate (cadrl.py:187-222) of one float32 joint row [self (9) | human (5)]: one rounding per torch op.
+__device__ __forceinline__ void rotate_row(float px, float py, float vx, float vy, float radius, float gx, float gy,
+                                           float v_pref, float theta, int unicycle, float px1, float py1, float vx1,
+                                           float vy1, float radius1, float* f) {
+    const float dx = gx - px, dy = gy - py;
+    const float rot = atan2f(dy, dx);
+    const float dg = sqrtf(dx * dx + dy * dy);
+    const float c = cosf(rot), s = sinf(rot);
+    f[0] = dg;
+    f[1] = v_pref;
+    f[2] = unicycle ? theta - rot : 0.0f;  // cadrl.py:207-211
+    f[3] = radius;
+    f[4] = vx * c + vy * s;
+    f[5] = vy * c - vx * s;
+    f[6] = (px1 - px) * c + (py1 - py) * s;
+    f[7] = (py1 - py) * c - (px1 - px) * s;
+    f[8] = vx1 * c + vy1 * s;
+    f[9] = vy1 * c - vx1 * s;
+    f[10] = radius1;
+    const float ex = px - px1, ey = py - py1;
+    f[11] = sqrtf(ex * ex + ey * ey);
+    f[12] = radius + radius1;
+}
+
 // X row of (env b, action a, human h): CADRL.rotate of the float32 joint row
 // [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written straight in the MLP
 // kernel's LDS order: group G = b * K + a -> tile G / 16, g = G % 16, row tile = h;
@@ -251,32 +293,75 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     const float gx = (float)goal[g0].x, gy = (float)goal[g0].y;
     const double* o = next_obs + ((size_t)b * C.H + h) * 5;
     const float px1 = (float)o[0], py1 = (float)o[1], vx1 = (float)o[2], vy1 = (float)o[3], radius1 = (float)o[4];
-    // CADRL.rotate (cadrl.py:195-221), float32, one rounding per torch op
-    const float dx = gx - px, dy = gy - py;
-    const float rot = atan2f(dy, dx);
-    const float dg = sqrtf(dx * dx + dy * dy);
-    const float c = cosf(rot), s = sinf(rot);
     float f[13];
-    f[0] = dg;
-    f[1] = v_pref;
-    f[2] = C.unicycle ? theta_f - rot : 0.0f;  // cadrl.py:207-211
-    f[3] = radius;
-    f[4] = vx * c + vy * s;
-    f[5] = vy * c - vx * s;
-    f[6] = (px1 - px) * c + (py1 - py) * s;
-    f[7] = (py1 - py) * c - (px1 - px) * s;
-    f[8] = vx1 * c + vy1 * s;
-    f[9] = vy1 * c - vx1 * s;
-    f[10] = radius1;
-    const float ex = px - px1, ey = py - py1;
-    f[11] = sqrtf(ex * ex + ey * ey);
-    f[12] = radius + radius1;
+    rotate_row(px, py, vx, vy, radius, gx, gy, v_pref, theta_f, C.unicycle, px1, py1, vx1, vy1, radius1, f);
 #pragma unroll
     for (int k = 0; k < 13; ++k) x[(k >> 2) * 64 + (k & 3) * 16] = f[k];
     const int extra = in_dim - 13;
     const float* m = om + ((size_t)b * C.H + h) * (extra > 0 ? extra : 0);
     for (int k = 0; k < extra; ++k) x[((13 + k) >> 2) * 64 + ((13 + k) & 3) * 16] = m[k];
     for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------ replay-memory side
+// MultiHumanRL.transform (multi_human_rl.py:90-104; CADRL.transform cadrl.py:171-185 when H = 1) of the CURRENT joint
+// state of every env: rotate(float32 [self_state (9) | human h (5)]) (+ human h's occupancy map among the current
+// human states) -> out[b][h][0..in_dim): the state a train-phase predict() leaves in policy.last_state and
+// Explorer.update_memory pushes into the replay memory.  lane = (env, human).
+__global__ void sarl_transform_kernel(SarlCfg C, int in_dim, const double2* pos, const double2* vel,
+                                      const double2* goal, const double2* rv, const double* theta,
+                                      float* out /*[B][H][in_dim]*/, int64_t env_stride /*floats between envs*/) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C.B * C.H) return;
+    const int b = idx / C.H, h = idx - b * C.H;
+    const size_t g0 = (size_t)b * (C.H + 1), g1 = g0 + 1 + h;
+    float f[13];
+    rotate_row((float)pos[g0].x, (float)pos[g0].y, (float)vel[g0].x, (float)vel[g0].y, (float)rv[g0].x,
+               (float)goal[g0].x, (float)goal[g0].y, (float)rv[g0].y, (float)theta[b], C.unicycle, (float)pos[g1].x,
+               (float)pos[g1].y, (float)vel[g1].x, (float)vel[g1].y, (float)rv[g1].x, f);
+    float* x = out + (size_t)b * env_stride + (size_t)h * in_dim;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) x[k] = f[k];
+    if (C.with_om) {
+        auto state_of = [&](int j, double& px, double& py, double& vx, double& vy) {
+            const size_t gj = g0 + 1 + j;
+            px = pos[gj].x, py = pos[gj].y, vx = vel[gj].x, vy = vel[gj].y;
+        };
+        occupancy_map(C, h, state_of, x + 13);
+    }
+}
+
+// The epsilon-greedy branch of MultiHumanRL.predict (multi_human_rl.py:28-31), on each env's OWN numpy stream — the
+// one cn_reset seeded (np.random.seed in CrowdSim.reset, crowd_sim.py:272-276), continued after the scenario draws:
+//   probability = np.random.random();  if probability < epsilon: action_space[np.random.choice(K)]
+// np.random.choice(K) of the legacy RandomState is randint(0, K): 32-bit draws masked to the next power of two minus
+// one, rejected while > K - 1.  An env already at its goal (best == -1) returned before the draw (:22-23).
+// lane = env.  explored (optional) receives 1 where the random action replaced the greedy one.
+__global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos, const double* actions,
+                                    const uint8_t* mask, int32_t* best, double* action, uint8_t* explored,
+                                    int* error) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (explored) explored[b] = 0;
+    if (mask && !mask[b]) return;
+    if (best[b] == -1) return;
+    if (mt_pos[b] < 0) {  // the env was not (re)started by cn_reset: there is no stream to continue
+        atomicOr(error, 2);
+        return;
+    }
+    Mt19937 rng{mt_key + b, B, mt_pos[b]};
+    const double probability = rng.random();
+    if (probability < epsilon) {
+        uint32_t bits = (uint32_t)(K - 1);
+        bits |= bits >> 1, bits |= bits >> 2, bits |= bits >> 4, bits |= bits >> 8, bits |= bits >> 16;
+        uint32_t k = 0;
+        if (K > 1) do k = rng.next32() & bits; while (k > (uint32_t)(K - 1));  // randint(0, 1) draws nothing
+        best[b] = (int32_t)k;
+        action[2 * b] = actions[2 * k];
+        action[2 * b + 1] = actions[2 * k + 1];
+        if (explored) explored[b] = 1;
+    }
+    mt_pos[b] = rng.pos;
 }
 
 // ------------------------------------------------------------------------------------ value network

@@ -268,7 +268,31 @@ def _sarl_export(self, name):
     return t
 
 
+def _sarl_explore(self, sel, epsilon, mask=None, want_explored=True):
+    """Epsilon-greedy on top of a sarl_select result (in place): each env draws np.random.random() — and, below
+    epsilon, np.random.choice(K) — from the numpy stream its last reset() seeded (multi_human_rl.py:28-31)."""
+    m = None if mask is None else self._dev(mask, torch.uint8, (self.B,))
+    explored = self._new((self.B,), torch.uint8) if want_explored else None
+    check(self._lib.cn_sarl_explore(self._h, float(epsilon), _ptr(m), _ptr(sel['best']), _ptr(sel['action']),
+                                    _ptr(explored)))
+    sel['explored'] = explored
+    return sel
+
+
+def _sarl_transform(self, out=None, env_stride=0):
+    """MultiHumanRL.transform of every env's current joint state: [B, H, in_dim] float32 (replay-memory state).
+    With out (a float32 device tensor) and env_stride (floats between consecutive envs) the rows are written in place,
+    e.g. out = traj[:, t] of a [B, T, H, D] trajectory tensor with env_stride = T * H * D."""
+    if out is None:
+        out = self._new((self.B, self.H, self.sarl['in_dim']), torch.float32)
+    assert out.dtype == torch.float32 and out.device.type == self.device.type
+    check(self._lib.cn_sarl_transform(self._h, C.c_void_p(out.data_ptr()), int(env_stride)))
+    return out
+
+
 BatchedCrowdSim.sarl_configure = _sarl_configure
 BatchedCrowdSim.sarl_set_weights = _sarl_set_weights
 BatchedCrowdSim.sarl_select = _sarl_select
 BatchedCrowdSim.sarl_export = _sarl_export
+BatchedCrowdSim.sarl_explore = _sarl_explore
+BatchedCrowdSim.sarl_transform = _sarl_transform

@@ -7,16 +7,18 @@ and the SARL decision run in libcrowdnav_amd, replay memory and the SGD trainer 
 """
 import argparse
 import copy
+import json
 import logging
 import os
 import sys
+import time
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import crowdnav_amd.compat as cn  # noqa: E402
 from crowdnav_amd.compat.sarl import default_policy_config  # noqa: E402
-from crowdnav_amd.compat.trainer import ReplayMemory, Trainer  # noqa: E402
+from crowdnav_amd.compat.trainer import DeviceReplayMemory, ReplayMemory, Trainer  # noqa: E402
 
 
 def run(args):
@@ -30,10 +32,25 @@ def run(args):
     robot = cn.Robot(env_cfg, 'robot')
     env.set_robot(robot)
 
-    memory = ReplayMemory(args.capacity)
+    # --gpu: the replay ring lives on the device next to the model (one index_copy per batched rollout, one gather per
+    # SGD batch); otherwise the reference-style list memory + DataLoader
+    memory = DeviceReplayMemory(args.capacity, device) if device.type == 'cuda' else ReplayMemory(args.capacity)
     model = policy.get_model()
     trainer = Trainer(model, memory, device, args.batch_size)
     explorer = cn.Explorer(env, robot, device, memory, policy.gamma, target_policy=policy)
+
+    timing = dict(il_collect_s=0.0, il_sgd_s=0.0, rl_sample_s=0.0, rl_sgd_s=0.0, eval_s=0.0, il_env_steps=0,
+                  rl_env_steps=0, eval_episodes=0)
+
+    def timed(key, fn, *a, **kw):
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn(*a, **kw)
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
+        timing[key] += time.perf_counter() - t0
+        return out
 
     # imitation learning from ORCA demonstrations (train.py:115-132)
     trainer.set_learning_rate(args.il_learning_rate)
@@ -42,8 +59,9 @@ def run(args):
     il_policy.safety_space = 0 if robot.visible else args.safety_space
     robot.set_policy(il_policy)
     env.set_robot(robot)
-    explorer.run_k_episodes(args.il_episodes, 'train', update_memory=True, imitation_learning=True)
-    il_loss = trainer.optimize_epoch(args.il_epochs)
+    timed('il_collect_s', explorer.run_k_episodes, args.il_episodes, 'train', update_memory=True, imitation_learning=True)
+    timing['il_env_steps'] = int((explorer.last_batch or {}).get('env_steps', 0))
+    il_loss = timed('il_sgd_s', trainer.optimize_epoch, args.il_epochs)
     logging.info('Finish imitation learning. Experience set size: %d/%d', len(memory), memory.capacity)
     explorer.update_target_model(model)
 
@@ -60,16 +78,28 @@ def run(args):
             epsilon = args.epsilon_end
         robot.policy.set_epsilon(epsilon)
         if episode % args.evaluation_interval == 0:
-            explorer.run_k_episodes(env.case_size['val'], 'val', episode=episode)
-        explorer.run_k_episodes(args.sample_episodes, 'train', update_memory=True, episode=episode)
-        rl_loss = trainer.optimize_batch(args.train_batches)
+            timed('eval_s', explorer.run_k_episodes, env.case_size['val'], 'val', episode=episode)
+            timing['eval_episodes'] += env.case_size['val']
+        timed('rl_sample_s', explorer.run_k_episodes, args.sample_episodes, 'train', update_memory=True, episode=episode)
+        timing['rl_env_steps'] += int((explorer.last_batch or {}).get('env_steps', 0))
+        rl_loss = timed('rl_sgd_s', trainer.optimize_batch, args.train_batches)
         episode += 1
         if episode % args.target_update_interval == 0:
             explorer.update_target_model(model)
         if args.output_dir and episode % args.checkpoint_interval == 0:
             torch.save(model.state_dict(), os.path.join(args.output_dir, 'rl_model.pth'))
-    explorer.run_k_episodes(env.case_size['test'], 'test', episode=episode)
-    return dict(il_loss=il_loss, rl_loss=rl_loss, memory=len(memory), stats=copy.deepcopy(explorer.last_stats))
+    timed('eval_s', explorer.run_k_episodes, env.case_size['test'], 'test', episode=episode)
+    timing['eval_episodes'] += env.case_size['test']
+    if timing['rl_sample_s'] > 0:
+        timing['rl_sample_env_steps_per_s'] = timing['rl_env_steps'] / timing['rl_sample_s']
+    if timing['il_collect_s'] > 0:
+        timing['il_collect_env_steps_per_s'] = timing['il_env_steps'] / timing['il_collect_s']
+    out = dict(il_loss=il_loss, rl_loss=rl_loss, memory=len(memory), stats=copy.deepcopy(explorer.last_stats),
+               timing=timing, schedule={k: v for k, v in vars(args).items()})
+    if args.timing_json:
+        with open(args.timing_json, 'w') as f:
+            json.dump(out, f, indent=1, default=str)
+    return out
 
 
 def parser():
@@ -77,6 +107,7 @@ def parser():
     ap.add_argument('--gpu', action='store_true', help='keep the torch model / trainer on cuda:0 (rollouts always are)')
     ap.add_argument('--with-om', action='store_true')
     ap.add_argument('--output-dir', default=None)
+    ap.add_argument('--timing-json', default=None, help='write losses, final stats and per-phase wall-clock here')
     for name, default in (('il-episodes', 3000), ('il-epochs', 50), ('train-episodes', 10000), ('train-batches', 100),
                           ('sample-episodes', 1), ('target-update-interval', 50), ('evaluation-interval', 1000),
                           ('checkpoint-interval', 1000), ('capacity', 100000), ('batch-size', 100),

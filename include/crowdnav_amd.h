@@ -212,6 +212,20 @@ int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array);
  *                  -2 = no finite value (the reference raises ValueError, :57-58)
  *   action  double [B][2] the chosen ActionXY */
 int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action);
+/* replaces the epsilon-greedy branch of MultiHumanRL.predict in the train phase (multi_human_rl.py:28-31), applied to
+ * the best/action a cn_sarl_select just produced: per env (mask == NULL or mask[b] != 0, and not already at its goal)
+ *   probability = np.random.random(); if probability < epsilon: action_space[np.random.choice(n_actions)]
+ * drawn from the env's OWN numpy stream — the one cn_reset seeded (np.random.seed, crowd_sim.py:272-276) continued
+ * after the scenario draws, exactly as the sequential reference consumes it.  Needs episodes started by cn_reset
+ * (otherwise the next cn_sync fails).  explored (optional) uint8 [B]: 1 where the random action was taken. */
+int cn_sarl_explore(cn_engine* e, double epsilon, const uint8_t* mask, int32_t* best, double* action,
+                    uint8_t* explored);
+/* replaces MultiHumanRL.transform (multi_human_rl.py:90-104; CADRL.transform cadrl.py:171-185 for one human) for the
+ * CURRENT joint state of every env — the state a train-phase predict() leaves in policy.last_state and
+ * Explorer.update_memory (explorer.py:92-125) pushes into the replay memory:
+ *   out float32, env b's [H][13 (+ cell_num^2 * om_channel_size)] block at out + b * env_stride (floats;
+ *   0 = densely packed [B][H][D]; a larger stride writes step t of a [B][T][H][D] trajectory tensor in place). */
+int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride);
 /* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):
  *   0 reward f64 [B][K] · 1 V f32 [B*K] · 2 next human states f64 [B][H][5] · 3 occupancy maps f32 [B][H][cells*ch]
  *   4 X f32 in MLP tile order (see sarl_kernels.h) */

@@ -1,0 +1,271 @@
+"""RL-phase sampling of BASELINE configs[4] (train.py:147-157): epsilon-greedy device SARL episodes in lock step,
+replay states from cn_sarl_transform, batched TD targets, device replay ring — against fixtures produced by the
+UNMODIFIED reference's Explorer.run_k_episodes(k, 'train', update_memory=True) (oracle/gen_golden_rl.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+RL_FIXTURES = ['rl_sarl_plain.npz', 'rl_sarl_om.npz']
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_device_replay_memory_is_the_reference_ring_cpu():
+    """push_batch == the same pushes one by one into the reference-style list ring (memory.py:12-18)."""
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory, ReplayMemory
+    torch.manual_seed(1)
+    dev, ref = DeviceReplayMemory(10, 'cpu'), ReplayMemory(10)
+    for n in (3, 4, 5, 12, 25, 1, 7, 10):
+        st, v = torch.randn(n, 2, 3), torch.randn(n)
+        dev.push_batch(st, v)
+        for i in range(n):
+            ref.push((st[i], v[i].reshape(1)))
+        assert len(dev) == len(ref) and dev.position == ref.position and dev.is_full() == ref.is_full()
+        for i in range(len(ref)):
+            assert torch.equal(dev[i][0], ref[i][0]) and torch.equal(dev[i][1], ref[i][1])
+    dev.push((torch.ones(2, 3), torch.tensor([2.0])))
+    ref.push((torch.ones(2, 3), torch.tensor([2.0])))
+    assert all(torch.equal(dev[i][0], ref[i][0]) for i in range(10))
+    with pytest.raises(IndexError):
+        dev[10]
+    dev.clear()
+    assert len(dev) == 0
+
+
+def test_trainer_on_device_memory_cpu():
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory, Trainer
+    torch.manual_seed(0)
+    mem = DeviceReplayMemory(64, 'cpu')
+    x = torch.randn(50, 5, 13)
+    mem.push_batch(x, x[:, 0, 0] * 0.1)
+    seen = torch.cat([b[1] for b in mem.batches(16)])
+    assert seen.shape == (50, 1) and torch.equal(seen.sort(0)[0], mem.values[:50].sort(0)[0])  # one permutation
+    assert [b[0].shape[0] for b in mem.batches(16)] == [16, 16, 16, 2]
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    tr = Trainer(net, mem, torch.device('cpu'), batch_size=16)
+    with pytest.raises(ValueError):
+        tr.optimize_epoch(1)
+    tr.set_learning_rate(0.01)
+    first = tr.optimize_epoch(1)
+    later = tr.optimize_epoch(25)
+    assert later < first and np.isfinite(tr.optimize_batch(3))
+
+
+def test_rl_fixture_is_self_consistent_cpu():
+    """The reference's memory holds exactly the steps of its ReachGoal / Collision episodes; terminal targets are the
+    terminal rewards (explorer.py:111-113)."""
+    for name in RL_FIXTURES:
+        g = load_golden(name)
+        kept = [e for e in range(int(g['k'])) if g['ep_outcome'][e] in (2, 3)]
+        assert sum(int(g['ep_steps'][e]) for e in kept) == len(g['memory_values'])
+        row = 0
+        for e in kept:
+            n = int(g['ep_steps'][e])
+            assert g['memory_values'][row + n - 1] == np.float32(g['ep_rewards'][e][n - 1])
+            row += n
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _setup(g):
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config
+    with_om, visible = bool(int(g['with_om'])), bool(int(g['robot_visible']))
+    cfg = c.default_env_config({('robot', 'visible'): 'true' if visible else 'false'})
+    env = c.CrowdSim()
+    env.configure(cfg)
+    robot = c.Robot(cfg, 'robot')
+    policy = c.policy_factory['sarl']()
+    policy.configure(default_policy_config({('sarl', 'with_om'): 'true' if with_om else 'false'}))
+    policy.get_model().load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items()
+                                        if k.startswith('param_')})
+    robot.set_policy(policy)
+    env.set_robot(robot)
+    policy.set_device(torch.device('cpu'))
+    policy.set_env(env)
+    policy.set_epsilon(float(g['epsilon']))
+    return c, env, robot, policy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('randomize', [False, True])
+def test_explore_continues_each_envs_numpy_stream(randomize):
+    """cn_sarl_explore draws from the stream np.random.seed(seed) + the scenario's random() calls left behind."""
+    import crowdnav_amd
+    B, K = 48, 81
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                       robot_visible=1, randomize_attributes=int(randomize))
+    acts = np.stack([np.arange(K), -np.arange(K)], axis=1).astype(np.float64)
+    eng.sarl_configure(actions=acts)
+    seeds = 2000 + 17 * np.arange(B)
+    draws = eng.reset(seeds).cpu().numpy()
+    rngs = []
+    for b in range(B):
+        rs = np.random.RandomState(int(seeds[b]))
+        rs.random_sample(int(draws[b]))
+        rngs.append(rs)
+    for rnd, eps in enumerate((1.0, 0.4, 0.0, 0.7)):
+        mask = np.ones(B, np.uint8)
+        mask[rnd::5] = 0                                  # masked envs draw nothing
+        best = torch.full((B,), 5, dtype=torch.int32, device=eng.device)
+        best[1] = -1                                      # an env at its goal returns before the draw
+        sel = dict(best=best, action=torch.zeros(B, 2, dtype=torch.float64, device=eng.device))
+        eng.sarl_explore(sel, eps, mask=mask)
+        eng.sync()
+        got_best, got_act, got_exp = (sel[k].cpu().numpy() for k in ('best', 'action', 'explored'))
+        for b in range(B):
+            if not mask[b] or b == 1:
+                want_best, want_exp = (-1 if b == 1 else 5), 0
+            else:
+                p = rngs[b].random_sample()
+                want_exp = int(p < eps)
+                want_best = int(rngs[b].choice(K)) if want_exp else 5
+            assert got_best[b] == want_best and got_exp[b] == want_exp, (rnd, b)
+            if want_exp:
+                assert tuple(got_act[b]) == (want_best, -want_best)
+
+
+@pytest.mark.gpu
+def test_explore_without_a_kept_stream_fails_loudly():
+    import crowdnav_amd
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=4, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.sarl_configure(actions=np.zeros((81, 2)))
+    eng.rollout_begin(seed_base=1000, seed_mod=500, record_capacity=2)  # the ring path does not keep numpy streams
+    sel = dict(best=torch.zeros(4, dtype=torch.int32, device=eng.device),
+               action=torch.zeros(4, 2, dtype=torch.float64, device=eng.device))
+    eng.sarl_explore(sel, 0.5)
+    with pytest.raises(crowdnav_amd.CrowdNavAmdError):
+        eng.sync()
+    eng.sync()  # the flag is cleared once reported
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_om', [False, True])
+def test_transform_matches_host_transform(with_om):
+    """cn_sarl_transform == the policy's own transform (the vectorised mirror of MultiHumanRL.transform that is itself
+    checked against the reference) on live states, dense and strided output."""
+    import crowdnav_amd
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config, occupancy_maps, rotate
+    from crowdnav_amd.compat.types import ObservableState
+    B, H = 32, 5
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    policy = c.policy_factory['sarl']()
+    policy.configure(default_policy_config({('sarl', 'with_om'): 'true' if with_om else 'false'}))
+    policy.build_action_space(1.0)
+    eng.sarl_configure(**policy.engine_kwargs())
+    eng.reset(3000 + np.arange(B))
+    rng = np.random.RandomState(0)
+    D = policy.input_dim()
+    traj = torch.zeros(B, 3, H, D, dtype=torch.float32, device=eng.device)
+    for t in range(3):
+        eng.step(rng.uniform(-0.7, 0.7, size=(B, 2)), update=True, want_obs=False)
+        st = eng.get_state()[0].cpu().numpy()                                   # [B, A, 8] px py vx vy gx gy r vpref
+        dense = eng.sarl_transform()
+        eng.sarl_transform(out=traj[:, t], env_stride=3 * H * D)
+        eng.sync()
+        me = np.concatenate([st[:, 0, [0, 1, 2, 3, 6, 4, 5, 7]], np.full((B, 1), np.pi / 2)], axis=1)   # FullState order
+        hum = st[:, 1:][:, :, [0, 1, 2, 3, 6]]
+        joint = torch.Tensor(np.concatenate([np.repeat(me[:, None], H, axis=1), hum], axis=2))         # [B, H, 14] f32
+        want = rotate(joint.reshape(B * H, 14)).reshape(B, H, 13)
+        if with_om:
+            maps = torch.stack([occupancy_maps([ObservableState(*row) for row in hum[b].tolist()], policy.cell_num,
+                                               policy.cell_size, policy.om_channel_size) for b in range(B)])
+            want = torch.cat([want, maps], dim=2)
+        assert torch.equal(dense.cpu(), traj[:, t].cpu())
+        assert (dense.cpu() - want).abs().max().item() <= 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', RL_FIXTURES)
+@pytest.mark.parametrize('device_memory', [False, True])
+def test_batched_rl_sampling_reproduces_the_reference_memory(name, device_memory):
+    """Explorer.run_k_episodes(k, 'train', update_memory=True) with the epsilon-greedy SARL robot: same episodes
+    (action for action), same outcomes, and the same replay memory as the unmodified reference produced."""
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory, ReplayMemory
+    g = load_golden(name)
+    c, env, robot, policy = _setup(g)
+    k = int(g['k'])
+    mem = DeviceReplayMemory(100000, 'cuda:0') if device_memory else ReplayMemory(100000)
+    ex = c.Explorer(env, robot, torch.device('cpu'), mem, float(g['gamma']), target_policy=policy)
+    ex.update_target_model(policy.get_model())
+    env.case_counter['train'] = int(g['first_case'])
+    ex.run_k_episodes(k, 'train', update_memory=True, episode=0)
+    lb = ex.last_batch
+    assert env.case_counter['train'] == int(g['first_case']) + k
+    assert lb['outcome'] == g['ep_outcome'].tolist() and lb['steps'] == g['ep_steps'].tolist()
+    for e in range(k):
+        n = int(g['ep_steps'][e])
+        assert lb['actions'][e] == g['ep_actions'][e][:n].tolist(), e
+    assert len(mem) == len(g['memory_values'])
+    states = torch.stack([mem[i][0].cpu() for i in range(len(mem))]).numpy()
+    values = torch.cat([mem[i][1].cpu() for i in range(len(mem))]).numpy()
+    assert np.abs(states - g['memory_states']).max() <= 5e-6       # float32 rotate: device vs torch CPU libm
+    assert np.abs(values - g['memory_values']).max() <= 1e-6       # TD targets through the target network
+    assert ex.last_stats['collision_rate'] == float(np.mean(g['ep_outcome'] == 3))
+
+
+@pytest.mark.gpu
+def test_batched_rl_sampling_equals_the_gym_surface_loop():
+    """The lock-step batch against the reference's own loop (_run_sequential) on the device-backed gym surface."""
+    from crowdnav_amd.compat.trainer import ReplayMemory
+    g = load_golden('rl_sarl_plain.npz')
+
+    def collect(sequential):
+        c, env, robot, policy = _setup(g)
+        mem = ReplayMemory(100000)
+        ex = c.Explorer(env, robot, torch.device('cpu'), mem, 0.9, target_policy=policy)
+        ex.update_target_model(policy.get_model())
+        env.case_counter['train'] = 40
+        if sequential:
+            policy.set_phase('train')
+            stats = ex._run_sequential(5, 'train', True, False)
+            ex._report(5, 'train', None, False, *stats)
+        else:
+            ex.run_k_episodes(5, 'train', update_memory=True)
+        return mem, dict(ex.last_stats)
+
+    mem_b, stats_b = collect(False)
+    mem_s, stats_s = collect(True)
+    assert len(mem_b) == len(mem_s)
+    for key in ('success_rate', 'collision_rate', 'too_close', 'collision_cases', 'timeout_cases'):
+        assert stats_b[key] == stats_s[key], key
+    assert abs(stats_b['total_reward'] - stats_s['total_reward']) <= 1e-9
+    if len(mem_b):
+        xb = torch.stack([m[0].cpu() for m in mem_b.memory])
+        xs = torch.stack([m[0].cpu() for m in mem_s.memory])
+        vb = torch.cat([m[1].cpu() for m in mem_b.memory])
+        vs = torch.cat([m[1].cpu() for m in mem_s.memory])
+        assert (xb - xs).abs().max().item() <= 5e-6 and (vb - vs).abs().max().item() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_graph_captured_sgd_step_equals_eager_step():
+    """Trainer on the device replay ring: the hipGraph replay of one SGD step updates the network exactly like the
+    eager step (same batches: same torch seed), and capturing itself does not train."""
+    import copy
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory, Trainer
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    base = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4).to(dev)
+    mem = DeviceReplayMemory(1000, dev)
+    x = torch.randn(400, 5, 13, device=dev)
+    mem.push_batch(x, x[:, 0, 0] * 0.1 + 0.2)
+    nets = {}
+    for mode in ('graph', 'eager'):
+        net = copy.deepcopy(base)
+        tr = Trainer(net, mem, dev, batch_size=100)
+        tr._graph_failed = mode == 'eager'
+        tr.set_learning_rate(0.01)
+        torch.manual_seed(7)
+        tr.optimize_epoch(3)
+        loss = tr.optimize_batch(5)
+        assert np.isfinite(loss)
+        assert (tr._graph is not None) == (mode == 'graph') and not (mode == 'graph' and tr._graph_failed)
+        nets[mode] = net
+    for (k, a), (_, b) in zip(nets['graph'].state_dict().items(), nets['eager'].state_dict().items()):
+        assert (a - b).abs().max().item() <= 1e-6, k
+    assert any((a - b).abs().max().item() > 1e-4
+               for a, b in zip(nets['graph'].state_dict().values(), base.state_dict().values()))  # it did train
