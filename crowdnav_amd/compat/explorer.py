@@ -314,8 +314,8 @@ class Explorer(object):
             T = 0
             for t in range(max_steps):
                 sel = eng.sarl_select(want_values=False)
-                bad |= (sel['best'] == -2) & (alive != 0)
                 eng.sarl_explore(sel, policy.epsilon, mask=alive, want_explored=False)
+                bad |= (sel['best'] == -2) & (alive != 0)  # greedy branch without a finite value
                 eng.sarl_transform(out=traj[:, t], env_stride=max_steps * human_num * D)
                 out = eng.step(sel['action'], update=True, want_obs=False)
                 rew[t], inf[t], dmn[t], act[t] = out['reward'], out['info'], out['dmin'], sel['best']
