@@ -158,7 +158,13 @@ class CrowdSim(_Base):
                 human_num, rule = self.human_num, self.test_sim
             self._rule = rule
             self._eng = self._engine(human_num, rule)
-            self._eng.reset([offset[phase] + case])
+            draws = int(self._eng.reset([offset[phase] + case])[0].item())
+            # the reference seeds numpy's GLOBAL generator here (crowd_sim.py:274) and its scenario draws advance it;
+            # a train-phase policy then takes its epsilon-greedy draws from the same stream (multi_human_rl.py:28-30):
+            # leave the host generator exactly where the reference leaves it
+            np.random.seed(offset[phase] + case)
+            if draws:
+                np.random.random(draws)
             self.case_counter[phase] = (case + 1) % self.case_size[phase]
         else:
             assert phase == 'test'
