@@ -517,3 +517,15 @@ int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out) {
 }  // extern "C"
 
 #include "sarl_abi.inc"
+
+#ifdef CN_PHASE_TIMING
+// profiling builds only (scripts/phase_probe.py): accumulated shader-clock cycles per rollout phase, [8] = waves
+extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cn::cn_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_phase_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -140,6 +140,89 @@ __device__ __forceinline__ int lp_planar_reg(const float4 (&L)[MAXL], int n, flo
     return fail;
 }
 
+// ------------------------------------------------------------------ lane-cooperative 2-D program
+// The same program with one lane per (agent, half-plane): a wave holds kWave / MAXL agents (12 at MAXL = 5), lane
+// g * MAXL + l owns half-plane l of the g-th agent of the chunk.  Per round every agent advances to its next violated
+// half-plane i (ballot + first set bit of the agent's MAXL-bit field) and solves the 1-D program on it: lane l < i
+// contributes the one (numerator, denominator) pair of line l against line i, and the running interval
+// [t_lo, t_hi] is folded over the agent's lanes IN LINE ORDER with RVO2's strict comparisons, so ties (and signed
+// zeros) resolve exactly as in the sequential loop.  RVO2's early exits (parallel line with negative numerator,
+// t_lo > t_hi) are monotone — once true they stay true — so testing them after the fold is equivalent.
+// Rounds per step = the largest number of violated half-planes of any agent in the wave (<= MAXL), each ~100 VALU
+// on all lanes, instead of one fully unrolled, predicated program per agent lane on 12 of 64 lanes.
+//   lines [nA][kLineStride] half-planes, count [nA], sol [nA] = (pref.x, pref.y, maxSpeed, solve ? 1 : 0)
+//   res   [nA] = (result.x, result.y, int bits: first infeasible line or n, -)
+template <int MAXL>
+__device__ __forceinline__ void lp_planar_coop(const float4* lines, const int* count, const float4* sol, float4* res,
+                                               int nA) {
+    constexpr int G = kWave / MAXL;
+    const int wl = threadIdx.x & (kWave - 1);
+    const int g = wl / MAXL, l = wl - g * MAXL;
+    const int gbase = g * MAXL;
+    const int waves = (blockDim.x + kWave - 1) / kWave;
+    const float inf = __builtin_inff();
+    for (int chunk = threadIdx.x / kWave; chunk * G < nA; chunk += waves) {
+        const int a = chunk * G + g;
+        const bool live = g < G && a < nA;
+        const float4 so = sol[live ? a : 0];
+        const float ox = so.x, oy = so.y, radius = so.z;
+        const int n = (live && so.w != 0.0f) ? count[a] : 0;
+        const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float rx, ry;
+        lp_start_point(radius, ox, oy, rx, ry);
+        int cursor = 0;  // half-planes below the cursor are settled
+        int fail = n;
+        while (true) {
+            const bool viol = l >= cursor && l < n && (my.z * (my.y - ry) - my.w * (my.x - rx) > 0.0f);
+            const unsigned long long m = __ballot(viol);
+            if (m == 0ull) break;
+            const unsigned gm = (unsigned)(m >> gbase) & ((1u << MAXL) - 1u);
+            const bool act = gm != 0u;
+            const int i = act ? __ffs(gm) - 1 : 0;
+            const float4 li = lines[(live ? a : 0) * kLineStride + i];  // read-only here: plain LDS broadcast
+            const float px = li.x, py = li.y, dx = li.z, dy = li.w;
+            // this lane's line against line i
+            const float den = dx * my.w - dy * my.z;
+            const float num = my.z * (py - my.y) - my.w * (px - my.x);
+            const bool parallel = fabsf(den) <= kRvoEps;
+            const float t = num / den;
+            const bool mine = act && l < i;
+            const bool bad = mine && parallel && num < 0.0f;
+            const float c_hi = (mine && !parallel && den >= 0.0f) ? t : inf;
+            const float c_lo = (mine && !parallel && !(den >= 0.0f)) ? t : -inf;
+            const unsigned badm = (unsigned)(__ballot(bad) >> gbase) & ((1u << MAXL) - 1u);
+            // interval of line i inside the speed disc
+            const float dp = px * dx + py * dy;
+            const float disc = (dp * dp + radius * radius) - (px * px + py * py);
+            bool ok = !(disc < 0.0f) && badm == 0u;
+            const float root = sqrtf(disc);
+            float t_lo = -dp - root;
+            float t_hi = -dp + root;
+#pragma unroll
+            for (int j = 0; j < MAXL - 1; ++j) {  // the last line never constrains another one
+                const float hj = __shfl(c_hi, gbase + j);
+                const float lj = __shfl(c_lo, gbase + j);
+                t_hi = (hj < t_hi) ? hj : t_hi;
+                t_lo = (t_lo < lj) ? lj : t_lo;
+            }
+            ok = ok && !(t_lo > t_hi);
+            float tt = dx * (ox - px) + dy * (oy - py);
+            tt = (tt < t_lo) ? t_lo : ((tt > t_hi) ? t_hi : tt);
+            if (act) {
+                if (ok) {
+                    rx = px + tt * dx;
+                    ry = py + tt * dy;
+                    cursor = i + 1;
+                } else {  // linearProgram2 returns i with the previous result
+                    fail = i;
+                    cursor = n;
+                }
+            }
+        }
+        if (live && l == 0) res[a] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
+    }
+}
+
 // ------------------------------------------------------------------ generic programs on LDS half-planes
 // (used by the infeasible fallback only; same arithmetic as the register versions)
 __device__ inline bool lp_on_line_lds(const float4* L, int k, float radius, float ox, float oy, bool dir_opt,

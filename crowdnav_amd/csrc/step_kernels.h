@@ -90,13 +90,15 @@ struct Smem {
     int* pinfo;       // [pairs] packed pair descriptor
     int* count;       // [nA] neighbours kept
     int* flag;        // [nA] (robot lanes) per-env flag broadcast
+    float4* sol;      // [nA] lane-cooperative program input: (pref.x, pref.y, maxSpeed, solve ? 1 : 0)
+    float4* res;      // [nA] ... and output: (result.x, result.y, first infeasible line or n, -)
     double* disc;     // [kMaxDiscount] discount table gamma^(t dt v_pref) (rollout kernel only)
 };
 
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
 
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs) {
-    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 +
+    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 +
            sizeof(double) * kMaxDiscount;
 }
 
@@ -110,6 +112,8 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
     s.proj = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.sol = reinterpret_cast<float4*>(p), p += 16 * nA;
+    s.res = reinterpret_cast<float4*>(p), p += 16 * nA;
     s.rad = reinterpret_cast<double*>(p), p += 8 * nA;
     s.closest = reinterpret_cast<double*>(p), p += 8 * nA;
     s.hview = reinterpret_cast<float*>(p), p += 4 * nA;
@@ -203,16 +207,64 @@ __device__ __forceinline__ void load_robot_view(const Params& P, const StateView
 // ---------------------------------------------------------------------------------------------- ORCA phases
 // Stage + pair phases + per-agent solve.  Called by all 64 lanes (contains barriers); on return every valid
 // agent lane with solve == true holds its new velocity (ORCA.predict, orca.py:82-132).
+// CN_PHASE_TIMING (compile time, profiling builds only): per-phase shader-clock accumulation inside the fused rollout
+// (scripts/phase_probe.py).  Off in the product build: PhaseClock is empty and CN_TICK expands to nothing.
+#ifdef CN_PHASE_TIMING
+__device__ unsigned long long cn_phase_cycles[16];
+struct PhaseClock {
+    unsigned long long last, acc[9];
+};
+#define CN_TICK(clk, k)                                                \
+    do {                                                               \
+        if (clk) {                                                     \
+            const unsigned long long now_ = __builtin_readcyclecounter(); \
+            (clk)->acc[k] += now_ - (clk)->last;                       \
+            (clk)->last = now_;                                        \
+        }                                                              \
+    } while (0)
+#else
+struct PhaseClock {};
+#define CN_TICK(clk, k) \
+    do {                \
+    } while (0)
+#endif
+
+// CN_COOP_LP5 / CN_COOP_LP10 (compile time): solve the 2-D program with one lane per (agent, half-plane)
+// (lp_planar_coop) instead of one unrolled program per agent lane (lp_planar_reg), for MAXL = 5 / 10.
+#ifndef CN_COOP_LP5
+#define CN_COOP_LP5 0
+#endif
+#ifndef CN_COOP_LP10
+#define CN_COOP_LP10 0
+#endif
+
 template <int MAXL>
 __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
-                                            float robot_max_speed, bool solve, float& out_vx, float& out_vy) {
+                                            float robot_max_speed, bool solve, float& out_vx, float& out_vy,
+                                            PhaseClock* clk = nullptr) {
+    (void)clk;
+    constexpr bool kCoop = (MAXL == 5) ? (CN_COOP_LP5 != 0) : (CN_COOP_LP10 != 0);
+    // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
+    const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
+    auto preferred = [&](float& pref_x, float& pref_y) {
+        const double gdx = r.gx - r.px, gdy = r.gy - r.py;
+        const double speed = norm2(gdx, gdy);
+        pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
+        pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
+    };
     if (L.lane < P.nA) {
         s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
         s.posd[L.lane] = make_double2(r.px, r.py);
         s.rad[L.lane] = r.rad;
         s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
+        if (kCoop) {
+            float pref_x, pref_y;
+            preferred(pref_x, pref_y);
+            s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
+        }
     }
     __syncthreads();
+    CN_TICK(clk, 0);
 
     // pairs-1: squared distances, self.pos - other.pos (Appendix A.2)
     for (int p = L.lane; p < P.pairs; p += blockDim.x) {
@@ -223,6 +275,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         s.d2[p] = ((info >> 24) & 1) ? dx * dx + dy * dy : std::numeric_limits<float>::infinity();
     }
     __syncthreads();
+    CN_TICK(clk, 1);
 
     // pairs-2: neighbour slot = stable rank by (distSq, visit order) among the in-range candidates, which
     // is what RVO2's sorted insertion with strict '<' produces; slots >= maxNeighbors fall off the list.
@@ -251,25 +304,34 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         }
     }
     __syncthreads();
+    CN_TICK(clk, 2);
 
     out_vx = 0.0f, out_vy = 0.0f;
-    if (solve) {
+    if (kCoop) {
+        lp_planar_coop<MAXL>(s.lines, s.count, s.sol, s.res, P.nA);
+        __syncthreads();
+        if (solve) {
+            const int n = s.count[L.lane];
+            const float4 got = s.res[L.lane];
+            float rx = got.x, ry = got.y;
+            const int fail = __float_as_int(got.z);
+            if (fail < n)
+                lp_relaxed_lds(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
+            out_vx = rx, out_vy = ry;
+        }
+    } else if (solve) {
         const int n = s.count[L.lane];
         const float4* mine = s.lines + L.lane * kLineStride;
         float4 Lr[MAXL];
 #pragma unroll
         for (int k = 0; k < MAXL; ++k) Lr[k] = (k < n) ? mine[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
-        const double gdx = r.gx - r.px, gdy = r.gy - r.py;
-        const double speed = norm2(gdx, gdy);
-        const float pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
-        const float pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
-        const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
-        float rx, ry;
+        float pref_x, pref_y, rx, ry;
+        preferred(pref_x, pref_y);
         const int fail = lp_planar_reg<MAXL>(Lr, n, max_speed, pref_x, pref_y, rx, ry);
         if (fail < n) lp_relaxed_lds(mine, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
         out_vx = rx, out_vy = ry;
     }
+    CN_TICK(clk, 3);
 }
 
 struct StepResult {  // meaningful on the robot lane
@@ -292,9 +354,10 @@ template <int MAXL, bool UNI>
 __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
                                           double& gtime, float robot_max_speed, const double* ext_action,
                                           int update, StepResult& res, double& new_vx, double& new_vy,
-                                          double* theta_io = nullptr) {
+                                          double* theta_io = nullptr, PhaseClock* clk = nullptr) {
+    (void)clk;
     float ovx, ovy;
-    orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy);
+    orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
     new_vx = ovx;
     new_vy = ovy;
     // unicycle robot (ActionRot v, r): the collision test uses v (cos, sin)(r + theta) (crowd_sim.py:339-341), the
@@ -314,6 +377,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
         s.act[L.lane] = make_double2(new_vx, new_vy);
     }
     __syncthreads();
+    CN_TICK(clk, 4);
 
     // One float64 distance per agent lane, computed branch-free so that humans and the robot share the
     // instruction stream:
@@ -348,6 +412,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
         }
     }
     __syncthreads();
+    CN_TICK(clk, 5);
 
     res.done = 0;
     if (L.valid && L.a == 0) {
@@ -393,6 +458,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
             r.vy = new_vy;
         }
     }
+    CN_TICK(clk, 6);
 }
 
 // ---------------------------------------------------------------------------------------------- kernels
@@ -731,13 +797,20 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
     for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
     __syncthreads();
 
+#ifdef CN_PHASE_TIMING
+    PhaseClock clock = {};
+    PhaseClock* clk = &clock;
+    clock.last = __builtin_readcyclecounter();
+#else
+    PhaseClock* clk = nullptr;
+#endif
     for (int step = 0; step < n_steps; ++step) {
         Lane Ls = L;
         Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env is running
 
         StepResult res;
         double nvx, nvy;
-        step_core<MAXL, UNI>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta);
+        step_core<MAXL, UNI>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
 
         if (robot && state == kRunning) {
             int next_flag = 1;
@@ -762,7 +835,14 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
             load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
             theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
         }
+        CN_TICK(clk, 7);
     }
+#ifdef CN_PHASE_TIMING
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
+        atomicAdd(&cn_phase_cycles[8], 1ull);  // waves
+    }
+#endif
 
     if (L.valid) {
         S.pos[L.gi] = make_double2(r.px, r.py);

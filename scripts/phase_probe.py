@@ -1,0 +1,60 @@
+"""Per-phase shader-clock breakdown of the fused rollout (profiling build only).
+
+    hipcc ... -DCN_PHASE_TIMING crowdnav_amd.hip -o crowdnav_amd/lib/exp/lib_timing.so
+    CROWDNAV_AMD_LIB=crowdnav_amd/lib/exp/lib_timing.so python scripts/phase_probe.py [--humans 5] [--envs 4096]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import crowdnav_amd  # noqa: E402
+from crowdnav_amd import _lib  # noqa: E402
+
+NAMES = ['stage', 'pairs-1 (distances)', 'pairs-2 (rank + half-plane)', 'solve (LP)', 'robot action publish',
+         'collide (f64 swept distance)', 'reduce + integrate', 'episode bookkeeping / ring']
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--humans', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--circle-radius', type=float, default=4.0)
+    a = ap.parse_args()
+    lib = _lib.load()
+    probe = lib.cn_debug_phase_cycles
+    probe.restype, probe.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=a.envs, num_humans=a.humans, robot_policy=crowdnav_amd.ROBOT_ORCA,
+                                       robot_visible=1, circle_radius=a.circle_radius)
+    bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, record_capacity=4)
+    eng.rollout(500)
+    eng.sync()
+    assert probe(None, 1) == 0
+    t0 = time.perf_counter()
+    done = 0
+    while done < a.steps:
+        eng.rollout(500)
+        done += 500
+    eng.sync()
+    dt = time.perf_counter() - t0
+    out = (C.c_ulonglong * 16)()
+    assert probe(out, 0) == 0
+    cyc = np.array(out[:8], dtype=np.float64)
+    launches = a.steps // 500
+    waves = out[8] / launches
+    per = cyc / out[8] / 500  # cycles per wave-step
+    print('envs %d humans %d: %.1f M env-steps/s (instrumented), %d waves, %.0f clock ticks per wave-step'
+          % (a.envs, a.humans, a.envs * a.steps / dt / 1e6, waves, per.sum()))
+    for n, c in zip(NAMES, per):
+        print('  %-34s %8.0f  %5.1f %%' % (n, c, 100 * c / per.sum()))
+    print('  transitions', int(bufs['transitions'].cpu()[0]))
+
+
+if __name__ == '__main__':
+    main()
