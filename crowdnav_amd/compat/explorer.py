@@ -49,7 +49,7 @@ class Explorer(object):
         no_wrap = (self.env.case_counter[phase] >= 0 and self.env.case_counter[phase] + k <= self.env.case_size[phase])
         batched_il = (is_device_orca(self.robot.policy) and update_memory and imitation_learning and no_wrap
                       and hasattr(self.env, 'engine_config') and isinstance(self.target_policy, SARL))
-        batched_rl = (type(self.robot.policy) is SARL and phase == 'train' and update_memory
+        batched_rl = (isinstance(self.robot.policy, SARL) and phase == 'train' and update_memory
                       and not imitation_learning and no_wrap and hasattr(self.env, 'engine_config')
                       and getattr(self.robot.policy, 'env', None) is self.env)
         if batched_il:
@@ -221,12 +221,15 @@ class Explorer(object):
             joint = torch.Tensor(np.concatenate(rows, axis=0))                                  # [N, H, 14] float32
             n, h, _ = joint.shape
             from .sarl import occupancy_maps, rotate
-            x = rotate(joint.reshape(n * h, 14)).reshape(n, h, 13)
+            x = rotate(joint.reshape(n * h, 14), policy.kinematics).reshape(n, h, 13)
             if policy.with_om:
                 from .types import ObservableState
                 maps = [occupancy_maps([ObservableState(*row) for row in js[:, 9:14].double().tolist()], policy.cell_num,
                                        policy.cell_size, policy.om_channel_size) for js in joint]
                 x = torch.cat([x, torch.stack(maps)], dim=2)
+            if policy.net_cfg.get('model') == 'cadrl':  # CADRL.transform (cadrl.py:174-185): one human, [13]
+                assert h == 1
+                x = x[:, 0]
             self._push_all(x, torch.Tensor(values))
 
         self.last_batch = dict(outcome=outcome, steps=length, env_steps=int(sum(length)))
@@ -275,7 +278,8 @@ class Explorer(object):
 
     def _run_batched_rl(self, k, phase):
         """RL-phase sampling (train.py:147-157: run_k_episodes(sample_episodes, 'train', update_memory=True)) with the
-        epsilon-greedy value-network robot, k episodes in lock step on the device.  Per batched step:
+        epsilon-greedy value-network robot (SARL, CADRL or LSTM-RL), k episodes in lock step on the device.  Per
+        batched step:
         cn_sarl_select (greedy action of every env) -> cn_sarl_explore (the epsilon branch of
         multi_human_rl.py:28-31 on each env's own numpy stream, continued after its scenario draws) ->
         cn_sarl_transform (policy.last_state, written straight into the trajectory tensor) -> cn_step.  Then
@@ -342,8 +346,11 @@ class Explorer(object):
                 bt = torch.as_tensor(b_idx, device=eng.device)
                 it = torch.as_tensor(i_idx, device=eng.device)
                 states = traj[bt, it]                                         # [N, H, D]
+                single = policy.net_cfg.get('model') == 'cadrl'      # CADRL.transform: one human, [13]
                 is_last = torch.as_tensor(i_idx == Tb[b_idx] - 1, device=eng.device)
                 nxt = traj[bt, torch.clamp(it + 1, max=max_steps - 1)]
+                if single:
+                    states, nxt = states[:, 0], nxt[:, 0]
                 with torch.no_grad():
                     tm_device = next(self.target_model.parameters()).device
                     v_next = self.target_model(nxt.to(tm_device)).reshape(-1).to(eng.device).double()

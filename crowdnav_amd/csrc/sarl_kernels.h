@@ -307,14 +307,38 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
 // MultiHumanRL.transform (multi_human_rl.py:90-104; CADRL.transform cadrl.py:171-185 when H = 1) of the CURRENT joint
 // state of every env: rotate(float32 [self_state (9) | human h (5)]) (+ human h's occupancy map among the current
 // human states) -> out[b][h][0..in_dim): the state a train-phase predict() leaves in policy.last_state and
-// Explorer.update_memory pushes into the replay memory.  lane = (env, human).
-__global__ void sarl_transform_kernel(SarlCfg C, int in_dim, const double2* pos, const double2* vel,
+// Explorer.update_memory pushes into the replay memory.  lane = (env, position in the joint state).
+__global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, const double2* pos, const double2* vel,
                                       const double2* goal, const double2* rv, const double* theta,
                                       float* out /*[B][H][in_dim]*/, int64_t env_stride /*floats between envs*/) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= C.B * C.H) return;
     const int b = idx / C.H, h = idx - b * C.H;
-    const size_t g0 = (size_t)b * (C.H + 1), g1 = g0 + 1 + h;
+    const size_t g0 = (size_t)b * (C.H + 1);
+    // perm[p] = human at position p of the joint state.  LSTM-RL (sort_humans): LstmRL.predict re-orders the humans by
+    // DEcreasing distance to the robot before MultiHumanRL.predict runs (lstm_rl.py:96-103; python's sorted(...,
+    // reverse=True) is stable: equal distances keep their original order), so that is the order of last_state.
+    int perm[kSarlMaxHumans];
+#pragma unroll
+    for (int p = 0; p < kSarlMaxHumans; ++p) perm[p] = p;
+    if (sort_humans) {
+        double d[kSarlMaxHumans];
+#pragma unroll
+        for (int j = 0; j < kSarlMaxHumans; ++j)
+            d[j] = j < C.H ? norm2(pos[g0 + 1 + j].x - pos[g0].x, pos[g0 + 1 + j].y - pos[g0].y) : -1.0;
+#pragma unroll
+        for (int j = 0; j < kSarlMaxHumans; ++j) {
+            int rank = 0;
+#pragma unroll
+            for (int k = 0; k < kSarlMaxHumans; ++k) rank += (k < C.H && (d[k] > d[j] || (d[k] == d[j] && k < j))) ? 1 : 0;
+#pragma unroll
+            for (int p = 0; p < kSarlMaxHumans; ++p) perm[p] = (j < C.H && rank == p) ? j : perm[p];
+        }
+    }
+    int me = 0;
+#pragma unroll
+    for (int p = 0; p < kSarlMaxHumans; ++p) me = (p == h) ? perm[p] : me;
+    const size_t g1 = g0 + 1 + me;
     float f[13];
     rotate_row((float)pos[g0].x, (float)pos[g0].y, (float)vel[g0].x, (float)vel[g0].y, (float)rv[g0].x,
                (float)goal[g0].x, (float)goal[g0].y, (float)rv[g0].y, (float)theta[b], C.unicycle, (float)pos[g1].x,
@@ -324,7 +348,10 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, const double2* pos,
     for (int k = 0; k < 13; ++k) x[k] = f[k];
     if (C.with_om) {
         auto state_of = [&](int j, double& px, double& py, double& vx, double& vy) {
-            const size_t gj = g0 + 1 + j;
+            int oj = 0;
+#pragma unroll
+            for (int p = 0; p < kSarlMaxHumans; ++p) oj = (p == j) ? perm[p] : oj;
+            const size_t gj = g0 + 1 + oj;
             px = pos[gj].x, py = pos[gj].y, vx = vel[gj].x, vy = vel[gj].y;
         };
         occupancy_map(C, h, state_of, x + 13);

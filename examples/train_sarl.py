@@ -24,8 +24,9 @@ from crowdnav_amd.compat.trainer import DeviceReplayMemory, ReplayMemory, Traine
 def run(args):
     device = torch.device('cuda:0' if args.gpu and torch.cuda.is_available() else 'cpu')
     env_cfg = cn.default_env_config({('env', 'val_size'): args.val_size, ('env', 'test_size'): args.test_size})
-    policy = cn.policy_factory['sarl']()
-    policy.configure(default_policy_config({('sarl', 'with_om'): 'true' if args.with_om else 'false'}))
+    policy = cn.policy_factory[args.policy]()
+    policy.configure(default_policy_config({(args.policy, 'with_om'): 'true' if args.with_om else 'false'}
+                                           if args.policy != 'cadrl' else None))
     policy.set_device(device)
     env = cn.CrowdSim()
     env.configure(env_cfg)
@@ -105,6 +106,7 @@ def run(args):
 def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpu', action='store_true', help='keep the torch model / trainer on cuda:0 (rollouts always are)')
+    ap.add_argument('--policy', choices=['sarl', 'cadrl', 'lstm_rl'], default='sarl')
     ap.add_argument('--with-om', action='store_true')
     ap.add_argument('--output-dir', default=None)
     ap.add_argument('--timing-json', default=None, help='write losses, final stats and per-phase wall-clock here')

@@ -25,13 +25,14 @@ OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 INFO = {'Nothing': 0, 'Danger': 1, 'ReachGoal': 2, 'Collision': 3, 'Timeout': 4}
 
 
-def generate(name, with_om, robot_visible, k, epsilon, first_case=0):
+def generate(name, with_om, robot_visible, k, epsilon, first_case=0, policy_name='sarl'):
     rh.activate()
     from crowd_nav.utils.explorer import Explorer
     from crowd_nav.utils.memory import ReplayMemory
     torch.manual_seed(0)
-    pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false'})
-    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name='sarl', policy_config=pcfg)
+    pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
+                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false'})
+    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
     device = torch.device('cpu')
     policy.set_device(device)
     policy.set_env(env)
@@ -45,6 +46,8 @@ def generate(name, with_om, robot_visible, k, epsilon, first_case=0):
     env.case_counter['train'] = first_case
     explorer.run_k_episodes(k, 'train', update_memory=True, episode=0)
     states = np.stack([s.numpy() for s, _ in memory.memory]) if len(memory) else np.zeros((0, 5, policy.input_dim()))
+    if states.ndim == 2:  # CADRL.transform: one human, [13]
+        states = states[:, None, :]
     values = np.array([float(v.item()) for _, v in memory.memory], dtype=np.float32)
 
     # pass 2: the same episodes step by step (every reset reseeds numpy, the network is deterministic on the CPU)
@@ -72,7 +75,7 @@ def generate(name, with_om, robot_visible, k, epsilon, first_case=0):
                ep_rewards=np.array(ep_rewards), ep_outcome=np.array(ep_outcome), ep_steps=np.array(ep_steps),
                ep_time=np.array(ep_time), epsilon=np.array(epsilon), k=np.array(k), first_case=np.array(first_case),
                with_om=np.array(int(with_om)), robot_visible=np.array(int(robot_visible)),
-               gamma=np.array(policy.gamma),
+               gamma=np.array(policy.gamma), policy=np.array(policy_name),
                action_space=np.array([list(a) for a in policy.action_space], dtype=np.float64))
     for key, v in model.state_dict().items():
         out['param_' + key] = v.numpy()
@@ -83,5 +86,12 @@ def generate(name, with_om, robot_visible, k, epsilon, first_case=0):
 
 if __name__ == '__main__':
     assert rh.available()
-    generate('rl_sarl_plain.npz', with_om=False, robot_visible=False, k=12, epsilon=0.5)
-    generate('rl_sarl_om.npz', with_om=True, robot_visible=True, k=8, epsilon=0.3, first_case=100)
+    which = sys.argv[1:] or ['sarl', 'cadrl', 'lstm_rl']
+    if 'sarl' in which:
+        generate('rl_sarl_plain.npz', with_om=False, robot_visible=False, k=12, epsilon=0.5)
+        generate('rl_sarl_om.npz', with_om=True, robot_visible=True, k=8, epsilon=0.3, first_case=100)
+    if 'cadrl' in which:  # one human (multiagent_training = false), circle crossing
+        generate('rl_cadrl.npz', with_om=False, robot_visible=True, k=10, epsilon=0.4, first_case=200, policy_name='cadrl')
+    if 'lstm_rl' in which:  # replay states hold the humans by decreasing distance (lstm_rl.py:96-103)
+        generate('rl_lstm_rl.npz', with_om=False, robot_visible=True, k=8, epsilon=0.3, first_case=300, policy_name='lstm_rl')
+        generate('rl_lstm_rl_om.npz', with_om=True, robot_visible=False, k=6, epsilon=0.5, first_case=400, policy_name='lstm_rl')

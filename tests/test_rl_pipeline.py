@@ -7,7 +7,7 @@ import torch
 
 from conftest import load_golden
 
-RL_FIXTURES = ['rl_sarl_plain.npz', 'rl_sarl_om.npz']
+RL_FIXTURES = ['rl_sarl_plain.npz', 'rl_sarl_om.npz', 'rl_cadrl.npz', 'rl_lstm_rl.npz', 'rl_lstm_rl_om.npz']
 
 
 # ------------------------------------------------------------------------------------------------ CPU
@@ -72,12 +72,14 @@ def _setup(g):
     import crowdnav_amd.compat as c
     from crowdnav_amd.compat.sarl import default_policy_config
     with_om, visible = bool(int(g['with_om'])), bool(int(g['robot_visible']))
+    name = str(g['policy']) if 'policy' in g else 'sarl'
     cfg = c.default_env_config({('robot', 'visible'): 'true' if visible else 'false'})
     env = c.CrowdSim()
     env.configure(cfg)
     robot = c.Robot(cfg, 'robot')
-    policy = c.policy_factory['sarl']()
-    policy.configure(default_policy_config({('sarl', 'with_om'): 'true' if with_om else 'false'}))
+    policy = c.policy_factory[name]()
+    policy.configure(default_policy_config({(name, 'with_om'): 'true' if with_om else 'false'} if name != 'cadrl'
+                                           else None))
     policy.get_model().load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items()
                                         if k.startswith('param_')})
     robot.set_policy(policy)
@@ -201,16 +203,20 @@ def test_batched_rl_sampling_reproduces_the_reference_memory(name, device_memory
     assert len(mem) == len(g['memory_values'])
     states = torch.stack([mem[i][0].cpu() for i in range(len(mem))]).numpy()
     values = torch.cat([mem[i][1].cpu() for i in range(len(mem))]).numpy()
+    if 'policy' in g and str(g['policy']) == 'cadrl':
+        assert states.shape[1:] == (13,)                            # CADRL.transform: one human, no human axis
+        states = states[:, None, :]
     assert np.abs(states - g['memory_states']).max() <= 5e-6       # float32 rotate: device vs torch CPU libm
     assert np.abs(values - g['memory_values']).max() <= 1e-6       # TD targets through the target network
     assert ex.last_stats['collision_rate'] == float(np.mean(g['ep_outcome'] == 3))
 
 
 @pytest.mark.gpu
-def test_batched_rl_sampling_equals_the_gym_surface_loop():
+@pytest.mark.parametrize('name', ['rl_sarl_plain.npz', 'rl_cadrl.npz', 'rl_lstm_rl_om.npz'])
+def test_batched_rl_sampling_equals_the_gym_surface_loop(name):
     """The lock-step batch against the reference's own loop (_run_sequential) on the device-backed gym surface."""
     from crowdnav_amd.compat.trainer import ReplayMemory
-    g = load_golden('rl_sarl_plain.npz')
+    g = load_golden(name)
 
     def collect(sequential):
         c, env, robot, policy = _setup(g)
@@ -218,6 +224,7 @@ def test_batched_rl_sampling_equals_the_gym_surface_loop():
         ex = c.Explorer(env, robot, torch.device('cpu'), mem, 0.9, target_policy=policy)
         ex.update_target_model(policy.get_model())
         env.case_counter['train'] = 40
+        assert ex.memory is mem
         if sequential:
             policy.set_phase('train')
             stats = ex._run_sequential(5, 'train', True, False)
@@ -269,3 +276,41 @@ def test_graph_captured_sgd_step_equals_eager_step():
         assert (a - b).abs().max().item() <= 1e-6, k
     assert any((a - b).abs().max().item() > 1e-4
                for a, b in zip(nets['graph'].state_dict().values(), base.state_dict().values()))  # it did train
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_om', [False, True])
+def test_lstm_rl_transform_orders_humans_by_decreasing_distance(with_om):
+    """cn_sarl_transform for CN_MODEL_LSTM_RL == LstmRL.predict's re-ordering followed by the policy's transform."""
+    import crowdnav_amd
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config, occupancy_maps, rotate
+    from crowdnav_amd.compat.types import ObservableState
+    B, H = 24, 5
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    policy = c.policy_factory['lstm_rl']()
+    policy.configure(default_policy_config({('lstm_rl', 'with_om'): 'true' if with_om else 'false'}))
+    policy.build_action_space(1.0)
+    eng.sarl_configure(**policy.engine_kwargs())
+    eng.reset(4000 + np.arange(B))
+    rng = np.random.RandomState(1)
+    for t in range(3):
+        eng.step(rng.uniform(-0.7, 0.7, size=(B, 2)), update=True, want_obs=False)
+    st = eng.get_state()[0].cpu().numpy()
+    st[3, 2, :2] = st[3, 4, :2] = st[3, 0, :2] + np.array([1.5, 2.0])       # an exact tie: stable, original order kept
+    eng.set_state(st, np.zeros(B))
+    got = eng.sarl_transform().cpu()
+    for b in range(B):
+        me = st[b, 0]
+        d = [np.linalg.norm(np.array((st[b, 1 + j, 0], st[b, 1 + j, 1])) - np.array((me[0], me[1]))) for j in range(H)]
+        order = sorted(range(H), key=lambda j: d[j], reverse=True)
+        hum = st[b, 1:][order][:, [0, 1, 2, 3, 6]]
+        self_row = np.array([me[0], me[1], me[2], me[3], me[6], me[4], me[5], me[7], np.pi / 2])
+        joint = torch.Tensor(np.concatenate([np.repeat(self_row[None], H, axis=0), hum], axis=1))
+        want = rotate(joint)
+        if with_om:
+            want = torch.cat([want, occupancy_maps([ObservableState(*row) for row in hum.tolist()], policy.cell_num,
+                                                   policy.cell_size, policy.om_channel_size)], dim=1)
+        assert (got[b] - want).abs().max().item() <= 5e-6, b
+    assert sorted(range(H), key=lambda j: np.hypot(*(st[3, 1 + j, :2] - st[3, 0, :2])), reverse=True).index(1) + 1 == \
+        sorted(range(H), key=lambda j: np.hypot(*(st[3, 1 + j, :2] - st[3, 0, :2])), reverse=True).index(3)

@@ -200,7 +200,8 @@ def test_replay_memory_and_trainer_cpu():
 
 
 @pytest.mark.gpu
-def test_train_schedule_smoke_config5():
+@pytest.mark.parametrize('policy', ['sarl', 'cadrl', 'lstm_rl'])
+def test_train_schedule_smoke_config5(policy):
     """The reference's train.py schedule end to end on tiny sizes: IL from device ORCA demonstrations, RL with
     epsilon-greedy device SARL decisions, torch trainer, batched val/test evaluation."""
     import importlib.util
@@ -211,7 +212,7 @@ def test_train_schedule_smoke_config5():
     spec.loader.exec_module(mod)
     args = mod.parser().parse_args(['--il-episodes', '6', '--il-epochs', '3', '--train-episodes', '3', '--train-batches',
                                     '4', '--evaluation-interval', '2', '--val-size', '4', '--test-size', '4',
-                                    '--target-update-interval', '2', '--batch-size', '16'])
+                                    '--target-update-interval', '2', '--batch-size', '16', '--policy', policy])
     out = mod.run(args)
     assert out['memory'] > 50 and out['il_loss'] is not None and out['rl_loss'] is not None
     assert np.isfinite(out['il_loss']) and np.isfinite(out['rl_loss'])
@@ -220,8 +221,8 @@ def test_train_schedule_smoke_config5():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('with_om', [False, True])
-def test_batched_imitation_collection_equals_sequential(with_om):
+@pytest.mark.parametrize('name,with_om', [('sarl', False), ('sarl', True), ('cadrl', False), ('lstm_rl', True)])
+def test_batched_imitation_collection_equals_sequential(name, with_om):
     """Explorer.run_k_episodes(k, 'train', update_memory=True, imitation_learning=True): the lock-step batched
     collection fills the replay memory with the same (state, value) pairs, in the same order, as the reference loop."""
     import crowdnav_amd.compat as c
@@ -233,8 +234,9 @@ def test_batched_imitation_collection_equals_sequential(with_om):
         env = c.CrowdSim()
         env.configure(cfg)
         robot = c.Robot(cfg, 'robot')
-        target = c.policy_factory['sarl']()
-        target.configure(default_policy_config({('sarl', 'with_om'): 'true' if with_om else 'false'}))
+        target = c.policy_factory[name]()
+        target.configure(default_policy_config({(name, 'with_om'): 'true' if with_om else 'false'} if name != 'cadrl'
+                                               else None))
         target.set_device(torch.device('cpu'))
         il = c.policy_factory['orca']()
         il.multiagent_training, il.safety_space = target.multiagent_training, 0.15
