@@ -220,7 +220,10 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    total = transitions * world
+    n = torch.tensor([transitions], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(n)  # transitions of every shard (they differ by the few ring-dry pauses)
+    total = int(n.item())
 
     kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
     launches = len(events)
