@@ -16,7 +16,7 @@ CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1,
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
 NOTHING, DANGER, REACH_GOAL, COLLISION, TIMEOUT = range(5)
 ROBOT_EXTERNAL, ROBOT_ORCA = 0, 1
-CIRCLE_CROSSING, SQUARE_CROSSING = 0, 1
+CIRCLE_CROSSING, SQUARE_CROSSING, MIXED = 0, 1, 2
 HOLONOMIC, UNICYCLE = 0, 1
 
 
@@ -83,6 +83,7 @@ SYMBOLS = {
     'cn_get_state': (C.c_int, [_P, _P, _P]),
     'cn_set_theta': (C.c_int, [_P, _P]),
     'cn_get_theta': (C.c_int, [_P, _P]),
+    'cn_get_human_count': (C.c_int, [_P, _P]),
     'cn_drop_robot_sim': (C.c_int, [_P]),
     'cn_reset': (C.c_int, [_P, _P, _P, _P]),
     'cn_orca': (C.c_int, [_P, _P]),

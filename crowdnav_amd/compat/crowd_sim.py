@@ -5,8 +5,9 @@
 
 Every transition (the humans' ORCA solves, collision / reward / done, integration) and every seeded reset runs
 in libcrowdnav_amd on the GPU; this class only moves the results into the objects the reference's callers read.
-Not covered (raise NotImplementedError): render, get_human_times, the 'mixed' scenario rule —
-out of the accelerated path."""
+All three scenario rules are covered (`mixed`: 5 agent slots, absent humans parked; unlike the reference — which sizes
+human_times from the previous episode, crowd_sim.py:262-265 — consecutive mixed resets work).  Not covered (raise
+NotImplementedError): render, get_human_times, value-network policies under `mixed`."""
 import configparser
 import logging
 
@@ -24,7 +25,8 @@ try:  # pragma: no cover
 except Exception:
     _Base = object
 
-_RULES = {'circle_crossing': _lib.CIRCLE_CROSSING, 'square_crossing': _lib.SQUARE_CROSSING}
+_RULES = {'circle_crossing': _lib.CIRCLE_CROSSING, 'square_crossing': _lib.SQUARE_CROSSING, 'mixed': _lib.MIXED}
+_MIXED_SLOTS = 5  # `mixed` draws 0..5 humans per episode (crowd_sim.py:105-106); the engine holds 5 slots
 
 
 def default_env_config(overrides=None):
@@ -107,6 +109,8 @@ class CrowdSim(_Base):
         if kin == 'unicycle' and robot_policy == _lib.ROBOT_ORCA:
             raise NotImplementedError('the device ORCA robot is holonomic')
         pol = self.robot.policy
+        if rule == 'mixed':  # the rule ignores the configured number and draws its own (crowd_sim.py:103-115)
+            human_num = _MIXED_SLOTS
         return dict(
             num_envs=num_envs, num_humans=human_num, time_step=self.time_step, time_limit=float(self.time_limit),
             success_reward=self.success_reward, collision_penalty=self.collision_penalty,
@@ -159,6 +163,11 @@ class CrowdSim(_Base):
             self._rule = rule
             self._eng = self._engine(human_num, rule)
             draws = int(self._eng.reset([offset[phase] + case])[0].item())
+            if rule == 'mixed':  # len(self.humans) of this episode; self.human_num as the reference leaves it (:115)
+                human_num = int(self._eng.human_count().cpu()[0])
+                st = self._eng.get_state()[0].cpu().numpy()[0]
+                placeholder = human_num == 1 and tuple(st[1, [0, 1, 4, 5]]) == (0.0, -10.0, 0.0, -10.0)
+                self.human_num = 0 if placeholder else human_num
             # the reference seeds numpy's GLOBAL generator here (crowd_sim.py:274) and its scenario draws advance it;
             # a train-phase policy then takes its epsilon-greedy draws from the same stream (multi_human_rl.py:28-30):
             # leave the host generator exactly where the reference leaves it
@@ -215,7 +224,7 @@ class CrowdSim(_Base):
         reward = float(out['reward'].cpu()[0])
         done = bool(out['done'].cpu()[0])
         info = info_from_code(out['info'].cpu()[0], out['dmin'].cpu()[0])
-        obs = out['obs'].cpu().numpy()[0]
+        obs = out['obs'].cpu().numpy()[0][:len(self.humans)]  # absent humans of a `mixed` episode are parked behind
         if update:
             self._pull()
             for i, h in enumerate(self.humans):
@@ -237,6 +246,9 @@ class CrowdSim(_Base):
     def sarl_action(self, policy):
         """Greedy SARL decision for the current device state: (best index | -1 stop | -2 invalid, 81 values)."""
         eng = self._eng
+        if self._rule == 'mixed':
+            raise NotImplementedError('value-network policies under the mixed rule (a different number of humans per '
+                                      'episode) are outside the accelerated path')
         if getattr(eng, 'sarl', None) is None:
             eng.sarl_configure(**policy.engine_kwargs())
         # re-upload the parameters only when the Trainer (or a load_state_dict) has changed them: torch bumps a

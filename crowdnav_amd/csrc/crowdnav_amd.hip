@@ -136,8 +136,17 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (c->max_neighbors < 0 || c->max_neighbors > cn::kMaxNb)
         return fail(CN_ERR_UNSUPPORTED, "max_neighbors must be in 0..%d (got %d)", cn::kMaxNb, c->max_neighbors);
     if (!(c->time_step > 0.0)) return fail(CN_ERR_INVALID, "time_step must be > 0");
-    if (c->scenario_rule != CN_CIRCLE_CROSSING && c->scenario_rule != CN_SQUARE_CROSSING)
+    if (c->scenario_rule != CN_CIRCLE_CROSSING && c->scenario_rule != CN_SQUARE_CROSSING && c->scenario_rule != CN_MIXED)
         return fail(CN_ERR_UNSUPPORTED, "scenario_rule %d not supported", c->scenario_rule);
+    if (c->scenario_rule == CN_MIXED) {
+        if (c->num_humans < 5 || c->num_humans > 8)
+            return fail(CN_ERR_UNSUPPORTED, "scenario_rule mixed draws up to 5 humans per episode: num_humans must be in 5..8 (got %d)",
+                        c->num_humans);
+        if (c->randomize_attributes && c->robot_policy == CN_ROBOT_ORCA)
+            return fail(CN_ERR_UNSUPPORTED,
+                        "mixed + randomize_attributes + the ORCA robot: the reference rebuilds the robot's rvo2 simulator "
+                        "whenever the number of humans changes (orca.py:95-98), which the per-env radius capture does not model");
+    }
     if (c->robot_policy != CN_ROBOT_EXTERNAL && c->robot_policy != CN_ROBOT_ORCA)
         return fail(CN_ERR_INVALID, "robot_policy %d unknown", c->robot_policy);
     if (c->robot_kinematics != CN_HOLONOMIC && c->robot_kinematics != CN_UNICYCLE)
@@ -342,6 +351,25 @@ int cn_get_theta(cn_engine* e, double* theta) {
     if (rc) return rc;
     if (!theta) return fail(CN_ERR_INVALID, "cn_get_theta: NULL");
     CN_HIP(hipMemcpyAsync(theta, e->S.theta, sizeof(double) * e->P.B, hipMemcpyDeviceToDevice, e->stream));
+    return CN_OK;
+}
+
+namespace {
+__global__ void human_count_kernel(int B, int A, const double2* pos, int32_t* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    for (int i = 1; i < A; ++i) n += cn::is_parked(pos[(size_t)b * A + i]) ? 0 : 1;
+    out[b] = n;
+}
+}  // namespace
+
+int cn_get_human_count(cn_engine* e, int32_t* count) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if (!count) return fail(CN_ERR_INVALID, "cn_get_human_count: NULL");
+    hipLaunchKernelGGL(human_count_kernel, dim3((e->P.B + 255) / 256), dim3(256), 0, e->stream, e->P.B, e->P.A, e->S.pos, count);
+    CN_HIP(hipGetLastError());
     return CN_OK;
 }
 

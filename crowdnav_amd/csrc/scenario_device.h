@@ -101,7 +101,7 @@ __device__ __forceinline__ double norm2(double x, double y) { return sqrt(__buil
 
 struct ScenarioCfg {
     int num_agents;  // A
-    int rule;        // 0 circle_crossing, 1 square_crossing
+    int rule;        // 0 circle_crossing, 1 square_crossing, 2 mixed
     int randomize;
     double circle_radius, square_width, discomfort_dist;
     double human_radius, human_v_pref, robot_radius, robot_v_pref;
@@ -110,6 +110,13 @@ struct ScenarioCfg {
     unsigned long long max_attempts;
     int* error;
 };
+
+// `mixed` (crowd_sim.py:103-151) draws the number of humans per episode (static obstacles 0..5, or 1..5 moving
+// humans).  The engine keeps a fixed A agents per env: humans beyond the drawn count are PARKED — at rest, goal =
+// position, far outside every neighbour range (10 m) and 100 m apart from each other — so no kernel needs a mask; they
+// never interact with anything.  cn_get_human_count reports how many are present.
+constexpr double kParkedX = 1.0e6;
+__device__ __forceinline__ bool is_parked(double2 p) { return p.x >= 0.5 * kParkedX; }
 
 // Writes agents [0, A) of one env into the SoA state (double2 planes indexed base + agent; vel may be NULL:
 // every agent starts at rest) and returns the number of np.random.random() calls consumed.
@@ -125,48 +132,46 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Rng& rng, uin
     goal[base] = make_double2(0.0, R);
     if (vel) vel[base] = make_double2(0.0, 0.0);
     rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
+
+    // mixed: how many humans, and are they static obstacles? (crowd_sim.py:103-115)
+    int present = A - 1;
+    bool obstacles = false, dummy = false;
+    if (c.rule == 2) {
+        obstacles = rng.random() < 0.2;
+        double prob = rng.random();
+        draws += 2;
+        const double p_static[6] = {0.05, 0.2, 0.2, 0.3, 0.1, 0.15};  // human_num 0..5
+        const double p_dynamic[5] = {0.3, 0.3, 0.2, 0.1, 0.1};        // human_num 1..5
+        const int keys = obstacles ? 6 : 5;
+        for (int k = 0; k < keys; ++k) {  // sorted(dict.items()); no key selected (rounding) keeps the configured count
+            const double value = obstacles ? p_static[k] : p_dynamic[k];
+            if (prob - value <= 0) {
+                present = obstacles ? k : k + 1;
+                break;
+            }
+            prob -= value;
+        }
+        if (present > A - 1) present = A - 1;
+        dummy = obstacles && present == 0;  // one placeholder human at (0, -10) (:121-124)
+    }
+
     for (int i = 1; i < A; ++i) {
         double radius = c.human_radius, v_pref = c.human_v_pref;
-        if (c.randomize) {
-            v_pref = rng.uniform(0.5, 1.5);
-            radius = rng.uniform(0.3, 0.5);
-            draws += 2;
-        }
         double x, y, tx, ty;
         unsigned long long attempts = 0;
-        if (c.rule == 0) {
-            for (;;) {
-                const double angle = rng.random() * kPi * 2;
-                const double nx = (rng.random() - 0.5) * v_pref;
-                const double ny = (rng.random() - 0.5) * v_pref;
-                draws += 3;
-                x = R * cos(angle) + nx;
-                y = R * sin(angle) + ny;
-                bool collide = false;
-                for (int k = 0; k < i; ++k) {
-                    const double2 p = pos[base + k], g = goal[base + k];
-                    const double min_dist = radius + rv[base + k].x + c.discomfort_dist;
-                    if (norm2(x - p.x, y - p.y) < min_dist || norm2(x - g.x, y - g.y) < min_dist) {
-                        collide = true;
-                        break;
-                    }
-                }
-                if (!collide) break;
-                if (rng.dead()) return draws;
-                if (++attempts >= c.max_attempts) {
-                    *c.error = 1;
-                    break;
-                }
-            }
-            tx = -x;
-            ty = -y;
-        } else {
-            const double w = c.square_width;
+        // 0 circle crossing, 1 square crossing, 2 static obstacle, 3 fixed placement (placeholder / parked)
+        int kind = c.rule;
+        if (c.rule == 2) kind = (i > present) ? 3 : (obstacles ? 2 : (i <= 2 ? 0 : 1));
+        if (kind == 3) {
+            const bool placeholder = dummy && i == 1;
+            x = tx = placeholder ? 0.0 : kParkedX + 100.0 * i;
+            y = ty = placeholder ? -10.0 : kParkedX;
+        } else if (kind == 2) {  // crowd_sim.py:125-141: a square of width 4, height 8; goal = position
             const double sign = (rng.random() > 0.5) ? -1.0 : 1.0;
             draws += 1;
             for (;;) {
-                x = rng.random() * w * 0.5 * sign;
-                y = (rng.random() - 0.5) * w;
+                x = rng.random() * 4 * 0.5 * sign;
+                y = (rng.random() - 0.5) * 8;
                 draws += 2;
                 bool collide = false;
                 for (int k = 0; k < i; ++k) {
@@ -183,23 +188,81 @@ __device__ inline uint64_t generate_scenario(const ScenarioCfg& c, Rng& rng, uin
                     break;
                 }
             }
-            for (;;) {
-                tx = rng.random() * w * 0.5 * -sign;
-                ty = (rng.random() - 0.5) * w;
+            tx = x;
+            ty = y;
+        } else {
+            if (c.randomize) {  // sample_random_attributes (agent.py:39-45), inside generate_*_crossing_human
+                v_pref = rng.uniform(0.5, 1.5);
+                radius = rng.uniform(0.3, 0.5);
                 draws += 2;
-                bool collide = false;
-                for (int k = 0; k < i; ++k) {
-                    const double2 g = goal[base + k];
-                    if (norm2(tx - g.x, ty - g.y) < radius + rv[base + k].x + c.discomfort_dist) {
-                        collide = true;
+            }
+            if (kind == 0) {
+                for (;;) {
+                    const double angle = rng.random() * kPi * 2;
+                    const double nx = (rng.random() - 0.5) * v_pref;
+                    const double ny = (rng.random() - 0.5) * v_pref;
+                    draws += 3;
+                    x = R * cos(angle) + nx;
+                    y = R * sin(angle) + ny;
+                    bool collide = false;
+                    for (int k = 0; k < i; ++k) {
+                        const double2 p = pos[base + k], g = goal[base + k];
+                        const double min_dist = radius + rv[base + k].x + c.discomfort_dist;
+                        if (norm2(x - p.x, y - p.y) < min_dist || norm2(x - g.x, y - g.y) < min_dist) {
+                            collide = true;
+                            break;
+                        }
+                    }
+                    if (!collide) break;
+                    if (rng.dead()) return draws;
+                    if (++attempts >= c.max_attempts) {
+                        *c.error = 1;
                         break;
                     }
                 }
-                if (!collide) break;
-                if (rng.dead()) return draws;
-                if (++attempts >= c.max_attempts) {
-                    *c.error = 1;
-                    break;
+                tx = -x;
+                ty = -y;
+            } else {
+                const double w = c.square_width;
+                const double sign = (rng.random() > 0.5) ? -1.0 : 1.0;
+                draws += 1;
+                for (;;) {
+                    x = rng.random() * w * 0.5 * sign;
+                    y = (rng.random() - 0.5) * w;
+                    draws += 2;
+                    bool collide = false;
+                    for (int k = 0; k < i; ++k) {
+                        const double2 p = pos[base + k];
+                        if (norm2(x - p.x, y - p.y) < radius + rv[base + k].x + c.discomfort_dist) {
+                            collide = true;
+                            break;
+                        }
+                    }
+                    if (!collide) break;
+                    if (rng.dead()) return draws;
+                    if (++attempts >= c.max_attempts) {
+                        *c.error = 1;
+                        break;
+                    }
+                }
+                for (;;) {
+                    tx = rng.random() * w * 0.5 * -sign;
+                    ty = (rng.random() - 0.5) * w;
+                    draws += 2;
+                    bool collide = false;
+                    for (int k = 0; k < i; ++k) {
+                        const double2 g = goal[base + k];
+                        if (norm2(tx - g.x, ty - g.y) < radius + rv[base + k].x + c.discomfort_dist) {
+                            collide = true;
+                            break;
+                        }
+                    }
+                    if (!collide) break;
+                    if (rng.dead()) return draws;
+                    if (++attempts >= c.max_attempts) {
+                        *c.error = 1;
+                        break;
+                    }
                 }
             }
         }

@@ -108,6 +108,12 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_get_theta(self._h, _ptr(t)))
         return t
 
+    def human_count(self):
+        """len(env.humans) per env, [B] int32 (differs from num_humans only under the `mixed` rule)."""
+        n = self._new((self.B,), torch.int32)
+        check(self._lib.cn_get_human_count(self._h, _ptr(n)))
+        return n
+
     def drop_robot_sim(self):
         check(self._lib.cn_drop_robot_sim(self._h))
 

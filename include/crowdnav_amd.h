@@ -44,7 +44,7 @@ enum { CN_ROBOT_EXTERNAL = 0, CN_ROBOT_ORCA = 1 };
 /* robot_kinematics */
 enum { CN_HOLONOMIC = 0, CN_UNICYCLE = 1 };
 /* scenario_rule (crowd_sim.py:84-153) */
-enum { CN_CIRCLE_CROSSING = 0, CN_SQUARE_CROSSING = 1 };
+enum { CN_CIRCLE_CROSSING = 0, CN_SQUARE_CROSSING = 1, CN_MIXED = 2 };
 
 /* Everything CrowdSim.configure (crowd_sim.py:51-79), the [humans]/[robot] sections read by Agent.__init__
  * (crowd_sim/envs/utils/agent.py:10-31) and the hard-coded ORCA parameters (orca.py:60-66) provide. */
@@ -102,6 +102,11 @@ int cn_get_state(cn_engine* e, double* state8, double* global_time);
 /* robot heading theta, double [B] (FullState.theta; reset sets pi/2, crowd_sim.py:274; only a unicycle robot changes it) */
 int cn_set_theta(cn_engine* e, const double* theta);
 int cn_get_theta(cn_engine* e, double* theta);
+/* len(env.humans) of every env, int32 [B].  Only the `mixed` rule (crowd_sim.py:103-151) draws the number of humans
+ * per episode (0..5 static obstacles — 0 leaves the reference's single placeholder human at (0, -10) — or 1..5 moving
+ * humans: two circle-crossing, the rest square-crossing).  The engine keeps num_humans slots per env; absent humans are
+ * parked at rest at x >= 1e6, out of every neighbour range, and sit AFTER the present ones in cn_get_state / obs. */
+int cn_get_human_count(cn_engine* e, int32_t* count);
 /* forget the robot ORCA policy's captured radii (a new policy object; orca.py:95-104) */
 int cn_drop_robot_sim(cn_engine* e);
 

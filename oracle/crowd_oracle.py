@@ -127,6 +127,10 @@ class CrowdOracle(object):
         lib().co_get_state(self._h, *[_p(c) for c in cols], _p(gt))
         return np.stack(cols, axis=2), gt
 
+    def human_count(self):
+        """len(env.humans) per env: humans the `mixed` rule left out are parked at x >= 1e6 behind the present ones."""
+        return (self.get_state()[0][:, 1:, 0] < 5.0e5).sum(axis=1).astype(np.int32)
+
     def set_theta(self, theta):
         t = np.ascontiguousarray(theta, dtype=np.float64).reshape(self.B)
         lib().co_set_theta(self._h, _p(t))

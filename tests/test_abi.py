@@ -87,8 +87,10 @@ def test_create_rejects_bad_configs_before_touching_the_device(built):
     assert rc == built.CN_ERR_UNSUPPORTED and 'max_neighbors' in msg
     rc, msg = create(time_step=0.0)
     assert rc == built.CN_ERR_INVALID and 'time_step' in msg
-    rc, msg = create(scenario_rule=2)
+    rc, msg = create(scenario_rule=3)
     assert rc == built.CN_ERR_UNSUPPORTED and 'scenario_rule' in msg
+    rc, msg = create(scenario_rule=2, num_humans=4)  # mixed draws up to 5 humans per episode
+    assert rc == built.CN_ERR_UNSUPPORTED and 'mixed' in msg
     rc, msg = create(robot_policy=7)
     assert rc == built.CN_ERR_INVALID
     assert lib.cn_create(None, None) == built.CN_ERR_INVALID

@@ -36,8 +36,10 @@ def test_types_and_config_cpu():
     assert str(c.ReachGoal()) == 'Reaching goal' and str(c.Nothing()) == '' and c.Danger(0.1).min_dist == 0.1
     cfg = env.engine_config(7, 5, 'square_crossing', 1)
     assert cfg['num_envs'] == 7 and cfg['scenario_rule'] == 1 and cfg['robot_visible'] == 0
+    mixed = env.engine_config(3, 2, 'mixed', 1)  # the rule draws its own number of humans: 5 slots whatever was asked
+    assert mixed['scenario_rule'] == 2 and mixed['num_humans'] == 5
     with pytest.raises(NotImplementedError):
-        env.engine_config(1, 5, 'mixed', 1)
+        env.engine_config(1, 5, 'trajnet', 1)
     with pytest.raises(AttributeError):
         c.CrowdSim().reset('test')
 
