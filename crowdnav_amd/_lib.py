@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CROWDNAV_AMD_LIB: another build of the same library (kernel A/B experiments, scripts/gpu_ab.sh); default in-tree
 LIB_PATH = os.environ.get('CROWDNAV_AMD_LIB') or os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
@@ -66,7 +66,7 @@ class CnSarlConfig(C.Structure):
         ('n_actions', C.c_int32), ('with_om', C.c_int32), ('cell_num', C.c_int32), ('om_channel_size', C.c_int32),
         ('cell_size', C.c_double), ('gamma', C.c_double), ('with_global_state', C.c_int32),
         ('mlp1_dims', C.c_int32 * 2), ('mlp2_dims', C.c_int32 * 2), ('attention_dims', C.c_int32 * 3),
-        ('mlp3_dims', C.c_int32 * 4), ('model', C.c_int32),
+        ('mlp3_dims', C.c_int32 * 4), ('model', C.c_int32), ('interaction_dims', C.c_int32 * 4),
     ]
 
 

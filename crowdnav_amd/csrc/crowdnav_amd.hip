@@ -125,7 +125,7 @@ inline int grid_lanes(const cn_engine* e) { return (e->P.B + cn::kWave - 1) / cn
 extern "C" {
 
 const char* cn_last_error(void) { return g_err; }
-int cn_abi_version(void) { return 2; }
+int cn_abi_version(void) { return 3; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
     if (!c || !out) return fail(CN_ERR_INVALID, "cn_create: NULL argument");

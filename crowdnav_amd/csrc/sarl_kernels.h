@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, co
     }
 }
 
-// lstm_rl.ValueNetwork1 (lstm_rl.py:9-33): an LSTM over the humans of a group (in the order the lookahead returns
+// lstm_rl.ValueNetwork1 / ValueNetwork2 (lstm_rl.py:9-66): an LSTM over the humans of a group (in the order the lookahead returns
 // them), its final hidden state joined with the robot's 6 self features into the value head.  Layers: L[kL_mlp1_0] =
 // weight_ih / bias_ih, L[kL_mlp1_2] = weight_hh / bias_hh (torch gate order i, f, g, o), L[kL_mlp3_*] = the head.
 // Row tile t of X is human t of the 16 groups = LSTM time step t, so each step is a 16-row product.
@@ -590,7 +590,9 @@ __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, con
     const int hid = net.L[kL_mlp1_2].K;                   // hidden width (50)
     const int ks_h = (hid + 15) / 16 * 4, ks_g = net.L[kL_mlp1_0].ctiles * 4;
     float* xs = lds;                                       // [H][ks_x][64]
-    float* gates = xs + H * net.ks_x * 64;                 // [ks_g][64]   i | f | g | o pre-activations
+    float* pbuf = xs + H * net.ks_x * 64;                  // [H][ks_b][64] ValueNetwork2.mlp1 ping (ks_b = 0 otherwise)
+    float* qbuf = pbuf + H * net.ks_b * 64;                // [H][ks_c][64] ... pong: the LSTM input when pairwise
+    float* gates = qbuf + H * net.ks_c * 64;               // [ks_g][64]   i | f | g | o pre-activations
     float* hbuf = gates + ks_g * 64;                       // [ks_h][64]   hidden state (A operand of the next step)
     float* cbuf = hbuf + ks_h * 64;                        // [hid][16]    cell state
     float* jbuf = cbuf + hid * kSarlGroups;                // [ks_a][64]
@@ -608,8 +610,24 @@ __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, con
         const int g = tid & 15, n = tid >> 4;
         jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];  // self_state = state[:, 0, :6]
     }
+    // lstm_rl.ValueNetwork2 (lstm_rl.py:36-66): mlp1 on every human's row first (ReLU between its 4 layers, none after)
+    const bool pairwise = net.L[kL_mlp2_0].w != nullptr;
+    const float* lstm_in = xs;
+    int ks_in = net.ks_x;
+    if (pairwise) {
+        dense_mfma<H>(net.L[kL_mlp2_0], xs, net.ks_x, pbuf, net.ks_b, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<H>(net.L[kL_mlp2_2], pbuf, net.ks_b, qbuf, net.ks_c, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<H>(net.L[kL_att_2], qbuf, net.ks_c, pbuf, net.ks_b, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<H>(net.L[kL_att_4], pbuf, net.ks_b, qbuf, net.ks_c, false, nullptr, wave, lane);
+        __syncthreads();
+        lstm_in = qbuf;
+        ks_in = net.ks_c;
+    }
     for (int t = 0; t < H; ++t) {
-        dense_mfma<1>(net.L[kL_mlp1_0], xs + t * net.ks_x * 64, net.ks_x, gates, ks_g, false, nullptr, wave, lane);
+        dense_mfma<1>(net.L[kL_mlp1_0], lstm_in + t * ks_in * 64, ks_in, gates, ks_g, false, nullptr, wave, lane);
         __syncthreads();
         dense_mfma<1>(net.L[kL_mlp1_2], hbuf, ks_h, gates, ks_g, false, gates, wave, lane);  // + (W_hh h + b_hh)
         __syncthreads();

@@ -211,14 +211,16 @@ SARL_PARAM_ORDER = tuple('%s.%d.%s' % (m, i, p) for m, idxs in (('mlp1', (0, 2))
 
 LSTM_PARAM_ORDER = tuple('mlp.%d.%s' % (i, p) for i in (0, 2, 4, 6) for p in ('weight', 'bias')) + (
     'lstm.weight_ih_l0', 'lstm.weight_hh_l0', 'lstm.bias_ih_l0', 'lstm.bias_hh_l0')
+LSTM_PAIRWISE_MLP1_ORDER = tuple('mlp1.%d.%s' % (i, p) for i in (0, 2, 4, 6) for p in ('weight', 'bias'))
 CADRL_PARAM_ORDER = tuple('value_network.%d.%s' % (i, p) for i in (0, 2, 4, 6) for p in ('weight', 'bias'))
 
 
 def _sarl_configure(self, actions, gamma=0.9, with_om=False, cell_num=4, cell_size=1.0, om_channel_size=3,
                     with_global_state=True, mlp1_dims=(150, 100), mlp2_dims=(100, 50), attention_dims=(100, 100, 1),
-                    mlp3_dims=(150, 100, 100, 1), model='sarl'):
+                    mlp3_dims=(150, 100, 100, 1), model='sarl', interaction_dims=None):
     """SARL.configure (or model='cadrl': mlp3_dims = [cadrl] mlp_dims; model='lstm_rl': mlp1_dims[0] = hidden width,
-    mlp3_dims = [lstm_rl] mlp2_dims) + build_action_space for
+    mlp3_dims = [lstm_rl] mlp2_dims, interaction_dims = [lstm_rl] mlp1_dims when with_interaction_module) +
+    build_action_space for
     this engine.  actions: [K, 2] float64 ActionXY table (host)."""
     acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(-1, 2))
     cfg = _lib.CnSarlConfig(n_actions=len(acts), with_om=int(bool(with_om)), cell_num=int(cell_num),
@@ -226,15 +228,18 @@ def _sarl_configure(self, actions, gamma=0.9, with_om=False, cell_num=4, cell_si
                             with_global_state=int(bool(with_global_state)),
                             mlp1_dims=(C.c_int32 * 2)(*mlp1_dims), mlp2_dims=(C.c_int32 * 2)(*mlp2_dims),
                             attention_dims=(C.c_int32 * 3)(*attention_dims), mlp3_dims=(C.c_int32 * 4)(*mlp3_dims),
-                            model={'sarl': 0, 'cadrl': 1, 'lstm_rl': 2}[model])
+                            model={'sarl': 0, 'cadrl': 1, 'lstm_rl': 2}[model],
+                            interaction_dims=(C.c_int32 * 4)(*(interaction_dims or (0, 0, 0, 0))))
     check(self._lib.cn_sarl_configure(self._h, C.byref(cfg), acts.ctypes.data_as(C.c_void_p)))
     self.sarl = dict(n_actions=len(acts), in_dim=13 + (cell_num ** 2 * om_channel_size if with_om else 0),
-                     actions=acts, model=model)
+                     actions=acts, model=model, pairwise=bool(interaction_dims))
 
 
 def _sarl_set_weights(self, state_dict):
     """Hand the value network's parameters (sarl.ValueNetwork.state_dict()) to the device kernels."""
     order = {'cadrl': CADRL_PARAM_ORDER, 'lstm_rl': LSTM_PARAM_ORDER}.get(self.sarl['model'], SARL_PARAM_ORDER)
+    if self.sarl.get('pairwise'):  # lstm_rl.ValueNetwork2: mlp1 first, as in its state_dict
+        order = LSTM_PAIRWISE_MLP1_ORDER + order
     tensors = [state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in order]
     ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     check(self._lib.cn_sarl_set_weights(self._h, ptrs))

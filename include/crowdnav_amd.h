@@ -184,7 +184,11 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
  *   CN_MODEL_LSTM_RL lstm_rl.ValueNetwork1 (LSTM over the humans + value head, lstm_rl.py:9-33; the variant the shipped
  *                   policy.config selects, with_interaction_module = false): mlp1_dims[0] = [lstm_rl] global_state_dim,
  *                   mlp3_dims = [lstm_rl] mlp2_dims, with_om as configured; cn_sarl_set_weights takes 12 pointers
- *                   (mlp.{0,2,4,6}.{weight,bias}, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0) */
+ *                   (mlp.{0,2,4,6}.{weight,bias}, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0).
+ *                   interaction_dims[0] > 0 selects lstm_rl.ValueNetwork2 (with_interaction_module = true,
+ *                   lstm_rl.py:36-66): every human's input row first passes mlp1 = [lstm_rl] mlp1_dims (4 layers, ReLU
+ *                   between them) and the LSTM runs over mlp1's outputs; cn_sarl_set_weights then takes 20 pointers:
+ *                   mlp1.{0,2,4,6}.{weight,bias} followed by the 12 above (the module's state_dict order) */
 enum { CN_MODEL_SARL = 0, CN_MODEL_CADRL = 1, CN_MODEL_LSTM_RL = 2 };
 
 typedef struct cn_sarl_config {
@@ -200,6 +204,8 @@ typedef struct cn_sarl_config {
     int32_t attention_dims[3];  /* [sarl] attention_dims (100, 100, 1) */
     int32_t mlp3_dims[4];       /* [sarl] mlp3_dims      (150, 100, 100, 1); CN_MODEL_CADRL: [cadrl] mlp_dims */
     int32_t model;              /* CN_MODEL_SARL (0), CN_MODEL_CADRL (1) or CN_MODEL_LSTM_RL (2) */
+    int32_t interaction_dims[4];/* CN_MODEL_LSTM_RL only: [lstm_rl] mlp1_dims (150, 100, 100, 50) when
+                                   with_interaction_module, else all 0 */
 } cn_sarl_config;
 
 /* replaces SARL.configure + CADRL.build_action_space: actions_host = double [n_actions][2] (ActionXY table, HOST

@@ -25,13 +25,13 @@ OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 INFO = {'Nothing': 0, 'Danger': 1, 'ReachGoal': 2, 'Collision': 3, 'Timeout': 4}
 
 
-def generate(name, with_om, robot_visible, k, epsilon, first_case=0, policy_name='sarl'):
+def generate(name, with_om, robot_visible, k, epsilon, first_case=0, policy_name='sarl', extra=None):
     rh.activate()
     from crowd_nav.utils.explorer import Explorer
     from crowd_nav.utils.memory import ReplayMemory
     torch.manual_seed(0)
     pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
-                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false'})
+                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false', **(extra or {})})
     env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
     device = torch.device('cpu')
     policy.set_device(device)
@@ -76,6 +76,7 @@ def generate(name, with_om, robot_visible, k, epsilon, first_case=0, policy_name
                ep_time=np.array(ep_time), epsilon=np.array(epsilon), k=np.array(k), first_case=np.array(first_case),
                with_om=np.array(int(with_om)), robot_visible=np.array(int(robot_visible)),
                gamma=np.array(policy.gamma), policy=np.array(policy_name),
+               pairwise=np.array(int(bool(extra))),
                action_space=np.array([list(a) for a in policy.action_space], dtype=np.float64))
     for key, v in model.state_dict().items():
         out['param_' + key] = v.numpy()
@@ -86,7 +87,7 @@ def generate(name, with_om, robot_visible, k, epsilon, first_case=0, policy_name
 
 if __name__ == '__main__':
     assert rh.available()
-    which = sys.argv[1:] or ['sarl', 'cadrl', 'lstm_rl']
+    which = sys.argv[1:] or ['sarl', 'cadrl', 'lstm_rl', 'lstm_rl2']
     if 'sarl' in which:
         generate('rl_sarl_plain.npz', with_om=False, robot_visible=False, k=12, epsilon=0.5)
         generate('rl_sarl_om.npz', with_om=True, robot_visible=True, k=8, epsilon=0.3, first_case=100)
@@ -95,3 +96,6 @@ if __name__ == '__main__':
     if 'lstm_rl' in which:  # replay states hold the humans by decreasing distance (lstm_rl.py:96-103)
         generate('rl_lstm_rl.npz', with_om=False, robot_visible=True, k=8, epsilon=0.3, first_case=300, policy_name='lstm_rl')
         generate('rl_lstm_rl_om.npz', with_om=True, robot_visible=False, k=6, epsilon=0.5, first_case=400, policy_name='lstm_rl')
+    if 'lstm_rl2' in which:  # lstm_rl.ValueNetwork2 (with_interaction_module = true)
+        generate('rl_lstm_rl2.npz', with_om=False, robot_visible=True, k=6, epsilon=0.3, first_case=500, policy_name='lstm_rl',
+                 extra={('lstm_rl', 'with_interaction_module'): 'true'})

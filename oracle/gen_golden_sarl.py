@@ -25,12 +25,12 @@ def snapshot(env):
     return np.array([[a.px, a.py, a.vx, a.vy, a.gx, a.gy, a.radius, a.v_pref] for a in [env.robot] + env.humans])
 
 
-def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl', kinematics='holonomic'):
+def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl', kinematics='holonomic', extra=None):
     rh.activate()
     torch.manual_seed(0)
     pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
                                             ('lstm_rl', 'with_om'): 'true' if with_om else 'false',
-                                            ('action_space', 'kinematics'): kinematics})
+                                            ('action_space', 'kinematics'): kinematics, **(extra or {})})
     env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
     policy.set_device(torch.device('cpu'))
     policy.set_phase('test')
@@ -104,3 +104,5 @@ if __name__ == '__main__':
     generate('cadrl_plain.npz', with_om=False, robot_visible=True, cases=[6, 7], max_steps=8, policy_name='cadrl')
     generate('lstm_rl_om.npz', with_om=True, robot_visible=True, cases=[8, 9], max_steps=8, policy_name='lstm_rl')
     generate('sarl_unicycle.npz', with_om=False, robot_visible=True, cases=[10, 11, 12], max_steps=10, kinematics='unicycle')
+    generate('lstm_rl2_om.npz', with_om=True, robot_visible=True, cases=[13, 14], max_steps=8, policy_name='lstm_rl',
+             extra={('lstm_rl', 'with_interaction_module'): 'true'})  # lstm_rl.ValueNetwork2

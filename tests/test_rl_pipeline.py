@@ -7,7 +7,8 @@ import torch
 
 from conftest import load_golden
 
-RL_FIXTURES = ['rl_sarl_plain.npz', 'rl_sarl_om.npz', 'rl_cadrl.npz', 'rl_lstm_rl.npz', 'rl_lstm_rl_om.npz']
+RL_FIXTURES = ['rl_sarl_plain.npz', 'rl_sarl_om.npz', 'rl_cadrl.npz', 'rl_lstm_rl.npz', 'rl_lstm_rl_om.npz',
+               'rl_lstm_rl2.npz']
 
 
 # ------------------------------------------------------------------------------------------------ CPU
@@ -78,8 +79,10 @@ def _setup(g):
     env.configure(cfg)
     robot = c.Robot(cfg, 'robot')
     policy = c.policy_factory[name]()
-    policy.configure(default_policy_config({(name, 'with_om'): 'true' if with_om else 'false'} if name != 'cadrl'
-                                           else None))
+    overrides = {(name, 'with_om'): 'true' if with_om else 'false'} if name != 'cadrl' else {}
+    if 'pairwise' in g and int(g['pairwise']):
+        overrides[('lstm_rl', 'with_interaction_module')] = 'true'
+    policy.configure(default_policy_config(overrides))
     policy.get_model().load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items()
                                         if k.startswith('param_')})
     robot.set_policy(policy)

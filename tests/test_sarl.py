@@ -363,6 +363,49 @@ def test_lstm_rl_select_vs_reference():
     assert clear.sum() >= n // 4 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
 
 
+def _lstm2_mirror(g):
+    from crowdnav_amd.compat.lstm_rl import ValueNetwork2
+    in_dim = 13 + (48 if int(g['with_om']) else 0)
+    net = ValueNetwork2(in_dim, 6, [150, 100, 100, 50], [150, 100, 100, 1], 50)
+    net.load_state_dict({k[len('param_'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param_')})
+    return net
+
+
+def test_lstm_rl_pairwise_value_network_mirror_cpu():
+    """lstm_rl.ValueNetwork2 (with_interaction_module = true): the torch mirror reproduces the reference's outputs."""
+    g = load_golden('lstm_rl2_om.npz')
+    net = _lstm2_mirror(g)
+    x = torch.from_numpy(g['inputs'])
+    d, k, h, f = x.shape
+    with torch.no_grad():
+        out = net(x.reshape(d * k, h, f)).reshape(d, k).numpy()
+    assert np.abs(out - g['net_out']).max() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_lstm_rl_pairwise_select_vs_reference():
+    """LSTM-RL with the pairwise interaction module (ValueNetwork2: mlp1 per human in front of the LSTM) on the device
+    pipeline vs the unmodified reference's LstmRL.predict."""
+    import crowdnav_amd
+    g = load_golden('lstm_rl2_om.npz')
+    n = len(g['states'])
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.set_state(g['states'], g['gtime'])
+    eng.sarl_configure(actions=g['action_space'], gamma=0.9, model='lstm_rl', with_om=True, mlp1_dims=(50, 1),
+                       mlp3_dims=(150, 100, 100, 1), interaction_dims=(150, 100, 100, 50))
+    eng.sarl_set_weights(_lstm2_mirror(g).state_dict())
+    out = eng.sarl_select()
+    eng.sync()
+    cpu = lambda t: t.cpu().numpy()  # noqa: E731
+    assert np.array_equal(cpu(eng.sarl_export('reward')), g['rewards'])
+    assert np.abs(cpu(eng.sarl_export('X')) - g['inputs']).max() <= 5e-6
+    assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
+    assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
+    top2 = np.sort(g['values'], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 4e-6
+    assert clear.sum() >= n // 4 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
+
+
 @pytest.mark.gpu
 def test_sarl_unicycle_select_vs_reference():
     """SARL with [action_space] kinematics = unicycle (ActionRot table, propagate / rotate with the heading feature,
