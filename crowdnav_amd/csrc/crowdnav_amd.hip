@@ -556,4 +556,12 @@ extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
     }
     return 0;
 }
+extern "C" int cn_debug_sarl_cycles(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cn::cn_sarl_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_sarl_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif

@@ -31,10 +31,40 @@
 
 namespace cn {
 
+// CN_PHASE_TIMING (profiling builds only): per-layer shader-clock ticks of sarl_mlp_kernel as wave 0 sees them
+// (barrier to barrier), summed over tiles into cn_sarl_cycles[k]; [15] = tiles.  scripts/sarl_phase_probe.py
+#ifdef CN_PHASE_TIMING
+__device__ unsigned long long cn_sarl_cycles[16];
+#define CN_SARL_CLOCK_BEGIN() unsigned long long sclk_last_ = __builtin_readcyclecounter(), sclk_acc_[15] = {}
+#define CN_SARL_TICK(k)                                                  \
+    do {                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter();    \
+        sclk_acc_[k] += now_ - sclk_last_;                               \
+        sclk_last_ = now_;                                               \
+    } while (0)
+#define CN_SARL_CLOCK_END()                                                              \
+    do {                                                                                 \
+        if (threadIdx.x == 0) {                                                          \
+            for (int k_ = 0; k_ < 15; ++k_) atomicAdd(&cn_sarl_cycles[k_], sclk_acc_[k_]); \
+            atomicAdd(&cn_sarl_cycles[15], 1ull);                                        \
+        }                                                                                \
+    } while (0)
+#else
+#define CN_SARL_CLOCK_BEGIN() \
+    do {                      \
+    } while (0)
+#define CN_SARL_TICK(k) \
+    do {                \
+    } while (0)
+#define CN_SARL_CLOCK_END() \
+    do {                    \
+    } while (0)
+#endif
+
 constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
 constexpr int kSarlMaxHumans = 8;    // LDS budget of the fused MLP kernel (H = 5 in every BASELINE config)
 constexpr int kSarlThreads = 1024;   // 8 waves per MLP workgroup (2 per SIMD: one wave's LDS/L2 waits hide behind the other's MFMAs)
-constexpr int kSarlKChunk = 4;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time)
+constexpr int kSarlKChunk = 5;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time): K = 100 is 25 k-steps
 constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -50,6 +80,16 @@ struct PackedLinear {
     int kpad;       // ksteps rounded up to kSarlKChunk (zero fragments): the B prefetch never runs off the end
     int ctiles;     // ceil(N / 16)
 };
+
+// k-steps per row tile of an LDS activation buffer that holds n features: whole 16-column tiles of its producer, and
+// at least the consumer's k loop (ksteps rounded up to kSarlKChunk) so that the straight-line loop stays inside the row
+// tile.  The kernels zero their LDS once per tile: k-steps the producer never writes are finite (zero or stale
+// activations) and meet zero weights.
+__host__ __device__ inline int sarl_ks(int n) {
+    const int tiles = (n + 15) / 16 * 4;
+    const int kpad = ((n + 3) / 4 + kSarlKChunk - 1) / kSarlKChunk * kSarlKChunk;
+    return tiles > kpad ? tiles : kpad;
+}
 
 enum {
     kL_mlp1_0, kL_mlp1_2, kL_mlp2_0, kL_mlp2_2, kL_att0_local, kL_att0_global, kL_att_2, kL_att_4,
@@ -454,6 +494,37 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
 }
 
 // Whole sarl.ValueNetwork.forward for one tile of 16 groups x H humans; X in fragment order, V[group] out.
+// A layer with ONE output (attention.4, mlp3.6) as a dot product on the vector ALUs: as an MFMA it would occupy one
+// wave of one SIMD with 15 of 16 columns wasted (7 % of the tile time at 100 -> 1 over 5 row tiles).  Thread = (row,
+// k slice); partial sums meet in `scratch` (kSarlThreads floats).  Contains one workgroup barrier.
+template <int RT>
+__device__ __forceinline__ void dense_vec1(const PackedLinear& P, const float* in, int ks_in, float* out, int ks_out,
+                                           float* scratch, int tid) {
+    constexpr int kRows = RT * 16, kSlices = kSarlThreads / kRows;
+    const int row = tid % kRows, slice = tid / kRows;
+    if (slice < kSlices) {
+        const float* a = in + ((row >> 4) * ks_in) * 64 + (row & 15);
+        float sum = 0.0f;
+        for (int s = slice; s < P.ksteps; s += kSlices) {  // fragment (0, s): w[s * 64 + 16 j] = W[0][4 s + j]
+            const float* w = P.w + s * 64;
+            const float* x = a + s * 64;
+            sum += (x[0] * w[0] + x[16] * w[16]) + (x[32] * w[32] + x[48] * w[48]);
+        }
+        scratch[slice * kRows + row] = sum;
+    }
+    __syncthreads();
+    if (tid < kRows) {
+        float v = P.bias[0];
+#pragma unroll
+        for (int s = 0; s < kSlices; ++s) v += scratch[s * kRows + tid];
+        out[(tid >> 4) * ks_out * 64 + (tid & 15)] = v;
+    }
+}
+
+__device__ __forceinline__ void zero_lds(float* lds, size_t words, int tid) {
+    for (size_t i = tid; i < words; i += kSarlThreads) lds[i] = 0.0f;
+}
+
 template <int H>
 __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
     extern __shared__ float lds[];
@@ -464,9 +535,13 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
     float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]     joint state / mlp3 ping
     float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term / mlp3 pong
     float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights, final value
+    float* vbuf = sbuf + H * net.ks_s * 64;       // [kSarlThreads] partial sums of the single-output layers
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t tile = blockIdx.x;
+    CN_SARL_CLOCK_BEGIN();
+    zero_lds(lds, (size_t)(vbuf - lds), tid);
+    __syncthreads();
 
     // stage X: a straight coalesced copy (the feature kernel wrote fragment order); X is staged with ks_x k-steps
     float* xs = bufB;
@@ -475,6 +550,7 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
     // k padding of the joint-state buffer (features 6 + nf .. ks*4) must be finite zeros
     for (int i = tid; i < net.ks_a * 64; i += kSarlThreads) jbuf[i] = 0.0f;
     __syncthreads();
+    CN_SARL_TICK(0);
     // self_state = state[:, 0, :6] (sarl.py:36): features 0..5 of human 0's row of each group
     if (tid < kSarlGroups * 6) {
         const int g = tid & 15, n = tid >> 4;
@@ -483,8 +559,10 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
 
     dense_mfma<H>(net.L[kL_mlp1_0], xs, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
+    CN_SARL_TICK(1);
     dense_mfma<H>(net.L[kL_mlp1_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);  // h2
     __syncthreads();
+    CN_SARL_TICK(2);
     // global state: mean over the humans of a group (sarl.py:42) — elementwise over fragment offsets
     if (net.with_global) {
         for (int i = tid; i < net.ks_b * 64; i += kSarlThreads) {
@@ -496,18 +574,23 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
     }
     dense_mfma<H>(net.L[kL_mlp2_0], bufB, net.ks_b, bufA, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
+    CN_SARL_TICK(3);
     dense_mfma<H>(net.L[kL_mlp2_2], bufA, net.ks_a, bufC, net.ks_c, false, nullptr, wave, lane);  // features
     // attention layer 0 on [h2 | global]: the global half is the same for every human of a group, so it is
     // one 16-row product (kbuf) added to every row tile's accumulator at the matching group row
     if (net.with_global) dense_mfma<1>(net.L[kL_att0_global], gbuf, net.ks_b, kbuf, net.ks_a, false, nullptr, wave, lane);
     __syncthreads();
+    CN_SARL_TICK(4);
     dense_mfma<H>(net.L[kL_att0_local], bufB, net.ks_b, bufA, net.ks_a, true, net.with_global ? kbuf : nullptr, wave,
                   lane);
     __syncthreads();
+    CN_SARL_TICK(5);
     dense_mfma<H>(net.L[kL_att_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<H>(net.L[kL_att_4], bufB, net.ks_b, sbuf, net.ks_s, false, nullptr, wave, lane);  // score (h, g) at h*ks_s*64 + g
+    CN_SARL_TICK(6);
+    dense_vec1<H>(net.L[kL_att_4], bufB, net.ks_b, sbuf, net.ks_s, vbuf, tid);  // score (h, g) at h*ks_s*64 + g
     __syncthreads();
+    CN_SARL_TICK(7);
     // masked softmax without max subtraction (sarl.py:52-53)
     if (tid < kSarlGroups) {
         float e[H], total = 0.0f;
@@ -521,6 +604,7 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
         for (int h = 0; h < H; ++h) sbuf[h * net.ks_s * 64 + tid] = e[h] / total;
     }
     __syncthreads();
+    CN_SARL_TICK(8);
     // weighted feature sum (sarl.py:60) -> joint state features 6 ..
     const int nf = net.L[kL_mlp2_2].N;
     for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
@@ -533,18 +617,24 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
         jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = sum;
     }
     __syncthreads();
+    CN_SARL_TICK(9);
     dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
+    CN_SARL_TICK(10);
     dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
+    CN_SARL_TICK(11);
     dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
     __syncthreads();
-    dense_mfma<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
+    CN_SARL_TICK(12);
+    dense_vec1<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, vbuf, tid);
     __syncthreads();
+    CN_SARL_TICK(13);
     if (tid < kSarlGroups) {
         const size_t G = tile * kSarlGroups + tid;
         if (G < (size_t)n_groups) V[G] = sbuf[tid];
     }
+    CN_SARL_CLOCK_END();
 }
 
 // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row, then the minimum over the humans
@@ -557,6 +647,8 @@ __global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, co
     float* sbuf = bufB + H * net.ks_b * 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t tile = blockIdx.x;
+    zero_lds(lds, (size_t)H * (net.ks_a + net.ks_b + net.ks_s) * 64, tid);
+    __syncthreads();
     const float* xg = X + tile * H * net.ks_x * 64;
     for (int i = tid; i < H * net.ks_x * 64; i += kSarlThreads) bufB[i] = xg[i];
     __syncthreads();
@@ -588,7 +680,7 @@ template <int H>
 __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
     extern __shared__ float lds[];
     const int hid = net.L[kL_mlp1_2].K;                   // hidden width (50)
-    const int ks_h = (hid + 15) / 16 * 4, ks_g = net.L[kL_mlp1_0].ctiles * 4;
+    const int ks_h = sarl_ks(hid), ks_g = net.L[kL_mlp1_0].ctiles * 4;
     float* xs = lds;                                       // [H][ks_x][64]
     float* pbuf = xs + H * net.ks_x * 64;                  // [H][ks_b][64] ValueNetwork2.mlp1 ping (ks_b = 0 otherwise)
     float* qbuf = pbuf + H * net.ks_b * 64;                // [H][ks_c][64] ... pong: the LSTM input when pairwise
@@ -600,6 +692,8 @@ __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, con
     float* sbuf = kbuf + net.ks_a * 64;                    // [ks_s][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t tile = blockIdx.x;
+    zero_lds(lds, (size_t)((sbuf + net.ks_s * 64) - lds), tid);
+    __syncthreads();
     const float* xg = X + tile * H * net.ks_x * 64;
     for (int i = tid; i < H * net.ks_x * 64; i += kSarlThreads) xs[i] = xg[i];
     for (int i = tid; i < ks_h * 64; i += kSarlThreads) hbuf[i] = 0.0f;   // h0 = 0
@@ -665,7 +759,7 @@ __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, con
 
 __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
     const size_t H = (size_t)net.H;
-    return sizeof(float) * 64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a);
+    return sizeof(float) * (64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a) + kSarlThreads);
 }
 
 // ------------------------------------------------------------------------------------ action selection

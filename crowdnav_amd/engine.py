@@ -267,7 +267,8 @@ def _sarl_export(self, name):
     elif name == 'om':
         t, which = self._new((self.B, H, self.sarl['in_dim'] - 13), torch.float32), 3
     elif name == 'X':
-        ks = (self.sarl['in_dim'] + 15) // 16 * 4
+        d = self.sarl['in_dim']  # cn::sarl_ks: whole 16-column tiles, at least the k loop's 5-step chunks
+        ks = max((d + 15) // 16 * 4, ((d + 3) // 4 + 4) // 5 * 5)
         tiles = (self.B * K + 15) // 16
         t, which = self._new((tiles, H, ks, 4, 16), torch.float32), 4  # MFMA A-fragment order
     else:
