@@ -223,6 +223,119 @@ __device__ __forceinline__ void lp_planar_coop(const float4* lines, const int* c
     }
 }
 
+// ------------------------------------------------------------------ lane-cooperative 3-D fallback
+// linearProgram3 (Appendix A.6) for the agents whose planar program was infeasible, with one lane per (agent, half-plane)
+// like lp_planar_coop.  The per-agent serial version (lp_relaxed_lds) walks LDS with a dependent load per inner
+// iteration while the other 60-odd lanes of the wave wait for it: 18 % of a step at 5 humans, 52 % at 20
+// (profiles/r01_phase_probe.txt).  Here, per outer round, every agent advances to its next half-plane i whose
+// violation exceeds the running distance; lane j < i projects half-plane j onto i (one division, one rsqrt — all j at
+// once), and the planar program over the projected lines (directionOpt) runs in rounds exactly like lp_planar_coop:
+// first violated projected line k, lanes j < k contribute their bound on k, fold in line order.  Projected lines that
+// RVO2 skips (parallel, same direction) simply hold no line; order and every arithmetic operation are RVO2's.
+//   res [nA] in: (result.x, result.y, int bits: first infeasible line — >= count[a] = nothing to do), out: result
+template <int MAXL>
+__device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* count, const float4* sol, float4* res,
+                                                int nA) {
+    constexpr int G = kWave / MAXL;
+    constexpr unsigned kField = (1u << MAXL) - 1u;
+    const int wl = threadIdx.x & (kWave - 1);
+    const int g = wl / MAXL, l = wl - g * MAXL;
+    const int gbase = g * MAXL;
+    const int waves = (blockDim.x + kWave - 1) / kWave;
+    const float inf = __builtin_inff();
+    for (int chunk = threadIdx.x / kWave; chunk * G < nA; chunk += waves) {
+        const int a = chunk * G + g;
+        const bool live = g < G && a < nA;
+        const float4 r0 = res[live ? a : 0];
+        const int n = live ? count[a] : 0;
+        const int begin = __float_as_int(r0.z);
+        const bool need = live && begin < n;
+        if (__ballot(need) == 0ull) continue;
+        const float radius = sol[live ? a : 0].z;
+        const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float rx = r0.x, ry = r0.y, distance = 0.0f;
+        int icur = need ? begin : n;
+        while (true) {
+            const bool cond = l >= icur && l < n && (my.z * (my.y - ry) - my.w * (my.x - rx) > distance);
+            const unsigned long long m = __ballot(cond);
+            if (m == 0ull) break;
+            const unsigned gm = (unsigned)(m >> gbase) & kField;
+            const bool act = gm != 0u;
+            const int i = act ? __ffs(gm) - 1 : 0;
+            const float4 li = lines[(live ? a : 0) * kLineStride + i];
+            // this lane's half-plane projected onto half-plane i (meaningful for l < i)
+            const float d = li.z * my.w - li.w * my.z;
+            const bool par = fabsf(d) <= kRvoEps;
+            const bool same_dir = li.z * my.z + li.w * my.w > 0.0f;
+            const float t = (my.z * (li.y - my.y) - my.w * (li.x - my.x)) / d;
+            const float qx = par ? 0.5f * (li.x + my.x) : li.x + t * li.z;
+            const float qy = par ? 0.5f * (li.y + my.y) : li.y + t * li.w;
+            const float ex = my.z - li.z, ey = my.w - li.w;
+            const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
+            const float pz = ex * inv, pw = ey * inv;
+            const bool valid = act && l < i && !(par && same_dir);
+            // planar program over the projected lines, optimising along the normal of half-plane i
+            const float ox = -li.w, oy = li.z;
+            float r2x = ox * radius, r2y = oy * radius;
+            int cur2 = 0;
+            bool failed = false;
+            while (true) {
+                const bool viol = valid && l >= cur2 && (pz * (qy - r2y) - pw * (qx - r2x) > 0.0f);
+                const unsigned long long m2 = __ballot(viol);
+                if (m2 == 0ull) break;
+                const unsigned gm2 = (unsigned)(m2 >> gbase) & kField;
+                const bool act2 = gm2 != 0u;
+                const int k = act2 ? __ffs(gm2) - 1 : 0;
+                const float kx = __shfl(qx, gbase + k), ky = __shfl(qy, gbase + k);
+                const float kz = __shfl(pz, gbase + k), kw = __shfl(pw, gbase + k);
+                const float den = kz * pw - kw * pz;
+                const float num = pz * (ky - qy) - pw * (kx - qx);
+                const bool parallel = fabsf(den) <= kRvoEps;
+                const float tk = num / den;
+                const bool mine = act2 && valid && l < k;
+                const bool bad = mine && parallel && num < 0.0f;
+                const float c_hi = (mine && !parallel && den >= 0.0f) ? tk : inf;
+                const float c_lo = (mine && !parallel && !(den >= 0.0f)) ? tk : -inf;
+                const unsigned badm = (unsigned)(__ballot(bad) >> gbase) & kField;
+                const float dp = kx * kz + ky * kw;
+                const float disc = (dp * dp + radius * radius) - (kx * kx + ky * ky);
+                bool ok = !(disc < 0.0f) && badm == 0u;
+                const float root = sqrtf(disc);
+                float t_lo = -dp - root;
+                float t_hi = -dp + root;
+#pragma unroll
+                for (int j = 0; j < MAXL - 1; ++j) {
+                    const float hj = __shfl(c_hi, gbase + j);
+                    const float lj = __shfl(c_lo, gbase + j);
+                    t_hi = (hj < t_hi) ? hj : t_hi;
+                    t_lo = (t_lo < lj) ? lj : t_lo;
+                }
+                ok = ok && !(t_lo > t_hi);
+                const float tt = (ox * kz + oy * kw > 0.0f) ? t_hi : t_lo;
+                if (act2) {
+                    if (ok) {
+                        r2x = kx + tt * kz;
+                        r2y = ky + tt * kw;
+                        cur2 = k + 1;
+                    } else {  // the projected program is infeasible: keep the previous result (RVO2: result = tempResult)
+                        failed = true;
+                        cur2 = MAXL;
+                    }
+                }
+            }
+            if (act) {
+                if (!failed) {
+                    rx = r2x;
+                    ry = r2y;
+                }
+                distance = li.z * (li.y - ry) - li.w * (li.x - rx);
+                icur = i + 1;
+            }
+        }
+        if (need && l == 0) res[a] = make_float4(rx, ry, r0.z, 0.0f);
+    }
+}
+
 // ------------------------------------------------------------------ generic programs on LDS half-planes
 // (used by the infeasible fallback only; same arithmetic as the register versions)
 __device__ inline bool lp_on_line_lds(const float4* L, int k, float radius, float ox, float oy, bool dir_opt,

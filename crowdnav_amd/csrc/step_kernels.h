@@ -212,7 +212,7 @@ __device__ __forceinline__ void load_robot_view(const Params& P, const StateView
 #ifdef CN_PHASE_TIMING
 __device__ unsigned long long cn_phase_cycles[16];
 struct PhaseClock {
-    unsigned long long last, acc[9];
+    unsigned long long last, acc[10];
 };
 #define CN_TICK(clk, k)                                                \
     do {                                                               \
@@ -237,6 +237,16 @@ struct PhaseClock {};
 #ifndef CN_COOP_LP10
 #define CN_COOP_LP10 0
 #endif
+// CN_COOP_LP3_5 / CN_COOP_LP3_10 (compile time): the infeasible-program fallback with one lane per (agent, half-plane)
+// (lp_relaxed_coop) instead of a serial LDS walk on the agent's own lane (lp_relaxed_lds).  Measured
+// (profiles/r01_coop_lp_ab.txt): H = 20 +12 % (48.3 -> 54.1 M env-steps/s); H = 5 neutral at 4096 envs and -8 % at
+// 32 768 envs (127 -> 153 VGPRs costs a resident wave per SIMD), hence on for MAXL = 10 only.
+#ifndef CN_COOP_LP3_5
+#define CN_COOP_LP3_5 0
+#endif
+#ifndef CN_COOP_LP3_10
+#define CN_COOP_LP3_10 1
+#endif
 
 template <int MAXL>
 __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
@@ -244,6 +254,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                                             PhaseClock* clk = nullptr) {
     (void)clk;
     constexpr bool kCoop = (MAXL == 5) ? (CN_COOP_LP5 != 0) : (CN_COOP_LP10 != 0);
+    constexpr bool kCoop3 = (MAXL == 5) ? (CN_COOP_LP3_5 != 0) : (CN_COOP_LP3_10 != 0);
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
     auto preferred = [&](float& pref_x, float& pref_y) {
@@ -261,6 +272,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             float pref_x, pref_y;
             preferred(pref_x, pref_y);
             s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
+        } else if (kCoop3) {
+            s.sol[L.lane] = make_float4(0.0f, 0.0f, max_speed, solve ? 1.0f : 0.0f);
         }
     }
     __syncthreads();
@@ -319,19 +332,38 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 lp_relaxed_lds(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
             out_vx = rx, out_vy = ry;
         }
-    } else if (solve) {
-        const int n = s.count[L.lane];
+    } else {
+        float rx = 0.0f, ry = 0.0f;
+        int n = 0, fail = 0;
         const float4* mine = s.lines + L.lane * kLineStride;
-        float4 Lr[MAXL];
+        if (solve) {
+            n = s.count[L.lane];
+            float4 Lr[MAXL];
 #pragma unroll
-        for (int k = 0; k < MAXL; ++k) Lr[k] = (k < n) ? mine[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float pref_x, pref_y, rx, ry;
-        preferred(pref_x, pref_y);
-        const int fail = lp_planar_reg<MAXL>(Lr, n, max_speed, pref_x, pref_y, rx, ry);
-        if (fail < n) lp_relaxed_lds(mine, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
+            for (int k = 0; k < MAXL; ++k) Lr[k] = (k < n) ? mine[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float pref_x, pref_y;
+            preferred(pref_x, pref_y);
+            fail = lp_planar_reg<MAXL>(Lr, n, max_speed, pref_x, pref_y, rx, ry);
+        }
+        CN_TICK(clk, 3);
+        const bool need = solve && fail < n;
+        if (kCoop3) {
+            if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible
+                if (L.lane < P.nA) s.res[L.lane] = make_float4(rx, ry, __int_as_float(need ? fail : 0x7fffffff), 0.0f);
+                __syncthreads();
+                lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, P.nA);
+                __syncthreads();
+                if (need) {
+                    const float4 got = s.res[L.lane];
+                    rx = got.x, ry = got.y;
+                }
+            }
+        } else if (need) {
+            lp_relaxed_lds(mine, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
+        }
         out_vx = rx, out_vy = ry;
     }
-    CN_TICK(clk, 3);
+    CN_TICK(clk, 8);
 }
 
 struct StepResult {  // meaningful on the robot lane
@@ -839,8 +871,8 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
     }
 #ifdef CN_PHASE_TIMING
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        for (int k = 0; k < 8; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
-        atomicAdd(&cn_phase_cycles[8], 1ull);  // waves
+        for (int k = 0; k < 9; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
+        atomicAdd(&cn_phase_cycles[15], 1ull);  // waves
     }
 #endif
 

@@ -16,8 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import crowdnav_amd  # noqa: E402
 from crowdnav_amd import _lib  # noqa: E402
 
-NAMES = ['stage', 'pairs-1 (distances)', 'pairs-2 (rank + half-plane)', 'solve (LP)', 'robot action publish',
-         'collide (f64 swept distance)', 'reduce + integrate', 'episode bookkeeping / ring']
+NAMES = ['stage', 'pairs-1 (distances)', 'pairs-2 (rank + half-plane)', 'solve: 2-D program', 'robot action publish',
+         'collide (f64 swept distance)', 'reduce + integrate', 'episode bookkeeping / ring',
+         'solve: 3-D fallback (+ wait for it)']
 
 
 def main():
@@ -45,10 +46,10 @@ def main():
     dt = time.perf_counter() - t0
     out = (C.c_ulonglong * 16)()
     assert probe(out, 0) == 0
-    cyc = np.array(out[:8], dtype=np.float64)
+    cyc = np.array(out[:9], dtype=np.float64)
     launches = a.steps // 500
-    waves = out[8] / launches
-    per = cyc / out[8] / 500  # cycles per wave-step
+    waves = out[15] / launches
+    per = cyc / out[15] / 500  # cycles per wave-step
     print('envs %d humans %d: %.1f M env-steps/s (instrumented), %d waves, %.0f clock ticks per wave-step'
           % (a.envs, a.humans, a.envs * a.steps / dt / 1e6, waves, per.sum()))
     for n, c in zip(NAMES, per):
