@@ -347,6 +347,9 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         }
         CN_TICK(clk, 3);
         const bool need = solve && fail < n;
+#ifdef CN_PHASE_TIMING
+        if (clk) clk->acc[9] += __popcll(__ballot(need));  // agents in the fallback
+#endif
         if (kCoop3) {
             if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible
                 if (L.lane < P.nA) s.res[L.lane] = make_float4(rx, ry, __int_as_float(need ? fail : 0x7fffffff), 0.0f);
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView 
     }
 #ifdef CN_PHASE_TIMING
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        for (int k = 0; k < 9; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
+        for (int k = 0; k < 10; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
         atomicAdd(&cn_phase_cycles[15], 1ull);  // waves
     }
 #endif

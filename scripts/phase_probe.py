@@ -54,6 +54,7 @@ def main():
           % (a.envs, a.humans, a.envs * a.steps / dt / 1e6, waves, per.sum()))
     for n, c in zip(NAMES, per):
         print('  %-34s %8.0f  %5.1f %%' % (n, c, 100 * c / per.sum()))
+    print('  agents in the 3-D fallback per wave-step: %.3f (of %d agent lanes)' % (out[9] / out[15] / 500, eng.A * max(1, a.envs // int(waves))))
     print('  transitions', int(bufs['transitions'].cpu()[0]))
 
 
