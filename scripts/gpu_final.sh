@@ -14,4 +14,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o 
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1 < /dev/null; echo "write rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sarl -o trace -- python $REPO/scripts/sarl_bench.py > $OUT/trace_sarl.log 2>&1 < /dev/null; echo "trace_sarl rc=$?"
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sarl -o sarl -- python $REPO/scripts/sarl_bench.py --iters 3 > $OUT/pmc_sarl.log 2>&1 < /dev/null; echo "pmc_sarl rc=$?"
+cd $REPO
+timeout 420 python examples/train_sarl.py --gpu --il-episodes 3000 --il-epochs 50 --train-episodes 625 --sample-episodes 16 --train-batches 100 --epsilon-decay 250 --target-update-interval 3 --evaluation-interval 125 --timing-json $OUT/config5_paced.json > $OUT/config5_paced.log 2>&1 < /dev/null; echo "train rc=$?"
+timeout 200 python bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 2000 --warmup 500 --chunk 500 > $OUT/bench_h20.log 2>&1 < /dev/null
 cd $REPO; tail -n 3 $OUT/pytest_gpu.log $OUT/smoke.log; for f in $OUT/bench*.log; do echo $f; timeout 20 python scripts/bench_line.py $f; done
