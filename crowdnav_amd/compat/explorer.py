@@ -100,13 +100,7 @@ class Explorer(object):
         env = self.env
         self.robot.time_step = env.time_step  # CrowdSim.reset does this (crowd_sim.py:296-298)
         self.robot.policy.time_step = env.time_step
-        multi = getattr(self.robot.policy, 'multiagent_training', None)
-        if phase == 'test':
-            human_num, rule = env.human_num, env.test_sim
-        else:
-            human_num, rule = (env.human_num if multi else 1), ('circle_crossing' if not multi else env.train_val_sim)
-        offset = {'train': env.case_capacity['val'] + env.case_capacity['test'], 'val': 0,
-                  'test': env.case_capacity['val']}[phase]
+        human_num, rule, offset = self._scenario_of(phase)
         start = env.case_counter[phase]
         size = env.case_size[phase]
         B = int(min(k, self.max_envs))
@@ -162,13 +156,7 @@ class Explorer(object):
         env, policy = self.env, self.target_policy
         self.robot.time_step = env.time_step
         self.robot.policy.time_step = env.time_step
-        multi = getattr(self.robot.policy, 'multiagent_training', None)
-        if phase == 'test':
-            human_num, rule = env.human_num, env.test_sim
-        else:
-            human_num, rule = (env.human_num if multi else 1), ('circle_crossing' if not multi else env.train_val_sim)
-        offset = {'train': env.case_capacity['val'] + env.case_capacity['test'], 'val': 0,
-                  'test': env.case_capacity['val']}[phase]
+        human_num, rule, offset = self._scenario_of(phase)
         start, dt, vp = env.case_counter[phase], env.time_step, self.robot.v_pref
         max_steps = int(round(env.time_limit / dt)) + 2
         outcome, length, rewards_all, states_all, danger_n, danger_sum = [], [], [], [], 0, 0.0
