@@ -790,8 +790,14 @@ __device__ __forceinline__ int finish_episode(const RolloutView R, int env, int 
 
 // Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs
 // take their next scenario from the ring.
+// CN_MAXL10_WAVES (compile time, experiments): resident waves per SIMD the 10-half-plane rollout kernel is compiled
+// for (its register-resident program wants ~190 VGPRs = 2 waves; 3 caps it at 168, 4 at 128 with spills).  Measured
+// at H = 20: 54.1 (unconstrained) / 51.7 / 47.2 M env-steps/s — occupancy is not the limiter.
+#ifndef CN_MAXL10_WAVES
+#define CN_MAXL10_WAVES 1
+#endif
 template <int MAXL, bool UNI>
-__global__ __launch_bounds__(kMaxBlock) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps,
+__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps,
                                                             const double* ext_action) {
     const Smem s = carve(P);
     const Lane L = lane_of(P);
