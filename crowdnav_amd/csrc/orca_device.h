@@ -232,10 +232,12 @@ __device__ __forceinline__ void lp_planar_coop(const float4* lines, const int* c
 // once), and the planar program over the projected lines (directionOpt) runs in rounds exactly like lp_planar_coop:
 // first violated projected line k, lanes j < k contribute their bound on k, fold in line order.  Projected lines that
 // RVO2 skips (parallel, same direction) simply hold no line; order and every arithmetic operation are RVO2's.
-//   res [nA] in: (result.x, result.y, int bits: first infeasible line — >= count[a] = nothing to do), out: result
+//   res [nA] in: (result.x, result.y, int bits: first infeasible line), out: result
+//   todo [n_todo] the agents that need the fallback, compacted: kWave / MAXL of them share a wave pass, so a 21-agent
+//        env with 6 infeasible agents takes one pass at MAXL = 10 instead of one per 6-agent slice that holds any
 template <int MAXL>
 __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* count, const float4* sol, float4* res,
-                                                int nA) {
+                                                const int* todo, int n_todo) {
     constexpr int G = kWave / MAXL;
     constexpr unsigned kField = (1u << MAXL) - 1u;
     const int wl = threadIdx.x & (kWave - 1);
@@ -243,15 +245,14 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
     const int gbase = g * MAXL;
     const int waves = (blockDim.x + kWave - 1) / kWave;
     const float inf = __builtin_inff();
-    for (int chunk = threadIdx.x / kWave; chunk * G < nA; chunk += waves) {
-        const int a = chunk * G + g;
-        const bool live = g < G && a < nA;
-        const float4 r0 = res[live ? a : 0];
+    for (int chunk = threadIdx.x / kWave; chunk * G < n_todo; chunk += waves) {
+        const bool live = g < G && chunk * G + g < n_todo;
+        const int a = live ? todo[chunk * G + g] : 0;
+        const float4 r0 = res[a];
         const int n = live ? count[a] : 0;
         const int begin = __float_as_int(r0.z);
         const bool need = live && begin < n;
-        if (__ballot(need) == 0ull) continue;
-        const float radius = sol[live ? a : 0].z;
+        const float radius = sol[a].z;
         const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
         float rx = r0.x, ry = r0.y, distance = 0.0f;
         int icur = need ? begin : n;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
             const unsigned gm = (unsigned)(m >> gbase) & kField;
             const bool act = gm != 0u;
             const int i = act ? __ffs(gm) - 1 : 0;
-            const float4 li = lines[(live ? a : 0) * kLineStride + i];
+            const float4 li = lines[a * kLineStride + i];
             // this lane's half-plane projected onto half-plane i (meaningful for l < i)
             const float d = li.z * my.w - li.w * my.z;
             const bool par = fabsf(d) <= kRvoEps;

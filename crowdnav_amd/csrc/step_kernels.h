@@ -92,13 +92,14 @@ struct Smem {
     int* flag;        // [nA] (robot lanes) per-env flag broadcast
     float4* sol;      // [nA] lane-cooperative program input: (pref.x, pref.y, maxSpeed, solve ? 1 : 0)
     float4* res;      // [nA] ... and output: (result.x, result.y, first infeasible line or n, -)
+    int* todo;        // [nA + 1] agents that need the 3-D fallback, compacted; [nA] = how many
     double* disc;     // [kMaxDiscount] discount table gamma^(t dt v_pref) (rollout kernel only)
 };
 
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
 
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs) {
-    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 +
+    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 +
            sizeof(double) * kMaxDiscount;
 }
 
@@ -120,6 +121,7 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.rview = reinterpret_cast<float*>(p), p += 4 * nA;
     s.count = reinterpret_cast<int*>(p), p += 4 * nA;
     s.flag = reinterpret_cast<int*>(p), p += 4 * nA;
+    s.todo = reinterpret_cast<int*>(p), p += 4 * (nA + 1);
     s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
     s.pinfo = reinterpret_cast<int*>(p), p += 4 * P.pairs;
     s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
@@ -239,7 +241,7 @@ struct PhaseClock {};
 #endif
 // CN_COOP_LP3_5 / CN_COOP_LP3_10 (compile time): the infeasible-program fallback with one lane per (agent, half-plane)
 // (lp_relaxed_coop) instead of a serial LDS walk on the agent's own lane (lp_relaxed_lds).  Measured
-// (profiles/r01_coop_lp_ab.txt): H = 20 +12 % (48.3 -> 54.1 M env-steps/s); H = 5 neutral at 4096 envs and -8 % at
+// (profiles/r01_coop_lp_ab.txt): H = 20 +12 % (48.3 -> 54.1 -> 61.2 M env-steps/s with the infeasible agents compacted); H = 5 neutral at 4096 envs and -8 % at
 // 32 768 envs (127 -> 153 VGPRs costs a resident wave per SIMD), hence on for MAXL = 10 only.
 #ifndef CN_COOP_LP3_5
 #define CN_COOP_LP3_5 0
@@ -352,9 +354,16 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 #endif
         if (kCoop3) {
             if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible
-                if (L.lane < P.nA) s.res[L.lane] = make_float4(rx, ry, __int_as_float(need ? fail : 0x7fffffff), 0.0f);
+                if (L.lane < kWave) {  // agent lanes live in wave 0: compact the infeasible ones
+                    const unsigned long long nm = __ballot(need);
+                    if (need) {
+                        s.res[L.lane] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
+                        s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
+                    }
+                    if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
+                }
                 __syncthreads();
-                lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, P.nA);
+                lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
                 __syncthreads();
                 if (need) {
                     const float4 got = s.res[L.lane];
