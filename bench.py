@@ -44,6 +44,23 @@ def pmc_traffic_bytes(envs, humans, steps_per_launch):
     return (2 * rec['fetch_size_kb'] + rec['write_size_kb']) * 1024
 
 
+def pmc_issue(envs, humans, steps_per_launch, launch_seconds):
+    """What actually bounds the fused rollout: vector-ALU issue.  SQ_INSTS_VALU per launch (committed PMC pass) over the
+    launch time measured in this run, against 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch')) != (envs, humans, steps_per_launch):
+        return None
+    if 'sq_insts_valu' not in rec:
+        return None
+    peak = 1024 * 2.4e9 / 4
+    achieved = rec['sq_insts_valu'] / launch_seconds
+    return {'bound': 'valu-issue', 'achieved': achieved / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instructions/s',
+            'frac': achieved / peak, 'valu_per_env_step': rec['sq_insts_valu'] / (envs * steps_per_launch) }
+
+
 def bench_sarl(args, world, rank, local_rank):
     """BASELINE configs[2]: 4096 envs x 5 humans, SARL value-network rollout (random-init weights), greedy phase.
     A step = cn_sarl_select (81 lookaheads + value network per env) + cn_step + masked seeded reset."""
@@ -244,6 +261,7 @@ def main():
                      'kernel': 'cn::rollout_kernel (+ cn::ring_fill_kernel, ~2 % of the launch: one cn_rollout call)',
                      'avg_launch_ms': avg_launch_s * 1e3,
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
+        'issue_roofline': pmc_issue(B, H, args.chunk, avg_launch_s),
         'paused_env_steps': paused_env_steps,
         'episodes_finished': int(summary[0].item()),
         'mean_recorded_return': float(summary[1].item() / max(summary[2].item(), 1.0)),
