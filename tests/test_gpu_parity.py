@@ -495,3 +495,26 @@ def test_rollout_step_with_external_actions_vs_oracle(amd, oracle_mod):
         k = min(len(rec_steps[b]), 8)
         assert got_steps[b, :k].tolist() == rec_steps[b][:k] and got_out[b, :k].tolist() == rec_outcome[b][:k]
     assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('humans,envs,rounds,radius', [(5, 512, 3, 4.0), (20, 128, 2, 12.0), (10, 192, 2, 6.0)])
+def test_free_running_soak_vs_oracle(amd, oracle_mod, humans, envs, rounds, radius):
+    """Soak: hundreds of envs free-running for 100 steps per round (through and past their terminal states: contact,
+    overlap, infeasible programs — the 3-D fallback in every variant), every output of every step bit-identical to
+    the oracle; each round starts from fresh oracle-generated scenarios.  H = 20 / 10 run the lane-cooperative fallback."""
+    cfg = dict(num_humans=humans, robot_visible=1, circle_radius=radius)
+    eng = amd.BatchedCrowdSim(num_envs=envs, robot_policy=amd.ROBOT_ORCA, **cfg)
+    for r in range(rounds):
+        o = oracle_mod.CrowdOracle(num_envs=envs, robot_policy=1, **cfg)
+        o.reset(50000 + 1000 * r + np.arange(envs))
+        eng.drop_robot_sim()
+        eng.set_state(o.get_state()[0], np.zeros(envs))
+        for t in range(100):
+            got = eng.step(None, update=True, want_obs=False)
+            want = o.step(None, update=True)
+            assert np.array_equal(_np(got['orca_vel']).view(np.uint32), want['orca_vel'].view(np.uint32)), (r, t)
+            for k in ('reward', 'done', 'info', 'dmin', 'action'):
+                assert np.array_equal(_np(got[k]), want[k]), (k, r, t)
+        s, g = (_np(x) for x in eng.get_state())
+        assert np.array_equal(s, o.get_state()[0]) and np.array_equal(g, o.get_state()[1])
