@@ -96,7 +96,7 @@ SYMBOLS = {
     'cn_sarl_set_weights': (C.c_int, [_P, C.POINTER(_P)]),
     'cn_sarl_select': (C.c_int, [_P, _P, _P, _P]),
     'cn_sarl_explore': (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
-    'cn_sarl_transform': (C.c_int, [_P, _P, C.c_int64]),
+    'cn_sarl_transform': (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     'cn_sarl_export': (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
     'cn_mt_random': (C.c_int, [_P, C.c_uint32, C.c_int, _P]),
 }

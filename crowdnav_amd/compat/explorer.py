@@ -48,7 +48,8 @@ class Explorer(object):
                    and self.env.case_counter[phase] + k <= self.env.case_size[phase])  # no wrap of the case table
         no_wrap = (self.env.case_counter[phase] >= 0 and self.env.case_counter[phase] + k <= self.env.case_size[phase])
         batched_il = (is_device_orca(self.robot.policy) and update_memory and imitation_learning and no_wrap
-                      and hasattr(self.env, 'engine_config') and isinstance(self.target_policy, SARL))
+                      and hasattr(self.env, 'engine_config') and isinstance(self.target_policy, SARL)
+                      and getattr(self.target_policy, 'kinematics', 'holonomic') == 'holonomic')
         batched_rl = (isinstance(self.robot.policy, SARL) and phase == 'train' and update_memory
                       and not imitation_learning and no_wrap and hasattr(self.env, 'engine_config')
                       and getattr(self.robot.policy, 'env', None) is self.env)
@@ -149,76 +150,72 @@ class Explorer(object):
 
     def _run_batched_imitation(self, k, phase):
         """Imitation-learning data collection (train.py:115-129): k ORCA-robot episodes in lock step on the device,
-        then update_memory(..., imitation_learning=True) for all of them at once — per-step joint states are turned
-        into the value network's input with the target policy's own transform (vectorised), values are the discounted
-        Monte-Carlo returns of explorer.py:100-105, and (state, value) pairs enter the memory in the reference's order."""
+        then update_memory(..., imitation_learning=True) for all of them at once.  Per step cn_sarl_transform writes
+        the target policy's transform of the joint state the ORCA robot saw (explorer.py:99:
+        target_policy.transform(state), humans in env order) straight into a [B, T, H, D] trajectory tensor; values
+        are the discounted Monte-Carlo returns of explorer.py:100-105 (host float64, the reference's left-to-right
+        sum); (state, value) pairs enter the memory in the reference's order."""
         import numpy as np
         env, policy = self.env, self.target_policy
         self.robot.time_step = env.time_step
         self.robot.policy.time_step = env.time_step
+        if policy.action_space is None:
+            policy.build_action_space(self.robot.v_pref)
         human_num, rule, offset = self._scenario_of(phase)
         start, dt, vp = env.case_counter[phase], env.time_step, self.robot.v_pref
         max_steps = int(round(env.time_limit / dt)) + 2
-        outcome, length, rewards_all, states_all, danger_n, danger_sum = [], [], [], [], 0, 0.0
+        D = policy.input_dim()
+        single = policy.net_cfg.get('model') == 'cadrl'  # CADRL.transform (cadrl.py:174-185): one human, [13]
+        outcome, length, rewards_all, danger_n, danger_sum = [], [], [], 0, 0.0
         for c0 in range(0, k, self.max_envs):
             B = min(self.max_envs, k - c0)
             eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
+            eng.sarl_configure(**policy.engine_kwargs())  # only the transform runs on this engine
             eng.reset(offset + start + c0 + np.arange(B))
-            hist_s, hist_r, hist_i, hist_d = [], [], [], []
+            traj = torch.zeros(B, max_steps, human_num, D, dtype=torch.float32, device=eng.device)
+            hist_r, hist_i, hist_d = [], [], []
             alive = torch.ones(B, dtype=torch.bool, device=eng.device)
-            for _ in range(max_steps):
-                hist_s.append(eng.get_state()[0])
+            for t in range(max_steps):
+                eng.sarl_transform(out=traj[:, t], env_stride=max_steps * human_num * D, sort_humans=False)
                 out = eng.step(None, update=True, want_obs=False)
                 hist_r.append(out['reward'])
                 hist_i.append(out['info'])
                 hist_d.append(out['dmin'])
                 alive = alive & (out['done'] == 0)
-                if not bool(alive.any().item()):
+                if t % 8 == 7 and not bool(alive.any().item()):
                     break
-            S = torch.stack(hist_s).cpu().numpy()      # [T, B, A, 8]
             R = torch.stack(hist_r).cpu().numpy()      # [T, B]
             I = torch.stack(hist_i).cpu().numpy()
-            D = torch.stack(hist_d).cpu().numpy()
+            Dm = torch.stack(hist_d).cpu().numpy()
+            terminal = I >= _lib.REACH_GOAL
+            if not terminal.any(axis=0).all():
+                raise ValueError('Invalid end signal from environment')
+            Tb = terminal.argmax(axis=0) + 1           # first terminal step of every episode
+            last = I[Tb - 1, np.arange(B)]
             for b in range(B):
-                T = int(np.argmax(I[:, b] >= _lib.REACH_GOAL)) + 1  # first terminal step
-                outcome.append(int(I[T - 1, b]))
-                length.append(T)
-                rewards_all.append(R[:T, b].tolist())
-                states_all.append(S[:T, b])
-                dang = I[:T, b] == _lib.DANGER
+                n = int(Tb[b])
+                outcome.append(int(last[b]))
+                length.append(n)
+                rewards_all.append(R[:n, b].tolist())
+                dang = I[:n, b] == _lib.DANGER
                 danger_n += int(dang.sum())
-                danger_sum += float(D[:T, b][dang].sum())
+                danger_sum += float(Dm[:n, b][dang].sum())
+            # explorer.py:66-69, 92-125 for every ReachGoal / Collision episode of this batch
+            keep = np.flatnonzero((last == _lib.REACH_GOAL) | (last == _lib.COLLISION))
+            if len(keep):
+                if self.memory is None or self.gamma is None:
+                    raise ValueError('Memory or gamma value is not set!')
+                b_idx = np.repeat(keep, Tb[keep])
+                i_idx = np.concatenate([np.arange(Tb[b]) for b in keep])
+                x = traj[torch.as_tensor(b_idx, device=eng.device), torch.as_tensor(i_idx, device=eng.device)]
+                values = []
+                for b in keep:
+                    rw = rewards_all[c0 + int(b)]
+                    for i in range(len(rw)):
+                        values.append(sum([pow(self.gamma, max(t - i, 0) * dt * vp) * r * (1 if t >= i else 0)
+                                           for t, r in enumerate(rw)]))
+                self._push_all(x[:, 0] if single else x, torch.Tensor(values))
         env.case_counter[phase] = (start + k) % env.case_size[phase]
-
-        # explorer.py:66-69, 92-125 for every ReachGoal / Collision episode, batched
-        keep = [e for e in range(k) if outcome[e] in (_lib.REACH_GOAL, _lib.COLLISION)]
-        if keep:
-            if self.memory is None or self.gamma is None:
-                raise ValueError('Memory or gamma value is not set!')
-            rows, values = [], []
-            for e in keep:
-                st, rw = states_all[e], rewards_all[e]
-                robot = st[:, 0]
-                me = np.stack([robot[:, 0], robot[:, 1], robot[:, 2], robot[:, 3], robot[:, 6], robot[:, 4], robot[:, 5],
-                               robot[:, 7], np.full(len(st), np.pi / 2)], axis=1)              # FullState order
-                hum = st[:, 1:][:, :, [0, 1, 2, 3, 6]]                                          # ObservableState order
-                rows.append(np.concatenate([np.repeat(me[:, None, :], hum.shape[1], axis=1), hum], axis=2))
-                for i in range(len(rw)):
-                    values.append(sum([pow(self.gamma, max(t - i, 0) * dt * vp) * r * (1 if t >= i else 0)
-                                       for t, r in enumerate(rw)]))
-            joint = torch.Tensor(np.concatenate(rows, axis=0))                                  # [N, H, 14] float32
-            n, h, _ = joint.shape
-            from .sarl import occupancy_maps, rotate
-            x = rotate(joint.reshape(n * h, 14), policy.kinematics).reshape(n, h, 13)
-            if policy.with_om:
-                from .types import ObservableState
-                maps = [occupancy_maps([ObservableState(*row) for row in js[:, 9:14].double().tolist()], policy.cell_num,
-                                       policy.cell_size, policy.om_channel_size) for js in joint]
-                x = torch.cat([x, torch.stack(maps)], dim=2)
-            if policy.net_cfg.get('model') == 'cadrl':  # CADRL.transform (cadrl.py:174-185): one human, [13]
-                assert h == 1
-                x = x[:, 0]
-            self._push_all(x, torch.Tensor(values))
 
         self.last_batch = dict(outcome=outcome, steps=length, env_steps=int(sum(length)))
         times = [length[e] * dt for e in range(k)]

@@ -291,14 +291,17 @@ def _sarl_explore(self, sel, epsilon, mask=None, want_explored=True):
     return sel
 
 
-def _sarl_transform(self, out=None, env_stride=0):
+def _sarl_transform(self, out=None, env_stride=0, sort_humans=None):
     """MultiHumanRL.transform of every env's current joint state: [B, H, in_dim] float32 (replay-memory state).
     With out (a float32 device tensor) and env_stride (floats between consecutive envs) the rows are written in place,
-    e.g. out = traj[:, t] of a [B, T, H, D] trajectory tensor with env_stride = T * H * D."""
+    e.g. out = traj[:, t] of a [B, T, H, D] trajectory tensor with env_stride = T * H * D.  sort_humans: LSTM-RL's
+    decreasing-distance order (default for that model: the RL phase); False = env order (imitation learning)."""
     if out is None:
         out = self._new((self.B, self.H, self.sarl['in_dim']), torch.float32)
     assert out.dtype == torch.float32 and out.device.type == self.device.type
-    check(self._lib.cn_sarl_transform(self._h, C.c_void_p(out.data_ptr()), int(env_stride)))
+    if sort_humans is None:  # what a train-phase predict() of this model leaves in last_state
+        sort_humans = self.sarl['model'] == 'lstm_rl'
+    check(self._lib.cn_sarl_transform(self._h, C.c_void_p(out.data_ptr()), int(env_stride), int(bool(sort_humans))))
     return out
 
 

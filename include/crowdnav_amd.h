@@ -236,9 +236,10 @@ int cn_sarl_explore(cn_engine* e, double epsilon, const uint8_t* mask, int32_t* 
  * Explorer.update_memory (explorer.py:92-125) pushes into the replay memory:
  *   out float32, env b's [H][13 (+ cell_num^2 * om_channel_size)] block at out + b * env_stride (floats;
  *   0 = densely packed [B][H][D]; a larger stride writes step t of a [B][T][H][D] trajectory tensor in place).
- * CN_MODEL_LSTM_RL: the humans appear by decreasing distance to the robot, as LstmRL.predict re-orders them before
- * it stores last_state (lstm_rl.py:96-103; stable for equal distances). */
-int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride);
+ * sort_humans != 0 (meaningful for CN_MODEL_LSTM_RL): the humans appear by decreasing distance to the robot, as
+ * LstmRL.predict re-orders them before it stores last_state (lstm_rl.py:96-103; stable for equal distances) — the RL
+ * phase; 0 = env order, which is what imitation learning stores (explorer.py:99 transforms the ORCA robot's own state). */
+int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_humans);
 /* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):
  *   0 reward f64 [B][K] · 1 V f32 [B*K] · 2 next human states f64 [B][H][5] · 3 occupancy maps f32 [B][H][cells*ch]
  *   4 X f32 in MLP tile order (see sarl_kernels.h) */
