@@ -85,9 +85,43 @@ def generate(name, with_om, robot_visible, k, epsilon, first_case=0, policy_name
           'value range', float(values.min()) if len(values) else None, float(values.max()) if len(values) else None)
 
 
+def generate_il(name, with_om, robot_visible, k, first_case=0, policy_name='sarl'):
+    """The imitation-learning collection of train.py:115-129: ORCA demonstrator, the target policy only transforms."""
+    rh.activate()
+    from crowd_nav.policy.policy_factory import policy_factory
+    from crowd_nav.utils.explorer import Explorer
+    from crowd_nav.utils.memory import ReplayMemory
+    torch.manual_seed(0)
+    pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
+                                            ('lstm_rl', 'with_om'): 'true' if with_om else 'false'})
+    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
+    device = torch.device('cpu')
+    policy.set_device(device)
+    memory = ReplayMemory(100000)
+    explorer = Explorer(env, robot, device, memory, policy.gamma, target_policy=policy)
+    il_policy = policy_factory['orca']()
+    il_policy.multiagent_training = policy.multiagent_training
+    il_policy.safety_space = 0 if robot_visible else 0.15
+    robot.set_policy(il_policy)
+    env.case_counter['train'] = first_case
+    explorer.run_k_episodes(k, 'train', update_memory=True, imitation_learning=True)
+    states = np.stack([s.numpy() for s, _ in memory.memory])
+    if states.ndim == 2:
+        states = states[:, None, :]
+    values = np.array([float(v.item()) for _, v in memory.memory], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, name), memory_states=states.astype(np.float32), memory_values=values,
+                        k=np.array(k), first_case=np.array(first_case), with_om=np.array(int(with_om)),
+                        robot_visible=np.array(int(robot_visible)), gamma=np.array(policy.gamma),
+                        policy=np.array(policy_name))
+    print(name, 'episodes', k, 'memory', len(values), 'value range', float(values.min()), float(values.max()))
+
+
 if __name__ == '__main__':
     assert rh.available()
-    which = sys.argv[1:] or ['sarl', 'cadrl', 'lstm_rl', 'lstm_rl2']
+    which = sys.argv[1:] or ['sarl', 'cadrl', 'lstm_rl', 'lstm_rl2', 'il']
+    if 'il' in which:
+        generate_il('il_sarl_om.npz', with_om=True, robot_visible=False, k=8, first_case=600)
+        generate_il('il_lstm_rl.npz', with_om=False, robot_visible=True, k=6, first_case=700, policy_name='lstm_rl')
     if 'sarl' in which:
         generate('rl_sarl_plain.npz', with_om=False, robot_visible=False, k=12, epsilon=0.5)
         generate('rl_sarl_om.npz', with_om=True, robot_visible=True, k=8, epsilon=0.3, first_case=100)

@@ -317,3 +317,37 @@ def test_lstm_rl_transform_orders_humans_by_decreasing_distance(with_om):
         assert (got[b] - want).abs().max().item() <= 5e-6, b
     assert sorted(range(H), key=lambda j: np.hypot(*(st[3, 1 + j, :2] - st[3, 0, :2])), reverse=True).index(1) + 1 == \
         sorted(range(H), key=lambda j: np.hypot(*(st[3, 1 + j, :2] - st[3, 0, :2])), reverse=True).index(3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['il_sarl_om.npz', 'il_lstm_rl.npz'])
+def test_batched_imitation_collection_reproduces_the_reference_memory(name):
+    """Explorer.run_k_episodes(k, 'train', update_memory=True, imitation_learning=True) (train.py:115-129): the replay
+    memory the unmodified reference filled from its ORCA demonstrations — device episodes, cn_sarl_transform in env
+    order (LSTM-RL included: imitation learning stores MultiHumanRL.transform of the demonstrator's state, unsorted),
+    Monte-Carlo returns of explorer.py:100-105."""
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory
+    g = load_golden(name)
+    pname, with_om, visible = str(g['policy']), bool(int(g['with_om'])), bool(int(g['robot_visible']))
+    cfg = c.default_env_config({('robot', 'visible'): 'true' if visible else 'false'})
+    env = c.CrowdSim()
+    env.configure(cfg)
+    robot = c.Robot(cfg, 'robot')
+    target = c.policy_factory[pname]()
+    target.configure(default_policy_config({(pname, 'with_om'): 'true' if with_om else 'false'}))
+    target.set_device(torch.device('cpu'))
+    il = c.policy_factory['orca']()
+    il.multiagent_training, il.safety_space = target.multiagent_training, (0 if visible else 0.15)
+    robot.set_policy(il)
+    env.set_robot(robot)
+    mem = DeviceReplayMemory(100000, 'cuda:0')
+    ex = c.Explorer(env, robot, torch.device('cpu'), mem, float(g['gamma']), target_policy=target)
+    env.case_counter['train'] = int(g['first_case'])
+    ex.run_k_episodes(int(g['k']), 'train', update_memory=True, imitation_learning=True)
+    assert len(mem) == len(g['memory_values'])
+    states = mem.states[:len(mem)].cpu().numpy()
+    values = mem.values[:len(mem), 0].cpu().numpy()
+    assert np.abs(states - g['memory_states']).max() <= 5e-6
+    assert np.array_equal(values, g['memory_values'])  # float64 Monte-Carlo sums, rounded once to float32
