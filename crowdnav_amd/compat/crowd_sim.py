@@ -6,8 +6,9 @@
 Every transition (the humans' ORCA solves, collision / reward / done, integration) and every seeded reset runs
 in libcrowdnav_amd on the GPU; this class only moves the results into the objects the reference's callers read.
 All three scenario rules are covered (`mixed`: 5 agent slots, absent humans parked; unlike the reference — which sizes
-human_times from the previous episode, crowd_sim.py:262-265 — consecutive mixed resets work).  Not covered (raise
-NotImplementedError): render, get_human_times, value-network policies under `mixed`."""
+human_times from the previous episode, crowd_sim.py:262-265 — consecutive mixed resets work).  get_human_times runs its centralised
+float32 simulation through cn_orca.  Not covered (raise NotImplementedError): render, value-network policies under
+`mixed`."""
 import configparser
 import logging
 
@@ -264,4 +265,42 @@ class CrowdSim(_Base):
         raise NotImplementedError('rendering is outside the accelerated path; use the reference CrowdSim')
 
     def get_human_times(self):
-        raise NotImplementedError('get_human_times is outside the accelerated path')
+        """crowd_sim.py:209-249: after the robot reached its goal, run ONE centralised rvo2 simulation of all agents
+        until every human has reached its goal, and report when each did.  The centralised simulator holds the raw
+        radii (no +0.01 padding: safety space -0.01 on this engine) and integrates float32 positions itself
+        (position += velocity * timeStep in float32), so that is what happens here: cn_orca for every agent's new
+        velocity, float32 integration on the host, positions written back.  (Difference from the per-agent simulators:
+        none but the visit order among exact distance ties — the robot comes first in the centralised simulator.)"""
+        if not self.robot.reached_destination():
+            raise ValueError('Episode is not done yet')
+        agents = [self.robot] + self.humans
+        cfg = self.engine_config(1, len(self.humans), self._rule if self._rule != 'mixed' else 'circle_crossing',
+                                 _lib.ROBOT_ORCA)
+        cfg.update(robot_visible=1, robot_safety_space=-0.01, human_safety_space=-0.01)
+        sim = BatchedCrowdSim(**cfg)
+        f32 = np.float32
+        pos = np.array([[a.px, a.py] for a in agents], dtype=f32)           # rvo2 stores float32
+        vel = np.array([[a.vx, a.vy] for a in agents], dtype=f32)
+        dt32 = f32(self.time_step)
+        max_time = 1000
+        while not all(self.human_times):
+            state = np.array([[[float(pos[i, 0]), float(pos[i, 1]), float(vel[i, 0]), float(vel[i, 1]), a.gx, a.gy,
+                                a.radius, a.v_pref] for i, a in enumerate(agents)]], dtype=np.float64)
+            # the preferred velocity comes from the agents' positions as Python sees them (goal - position, :229-232)
+            for i, a in enumerate(agents):
+                state[0, i, 0], state[0, i, 1] = a.px, a.py
+            sim.set_state(state, np.zeros(1))
+            new_vel = sim.orca().cpu().numpy()[0].astype(f32)                # doStep: new velocities ...
+            sim.drop_robot_sim()
+            vel = new_vel
+            pos = (pos + vel * dt32).astype(f32)                             # ... then float32 integration
+            self.global_time += self.time_step
+            if self.global_time > max_time:
+                logging.warning('Simulation cannot terminate!')
+            for i, human in enumerate(self.humans):
+                if self.human_times[i] == 0 and human.reached_destination():
+                    self.human_times[i] = self.global_time
+            for i, a in enumerate(agents):                                   # for visualization (:243-246)
+                a.px, a.py = float(pos[i, 0]), float(pos[i, 1])
+            self.states.append([self.robot.get_full_state(), [h.get_full_state() for h in self.humans]])
+        return self.human_times

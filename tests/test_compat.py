@@ -146,3 +146,34 @@ def test_debug_case_minus_one_and_square_crossing_through_gym_surface():
         ob, reward, done, info = env.step(action)
         assert reward == e['rewards'][t] and done == bool(e['dones'][t])
     assert done
+
+
+@pytest.mark.gpu
+def test_get_human_times_vs_reference():
+    """CrowdSim.get_human_times (crowd_sim.py:209-249): the centralised float32 rvo2 continuation after the robot has
+    arrived — same arrival times, same number of simulated steps, same final positions as the unmodified reference
+    (fixture: oracle/gen_golden_human_times.py)."""
+    from conftest import load_golden
+    import crowdnav_amd.compat as c
+    g = load_golden('human_times.npz')
+    cfg = c.default_env_config({('robot', 'visible'): 'true'})
+    env = c.CrowdSim()
+    env.configure(cfg)
+    robot = c.Robot(cfg, 'robot')
+    robot.set_policy(c.policy_factory['orca']())
+    env.set_robot(robot)
+    with pytest.raises(ValueError):
+        env.reset('test', 0)
+        env.get_human_times()  # episode is not done yet
+    for k, case in enumerate(g['case'].tolist()):
+        env.reset('test', case)
+        # continue from the reference's own end-of-episode state (device scenarios differ from numpy's at 1e-12)
+        env._eng.set_state(g['end_state'][k][None], np.array([g['end_time'][k]]))
+        env._pull()
+        env.human_times = list(g['times_before'][k])
+        n0 = len(env.states)
+        times = env.get_human_times()
+        assert times == g['human_times'][k].tolist(), case
+        assert len(env.states) - n0 == int(g['extra_steps'][k])
+        got = np.array([[a.px, a.py] for a in [env.robot] + env.humans])
+        assert np.array_equal(got, g['final_pos'][k]), case
