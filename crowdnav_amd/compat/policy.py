@@ -61,11 +61,28 @@ class ORCA(Policy):
         return ActionXY(vx, vy)
 
 
+class Linear(Policy):
+    """crowd_sim/envs/policy/linear.py: straight to the goal at the preferred speed (a robot policy; nothing to
+    accelerate — the action then goes through cn_step like any other)."""
+
+    def __init__(self):
+        super().__init__()
+        self.trainable = False
+        self.kinematics = 'holonomic'
+        self.multiagent_training = True
+
+    def predict(self, state):
+        import numpy as np
+        me = state.self_state
+        theta = np.arctan2(me.gy - me.py, me.gx - me.px)
+        return ActionXY(np.cos(theta) * me.v_pref, np.sin(theta) * me.v_pref)
+
+
 def is_device_orca(policy):
     return isinstance(policy, ORCA)
 
 
-policy_factory = {'orca': ORCA, 'none': lambda: None}
+policy_factory = {'orca': ORCA, 'linear': Linear, 'none': lambda: None}
 
 
 def _register_trainable():
