@@ -186,3 +186,21 @@ def test_linear_policy_cpu():
     state = c.JointState(c.FullState(0.0, -4.0, 0.0, 0.0, 0.3, 3.0, 0.0, 1.0, np.pi / 2), [])
     a = pol.predict(state)
     assert abs(a.vx - 0.6) < 1e-12 and abs(a.vy - 0.8) < 1e-12 and not pol.trainable and pol.multiagent_training
+
+
+@pytest.mark.gpu
+def test_example_test_policy_script():
+    """examples/test_policy.py = the reference's test.py: `--policy orca` over the 500 test cases gives the paper's
+    ORCA row (success 0.43, collision 0.57, nav time 10.86: SURVEY.md §8(c)); one visible case ends with
+    get_human_times."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('test_policy', os.path.join(ROOT, 'examples', 'test_policy.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stats = mod.run(mod.parser().parse_args(['--policy', 'orca']))
+    assert round(stats['success_rate'], 2) == 0.43 and round(stats['collision_rate'], 2) == 0.57
+    assert round(stats['nav_time'], 2) == 10.86
+    one = mod.run(mod.parser().parse_args(['--policy', 'orca', '--visible', '--test-case', '1']))
+    assert 'reach' in one['info'].lower() and len(one['human_times']) == 5 and all(t > 0 for t in one['human_times'])
