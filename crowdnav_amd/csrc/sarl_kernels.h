@@ -62,7 +62,8 @@ __device__ unsigned long long cn_sarl_cycles[16];
 #endif
 
 constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
-constexpr int kSarlMaxHumans = 8;    // LDS budget of the fused MLP kernel (H = 5 in every BASELINE config)
+constexpr int kSarlMaxHumans = 8;    // register arrays of the occupancy map / LSTM-RL ordering; more humans: SARL without maps
+                                     // (sarl_mlp_chunked_kernel streams them; one-tile kernels hold up to 5 at the shipped widths)
 constexpr int kSarlThreads = 1024;   // 8 waves per MLP workgroup (2 per SIMD: one wave's LDS/L2 waits hide behind the other's MFMAs)
 constexpr int kSarlKChunk = 5;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time): K = 100 is 25 k-steps
 constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
@@ -375,9 +376,11 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
             for (int p = 0; p < kSarlMaxHumans; ++p) perm[p] = (j < C.H && rank == p) ? j : perm[p];
         }
     }
-    int me = 0;
+    int me = h;  // env order unless sorted (sorting and occupancy maps are limited to kSarlMaxHumans humans)
+    if (sort_humans) {
 #pragma unroll
-    for (int p = 0; p < kSarlMaxHumans; ++p) me = (p == h) ? perm[p] : me;
+        for (int p = 0; p < kSarlMaxHumans; ++p) me = (p == h) ? perm[p] : me;
+    }
     const size_t g1 = g0 + 1 + me;
     float f[13];
     rotate_row((float)pos[g0].x, (float)pos[g0].y, (float)vel[g0].x, (float)vel[g0].y, (float)rv[g0].x,
@@ -639,6 +642,127 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, con
 
 // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row, then the minimum over the humans
 // of a group (cadrl.py:162-163).  Layers live in L[kL_mlp3_0 .. kL_mlp3_6]; buffers as in the SARL kernel.
+// sarl.ValueNetwork for MORE humans than one tile's LDS holds (H > kSarlMaxHumans; e.g. the 20-human crowds of
+// BASELINE configs[3]): the humans of a tile's 16 groups stream through in chunks of HC row tiles.
+//   pass 1  mlp1 of every chunk, summed over the humans -> the global state (mean) and its attention term
+//   pass 2  mlp1 again (cheaper than parking [H][112] floats per group row in LDS), mlp2, attention; exp(score) and
+//           exp(score) * feature accumulate per group in human order, the division by the total comes last
+//           (the reference divides first: w_h = e_h / total, then sums w_h f_h — same value to rounding)
+// then the value head.  Rows of a partial last chunk are computed on zero inputs and masked out of every sum.
+template <int HC>
+__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_chunked_kernel(SarlNet net, const float* X, float* V,
+                                                                        int n_groups) {
+    extern __shared__ float lds[];
+    const int H = net.H;
+    float* bufA = lds;                            // [HC][ks_a][64]
+    float* bufB = bufA + HC * net.ks_a * 64;      // [HC][ks_b][64]
+    float* bufC = bufB + HC * net.ks_b * 64;      // [HC][ks_c][64]
+    float* gbuf = bufC + HC * net.ks_c * 64;      // [ks_b][64]  sum, then mean, over humans of h2
+    float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]
+    float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]
+    float* sbuf = kbuf + net.ks_a * 64;           // [HC][ks_s][64]
+    float* wsum = sbuf + HC * net.ks_s * 64;      // [ks_c][64]  sum_h exp(score_h) * feature_h
+    float* den = wsum + net.ks_c * 64;            // [64]        sum_h exp(score_h) (16 groups used)
+    float* vbuf = den + 64;                       // [kSarlThreads]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t tile = blockIdx.x;
+    const float* xg = X + tile * H * net.ks_x * 64;
+    zero_lds(lds, (size_t)(vbuf - lds), tid);
+    __syncthreads();
+    if (tid < kSarlGroups * 6) {  // self_state = state[:, 0, :6]
+        const int g = tid & 15, n = tid >> 4;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xg[(n >> 2) * 64 + (n & 3) * 16 + g];
+    }
+    auto stage = [&](int h0, int nh) {  // X rows of humans [h0, h0 + nh) -> bufB, zeros beyond
+        for (int i = tid; i < HC * net.ks_x * 64; i += kSarlThreads)
+            bufB[i] = (i / (net.ks_x * 64) < nh) ? xg[(size_t)h0 * net.ks_x * 64 + i] : 0.0f;
+    };
+    for (int h0 = 0; h0 < H; h0 += HC) {
+        const int nh = H - h0 < HC ? H - h0 : HC;
+        stage(h0, nh);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp1_0], bufB, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp1_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
+        __syncthreads();
+        for (int i = tid; i < net.ks_b * 64; i += kSarlThreads) {
+            float sum = gbuf[i];
+            for (int rt = 0; rt < nh; ++rt) sum += bufB[rt * net.ks_b * 64 + i];
+            gbuf[i] = sum;
+        }
+        __syncthreads();
+    }
+    if (net.with_global) {
+        for (int i = tid; i < net.ks_b * 64; i += kSarlThreads) gbuf[i] = gbuf[i] / (float)H;
+        __syncthreads();
+        dense_mfma<1>(net.L[kL_att0_global], gbuf, net.ks_b, kbuf, net.ks_a, false, nullptr, wave, lane);
+        __syncthreads();
+    }
+    const int nf = net.L[kL_mlp2_2].N;
+    for (int h0 = 0; h0 < H; h0 += HC) {
+        const int nh = H - h0 < HC ? H - h0 : HC;
+        stage(h0, nh);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp1_0], bufB, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp1_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp2_0], bufB, net.ks_b, bufA, net.ks_a, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp2_2], bufA, net.ks_a, bufC, net.ks_c, false, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_att0_local], bufB, net.ks_b, bufA, net.ks_a, true, net.with_global ? kbuf : nullptr,
+                       wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_att_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_vec1<HC>(net.L[kL_att_4], bufB, net.ks_b, sbuf, net.ks_s, vbuf, tid);
+        __syncthreads();
+        if (tid < kSarlGroups) {  // masked exp without max subtraction (sarl.py:52-53), humans in order
+            float total = den[tid];
+            for (int rt = 0; rt < nh; ++rt) {
+                const float sc = sbuf[rt * net.ks_s * 64 + tid];
+                const float e = expf(sc) * (sc != 0.0f ? 1.0f : 0.0f);
+                sbuf[rt * net.ks_s * 64 + tid] = e;
+                total += e;
+            }
+            den[tid] = total;
+        }
+        __syncthreads();
+        for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
+            const int g = i & 15, c = i >> 4;
+            const int src = (c >> 2) * 64 + (c & 3) * 16 + g;
+            float sum = wsum[src];
+            for (int rt = 0; rt < nh; ++rt) sum += sbuf[rt * net.ks_s * 64 + g] * bufC[rt * net.ks_c * 64 + src];
+            wsum[src] = sum;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
+        const int g = i & 15, c = i >> 4, n = 6 + c;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = wsum[(c >> 2) * 64 + (c & 3) * 16 + g] / den[g];
+    }
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_vec1<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, vbuf, tid);
+    __syncthreads();
+    if (tid < kSarlGroups) {
+        const size_t G = tile * kSarlGroups + tid;
+        if (G < (size_t)n_groups) V[G] = sbuf[tid];
+    }
+}
+
+constexpr int kSarlChunk = 5;  // row tiles per chunk of sarl_mlp_chunked_kernel
+__host__ inline size_t sarl_mlp_chunked_lds_bytes(const SarlNet& net) {
+    return sizeof(float) * (64 * ((size_t)kSarlChunk * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b +
+                                  2 * net.ks_a + net.ks_c + 1) + kSarlThreads);
+}
+
 template <int H>
 __global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
     extern __shared__ float lds[];

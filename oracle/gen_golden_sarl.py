@@ -25,13 +25,15 @@ def snapshot(env):
     return np.array([[a.px, a.py, a.vx, a.vy, a.gx, a.gy, a.radius, a.v_pref] for a in [env.robot] + env.humans])
 
 
-def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl', kinematics='holonomic', extra=None):
+def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl', kinematics='holonomic', extra=None,
+             human_num=5):
     rh.activate()
     torch.manual_seed(0)
     pcfg = rh.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
                                             ('lstm_rl', 'with_om'): 'true' if with_om else 'false',
                                             ('action_space', 'kinematics'): kinematics, **(extra or {})})
-    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg)
+    env, robot, policy = rh.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg,
+                                     human_num=human_num)
     policy.set_device(torch.device('cpu'))
     policy.set_phase('test')
     policy.set_env(env)
@@ -106,3 +108,4 @@ if __name__ == '__main__':
     generate('sarl_unicycle.npz', with_om=False, robot_visible=True, cases=[10, 11, 12], max_steps=10, kinematics='unicycle')
     generate('lstm_rl2_om.npz', with_om=True, robot_visible=True, cases=[13, 14], max_steps=8, policy_name='lstm_rl',
              extra={('lstm_rl', 'with_interaction_module'): 'true'})  # lstm_rl.ValueNetwork2
+    generate('sarl_h12.npz', with_om=False, robot_visible=True, cases=[15, 16], max_steps=6, human_num=12)  # streamed humans

@@ -11,6 +11,7 @@ import torch
 from conftest import load_golden
 
 FIXTURES = ['sarl_plain.npz', 'sarl_om.npz']
+SELECT_FIXTURES = FIXTURES + ['sarl_h12.npz']  # 12 humans: more than a tile's LDS holds, streamed in chunks of 5
 
 
 def _mirror(g):
@@ -42,14 +43,14 @@ def test_action_space_matches_reference_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', FIXTURES)
+@pytest.mark.parametrize('name', SELECT_FIXTURES)
 def test_sarl_select_vs_reference(name):
     import crowdnav_amd
     g = load_golden(name)
     n = len(g['states'])
     with_om = bool(int(g['with_om']))
-    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
-                                       robot_visible=int(g['robot_visible']))
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=g['states'].shape[1] - 1,
+                                       robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=int(g['robot_visible']))
     eng.set_state(g['states'], g['gtime'])
     eng.sarl_configure(actions=g['action_space'], gamma=0.9, with_om=with_om)
     eng.sarl_set_weights(_mirror(g).state_dict())
@@ -80,14 +81,17 @@ def test_sarl_select_vs_reference(name):
 
 
 @pytest.mark.gpu
-def test_sarl_mlp_vs_torch_fp32_random_inputs():
-    """The MFMA value network alone against the torch fp32 module on random states (bigger, non-fixture batch)."""
+@pytest.mark.parametrize('humans', [5, 8, 9, 20])
+def test_sarl_mlp_vs_torch_fp32_random_inputs(humans):
+    """The MFMA value network alone against the torch fp32 module on random states (bigger, non-fixture batch);
+    9 and 20 humans stream through the tile in chunks (sarl_mlp_chunked_kernel: a partial and four full chunks)."""
     import crowdnav_amd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
     torch.manual_seed(3)
     net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
     B = 37  # not a multiple of 16 groups
-    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                       robot_visible=1, circle_radius=4.0 if humans <= 9 else 10.0)
     eng.reset(1000 + np.arange(B))
     eng.step(np.zeros((B, 2)), update=True)  # humans get non-zero velocities
     space, _, _ = build_action_space(1.0)
@@ -97,7 +101,7 @@ def test_sarl_mlp_vs_torch_fp32_random_inputs():
     X = eng.sarl_export('X').cpu()
     V = eng.sarl_export('V').cpu().numpy()
     with torch.no_grad():
-        want = net(X.reshape(B * 81, 5, 13)).reshape(B, 81).numpy()
+        want = net(X.reshape(B * 81, humans, 13)).reshape(B, 81).numpy()
     assert np.abs(V - want).max() <= 2e-5
     assert np.all(out['best'].cpu().numpy() >= 0)
 
