@@ -99,7 +99,7 @@ def bench_sarl(args, world, rank, local_rank):
     flop = 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B
     step_s = sum(a.elapsed_time(b) for a, b in sel_ms) / 1e3 / steps
     out = {
-        'metric': 'env-steps/sec, 4096 envs x 5 humans, %s value-net rollout (BASELINE configs[2])' % args.workload,
+        'metric': 'env-steps/sec, %d envs x %d humans, %s value-net rollout (BASELINE configs[2])' % (B, H, args.workload),
         'value': transitions * world / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warm,
         'ms_per_step': elapsed * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (FP32 MFMA value network, f64 lookahead rewards)', 'data': 'synthetic',
@@ -248,7 +248,7 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_env_step(H) * B * (args.steps / launches)
     achieved = bytes_per_launch / avg_launch_s / 1e9
     out = {
-        'metric': 'env-steps/sec (whole node), 4096 envs x 5 humans, ORCA step',
+        'metric': 'env-steps/sec (whole node), %d envs x %d humans, ORCA step' % (B, H),
         'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 ORCA solve + f64 env step', 'data': 'synthetic',
