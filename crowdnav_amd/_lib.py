@@ -85,6 +85,7 @@ SYMBOLS = {
     'cn_get_theta': (C.c_int, [_P, _P]),
     'cn_get_human_count': (C.c_int, [_P, _P]),
     'cn_drop_robot_sim': (C.c_int, [_P]),
+    'cn_set_robot_sim': (C.c_int, [_P, _P, C.c_float]),
     'cn_reset': (C.c_int, [_P, _P, _P, _P]),
     'cn_orca': (C.c_int, [_P, _P]),
     'cn_step': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),

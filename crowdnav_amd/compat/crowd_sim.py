@@ -234,6 +234,22 @@ class CrowdSim(_Base):
         ob = [ObservableState(*(float(x) for x in row)) for row in obs]
         return ob, reward, done, info
 
+    def robot_sim_capture(self, radii=None):
+        """(radii float32 [A], maxSpeed) of the robot policy's persistent rvo2 simulator (orca.py:95-110): built at the
+        policy's first predict — and again whenever the number of agents changes — from the radii it sees THEN
+        (+ 0.01 + safety_space), never refreshed afterwards.  Kept on the policy object, like the reference's sim, so
+        the gym surface and the batched Explorer agree; only observable with randomize_attributes."""
+        pol = self.robot.policy
+        if radii is None:
+            radii = [a.radius for a in [self.robot] + self.humans]
+        cap = getattr(pol, '_rsim', None)
+        if cap is None or len(cap[0]) != len(radii):
+            safety = float(getattr(pol, 'safety_space', 0) or 0)
+            cap = (np.array([np.float32(r + 0.01 + safety) for r in radii], dtype=np.float32),
+                   float(np.float32(self.robot.v_pref)))
+            pol._rsim = cap
+        return cap
+
     def robot_orca_action(self):
         """Agent 0's ORCA velocity from the current device state (used by the device-backed ORCA policy)."""
         want = float(getattr(self.robot.policy, 'safety_space', 0) or 0)
@@ -241,6 +257,11 @@ class CrowdSim(_Base):
             s, g = self._eng.get_state()
             self._eng = self._engine(self._eng.H, self._rule)
             self._eng.set_state(s, g)
+        if self.randomize_attributes:
+            cap = self.robot_sim_capture()
+            if getattr(self._eng, '_rsim_token', None) is not cap:
+                self._eng.set_robot_sim(*cap)
+                self._eng._rsim_token = cap
         v = self._eng.orca().cpu().numpy()[0, 0]
         return float(v[0]), float(v[1])
 

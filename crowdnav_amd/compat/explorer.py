@@ -112,6 +112,7 @@ class Explorer(object):
         if is_device_orca(self.robot.policy):
             eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
             eng.set_gamma(self.gamma)
+            self._share_robot_sim(eng, human_num, rule, offset + start)
             bufs = eng.rollout_begin(seed_base=offset + start, seed_mod=size, episode_limit=k, record_capacity=per_env)
             while True:
                 eng.rollout(max_steps)
@@ -171,6 +172,7 @@ class Explorer(object):
             B = min(self.max_envs, k - c0)
             eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
             eng.sarl_configure(**policy.engine_kwargs())  # only the transform runs on this engine
+            self._share_robot_sim(eng, human_num, rule, offset + start)
             eng.reset(offset + start + c0 + np.arange(B))
             traj = torch.zeros(B, max_steps, human_num, D, dtype=torch.float32, device=eng.device)
             hist_r, hist_i, hist_d = [], [], []
@@ -227,6 +229,19 @@ class Explorer(object):
         returns = [sum([pow(self.gamma, t * dt * vp) * r for t, r in enumerate(rw)]) for rw in rewards_all]
         return (success_times, collision_times, timeout_times, collision_cases, timeout_cases, danger_n,
                 danger_sum / danger_n if danger_n else 0, returns)
+
+    def _share_robot_sim(self, eng, human_num, rule, first_seed):
+        """One persistent ORCA policy object = one captured rvo2 simulator (orca.py:95-110): every env of a batched run
+        sees the radii the policy captured at its first episode — this call's first episode if it has none yet."""
+        env = self.env
+        if not (env.randomize_attributes and is_device_orca(self.robot.policy)):
+            return  # constant radii: every capture is the same
+        cap = getattr(self.robot.policy, '_rsim', None)
+        if cap is None or len(cap[0]) != human_num + 1:
+            one = BatchedCrowdSim(**env.engine_config(1, human_num, rule, _lib.ROBOT_ORCA))
+            one.reset([first_seed])
+            cap = env.robot_sim_capture(one.get_state()[0].cpu().numpy()[0, :, 6].tolist())
+        eng.set_robot_sim(*cap)
 
     def _scenario_of(self, phase):
         env = self.env

@@ -373,6 +373,31 @@ int cn_get_human_count(cn_engine* e, int32_t* count) {
     return CN_OK;
 }
 
+namespace {
+__global__ void set_robot_sim_kernel(int B, int A, const float* radii, float max_speed, cn::StateView S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * A) return;
+    S.rsim_radius[i] = radii[i % A];
+    if (i % A == 0) {
+        S.rsim_max_speed[i / A] = max_speed;
+        S.rsim_valid[i / A] = 1;
+    }
+}
+}  // namespace
+
+int cn_set_robot_sim(cn_engine* e, const float* radii_host, float max_speed) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if (!radii_host) return fail(CN_ERR_INVALID, "cn_set_robot_sim: NULL");
+    float* staged = reinterpret_cast<float*>(e->probe_key);  // 624 words of scratch, A <= 64
+    CN_HIP(hipMemcpyAsync(staged, radii_host, sizeof(float) * e->P.A, hipMemcpyHostToDevice, e->stream));
+    CN_HIP(hipStreamSynchronize(e->stream));  // radii_host may be a temporary
+    hipLaunchKernelGGL(set_robot_sim_kernel, dim3((e->P.B * e->P.A + 255) / 256), dim3(256), 0, e->stream, e->P.B, e->P.A,
+                       staged, max_speed, e->S);
+    CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
 int cn_drop_robot_sim(cn_engine* e) {
     int rc = bind(e);
     if (rc) return rc;

@@ -114,6 +114,12 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_get_human_count(self._h, _ptr(n)))
         return n
 
+    def set_robot_sim(self, radii, max_speed):
+        """Every env gets the same captured robot simulator: radii float32 [A] (radius + 0.01 + safety_space as the
+        persistent ORCA policy first saw them), max_speed (cn_set_robot_sim)."""
+        r = np.ascontiguousarray(radii, dtype=np.float32).reshape(self.A)
+        check(self._lib.cn_set_robot_sim(self._h, r.ctypes.data_as(C.c_void_p), C.c_float(float(max_speed))))
+
     def drop_robot_sim(self):
         check(self._lib.cn_drop_robot_sim(self._h))
 

@@ -109,6 +109,12 @@ int cn_get_theta(cn_engine* e, double* theta);
 int cn_get_human_count(cn_engine* e, int32_t* count);
 /* forget the robot ORCA policy's captured radii (a new policy object; orca.py:95-104) */
 int cn_drop_robot_sim(cn_engine* e);
+/* The opposite: give every env the SAME captured simulator — radii host float32 [num_humans + 1] (robot, humans) as
+ * the robot's rvo2 simulator holds them (radius + 0.01 + safety_space), max_speed its maxSpeed.  This is what one
+ * persistent ORCA policy object means for a batch: the reference builds the simulator at the policy's first predict and
+ * keeps those radii for every later episode (orca.py:95-110), so k episodes run as a batch must all see the radii of
+ * the policy's first episode (only observable with randomize_attributes). */
+int cn_set_robot_sim(cn_engine* e, const float* radii_host, float max_speed);
 
 /* replaces CrowdSim.reset (crowd_sim.py:251-312) for the envs with mask[b] != 0 (mask NULL = all):
  * np.random.seed(seeds[b]) + generate_random_human_position, numpy-MT19937-compatible, on device.

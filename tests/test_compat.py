@@ -204,3 +204,42 @@ def test_example_test_policy_script():
     assert round(stats['nav_time'], 2) == 10.86
     one = mod.run(mod.parser().parse_args(['--policy', 'orca', '--visible', '--test-case', '1']))
     assert 'reach' in one['info'].lower() and len(one['human_times']) == 5 and all(t > 0 for t in one['human_times'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['persistent_orca.npz', 'persistent_orca_visible.npz'])
+def test_persistent_orca_policy_with_random_attributes(name):
+    """[env] randomize_attributes = true: the reference's ONE robot ORCA policy keeps the radii of the first episode's
+    humans in its rvo2 simulator for every later episode (orca.py:95-110).  The batched Explorer shares that capture
+    across its envs (cn_set_robot_sim) and so reproduces the unmodified reference case by case; so does the sequential
+    loop on the gym surface."""
+    from conftest import load_golden
+    import crowdnav_amd.compat as c
+    g = load_golden(name)
+    k = int(g['k'])
+
+    def make():
+        cfg = c.default_env_config({('robot', 'visible'): 'true' if int(g['robot_visible']) else 'false',
+                                    ('env', 'randomize_attributes'): 'true'})
+        env = c.CrowdSim()
+        env.configure(cfg)
+        robot = c.Robot(cfg, 'robot')
+        robot.set_policy(c.policy_factory['orca']())
+        env.set_robot(robot)
+        return c, env, robot
+
+    c_, env, robot = make()
+    ex = c_.Explorer(env, robot, 'cpu', gamma=0.9)
+    ex.run_k_episodes(k, 'test')
+    lb = ex.last_batch
+    assert lb['outcome'] == g['outcome'].tolist() and lb['steps'] == g['steps'].tolist()
+    assert np.abs(np.array(lb['discounted_return']) - g['returns']).max() <= 1e-9
+    assert np.allclose(robot.policy._rsim[0], np.float32(g['first_radii'] + 0.01), rtol=0, atol=0)
+    # the same through env.reset / robot.act / env.step
+    c_, env, robot = make()
+    ex = c_.Explorer(env, robot, 'cpu', gamma=0.9)
+    robot.policy.set_phase('test')
+    stats = ex._run_sequential(12, 'test', False, False)
+    want = g['outcome'][:12]
+    assert len(stats[0]) == int((want == 2).sum()) and len(stats[1]) == int((want == 3).sum())
+    assert np.abs(np.array(stats[-1]) - g['returns'][:12]).max() <= 1e-9
