@@ -64,7 +64,7 @@ __device__ unsigned long long cn_sarl_cycles[16];
 constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
 constexpr int kSarlMaxHumans = 8;    // register arrays of the occupancy map / LSTM-RL ordering; more humans: SARL without maps
                                      // (sarl_mlp_chunked_kernel streams them; one-tile kernels hold up to 5 at the shipped widths)
-constexpr int kSarlThreads = 1024;   // 8 waves per MLP workgroup (2 per SIMD: one wave's LDS/L2 waits hide behind the other's MFMAs)
+constexpr int kSarlThreads = 1024;   // 16 waves per MLP workgroup (4 per SIMD: one wave's LDS/L2 waits hide behind the others' MFMAs)
 constexpr int kSarlKChunk = 5;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time): K = 100 is 25 k-steps
 constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
 
@@ -436,9 +436,9 @@ __global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_k
 
 // ------------------------------------------------------------------------------------ value network
 // Dense layer on MFMA: out[r][n] = act(bias[n] + extra[g][n] + sum_k in[r][k] W[n][k]) for r in [0, RT*16), buffers in
-// fragment order (ks_in / ks_out k-steps per row tile).  A wave owns whole column tiles (ct = wave, wave + 4, ..)
+// fragment order (ks_in / ks_out k-steps per row tile).  A wave owns whole column tiles (ct = wave, wave + 16, ..)
 // and all RT row tiles of them: per k-step it reads RT A fragments from LDS (conflict-free) and issues RT
-// independent MFMAs; the B fragments of the NEXT 8 k-steps are already in flight from L2 (register double buffer).
+// independent MFMAs; the B fragments of the next trip are already in flight from L2 (register double buffer).
 template <int RT>
 __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* in, int ks_in, float* out, int ks_out,
                                            bool relu, const float* extra, int wave, int lane) {
@@ -455,7 +455,7 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-        // Straight-line k loop, 4 k-steps per trip, no conditionals (kpad <= ks_in by construction: every buffer
+        // Straight-line k loop, kSarlKChunk k-steps per trip, no conditionals (kpad <= ks_in by construction: every buffer
         // holds whole column tiles of its producer, zero beyond the true width, and the packed weights are zero
         // there too).  The B fragments of the next trip are requested before this trip's MFMAs issue; the
         // packed buffer carries one spare chunk so the last request stays in bounds.
