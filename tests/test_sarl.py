@@ -81,27 +81,28 @@ def test_sarl_select_vs_reference(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('humans', [5, 8, 9, 20])
-def test_sarl_mlp_vs_torch_fp32_random_inputs(humans):
+@pytest.mark.parametrize('humans,with_om', [(5, False), (8, False), (9, False), (20, False), (7, True)])
+def test_sarl_mlp_vs_torch_fp32_random_inputs(humans, with_om):
     """The MFMA value network alone against the torch fp32 module on random states (bigger, non-fixture batch);
     9 and 20 humans stream through the tile in chunks (sarl_mlp_chunked_kernel: a partial and four full chunks)."""
     import crowdnav_amd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
     torch.manual_seed(3)
-    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    d = 61 if with_om else 13
+    net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
     B = 37  # not a multiple of 16 groups
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
                                        robot_visible=1, circle_radius=4.0 if humans <= 9 else 10.0)
     eng.reset(1000 + np.arange(B))
     eng.step(np.zeros((B, 2)), update=True)  # humans get non-zero velocities
     space, _, _ = build_action_space(1.0)
-    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
     eng.sarl_set_weights(net.state_dict())
     out = eng.sarl_select()
     X = eng.sarl_export('X').cpu()
     V = eng.sarl_export('V').cpu().numpy()
     with torch.no_grad():
-        want = net(X.reshape(B * 81, humans, 13)).reshape(B, 81).numpy()
+        want = net(X.reshape(B * 81, humans, d)).reshape(B, 81).numpy()
     assert np.abs(V - want).max() <= 2e-5
     assert np.all(out['best'].cpu().numpy() >= 0)
 
