@@ -524,7 +524,13 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     else
         hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
-    CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
+    const cn::Params& P = e->P;
+    if (e->maxl == 5 && !P.robot_unicycle && P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 &&
+        P.threads == 64)  // BASELINE configs[1]: the instantiation with this geometry folded in
+        hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S,
+                           R, n_steps, (const double*)nullptr);
+    else
+        CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
     CN_HIP(hipGetLastError());
     e->steps_since_fill = 0;
     return CN_OK;

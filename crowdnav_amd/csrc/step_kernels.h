@@ -805,9 +805,16 @@ __device__ __forceinline__ int finish_episode(const RolloutView R, int env, int 
 #ifndef CN_MAXL10_WAVES
 #define CN_MAXL10_WAVES 1
 #endif
-template <int MAXL, bool UNI>
-__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void rollout_kernel(Params P, StateView S, RolloutView R, int n_steps,
+template <int MAXL, bool UNI, bool HEADLINE = false>
+__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void rollout_kernel(Params P_in, StateView S, RolloutView R, int n_steps,
                                                             const double* ext_action) {
+    // HEADLINE: the geometry of BASELINE configs[1] (5 humans + robot, 2 envs per 64-lane workgroup) as compile-time
+    // constants — the pair loops become single passes, the 5-candidate rank loop unrolls, divisions by A / NC fold:
+    // 706 -> 740 M env-steps/s.  Every other geometry runs the generic instantiation.
+    Params P = P_in;
+    if (HEADLINE) {
+        P.A = 6, P.NC = 5, P.E = 2, P.nA = 12, P.pairs = 60, P.threads = 64;
+    }
     const Smem s = carve(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};

@@ -370,7 +370,7 @@ def test_minimum_and_maximum_crowd_sizes(amd, oracle_mod, humans, radius):
     assert np.array_equal(_np(eng.get_state()[0]), o.get_state()[0])
 
 
-@pytest.mark.parametrize('envs_per_wave,waves', [(3, 1), (4, 2), (10, 5)])
+@pytest.mark.parametrize('envs_per_wave,waves', [(2, 1), (3, 1), (4, 2), (10, 5)])  # (2, 1) = the HEADLINE instantiation
 def test_ragged_last_workgroup_and_geometry_knobs(amd, oracle_mod, monkeypatch, envs_per_wave, waves):
     """B not a multiple of the envs per workgroup (last workgroup partly empty) and multi-wave workgroups: the
     geometry is a pure performance knob — results identical to the oracle whatever it is."""
