@@ -22,6 +22,8 @@ from crowdnav_amd.compat.trainer import DeviceReplayMemory, ReplayMemory, Traine
 
 
 def run(args):
+    if args.seed is not None:  # the reference does not seed torch; runs then differ in initial weights and batch order
+        torch.manual_seed(args.seed)
     device = torch.device('cuda:0' if args.gpu and torch.cuda.is_available() else 'cpu')
     env_cfg = cn.default_env_config({('env', 'val_size'): args.val_size, ('env', 'test_size'): args.test_size})
     policy = cn.policy_factory[args.policy]()
@@ -109,6 +111,7 @@ def parser():
     ap.add_argument('--policy', choices=['sarl', 'cadrl', 'lstm_rl'], default='sarl')
     ap.add_argument('--with-om', action='store_true')
     ap.add_argument('--output-dir', default=None)
+    ap.add_argument('--seed', type=int, default=None, help='torch.manual_seed (weights, batch order); default: unseeded')
     ap.add_argument('--timing-json', default=None, help='write losses, final stats and per-phase wall-clock here')
     for name, default in (('il-episodes', 3000), ('il-epochs', 50), ('train-episodes', 10000), ('train-batches', 100),
                           ('sample-episodes', 1), ('target-update-interval', 50), ('evaluation-interval', 1000),
