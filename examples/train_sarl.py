@@ -55,17 +55,35 @@ def run(args):
         timing[key] += time.perf_counter() - t0
         return out
 
-    # imitation learning from ORCA demonstrations (train.py:115-132)
-    trainer.set_learning_rate(args.il_learning_rate)
-    il_policy = cn.policy_factory['orca']()
-    il_policy.multiagent_training = policy.multiagent_training
-    il_policy.safety_space = 0 if robot.visible else args.safety_space
-    robot.set_policy(il_policy)
-    env.set_robot(robot)
-    timed('il_collect_s', explorer.run_k_episodes, args.il_episodes, 'train', update_memory=True, imitation_learning=True)
-    timing['il_env_steps'] = int((explorer.last_batch or {}).get('env_steps', 0))
-    il_loss = timed('il_sgd_s', trainer.optimize_epoch, args.il_epochs)
-    logging.info('Finish imitation learning. Experience set size: %d/%d', len(memory), memory.capacity)
+    if args.output_dir:
+        os.makedirs(args.output_dir, exist_ok=True)
+    il_weights = os.path.join(args.output_dir, 'il_model.pth') if args.output_dir else None
+    rl_weights = os.path.join(args.output_dir, 'rl_model.pth') if args.output_dir else None
+    il_loss = None
+    if args.resume:  # train.py:106-111: continue from the RL weights, write to resumed_rl_model.pth
+        if not (rl_weights and os.path.exists(rl_weights)):
+            raise SystemExit('--resume needs --output-dir with rl_model.pth')
+        model.load_state_dict(torch.load(rl_weights, map_location=device))
+        rl_weights = os.path.join(args.output_dir, 'resumed_rl_model.pth')
+        logging.info('Load reinforcement learning trained weights. Resume training')
+    elif il_weights and os.path.exists(il_weights):  # :112-114
+        model.load_state_dict(torch.load(il_weights, map_location=device))
+        logging.info('Load imitation learning trained weights.')
+    else:
+        # imitation learning from ORCA demonstrations (train.py:115-132)
+        trainer.set_learning_rate(args.il_learning_rate)
+        il_policy = cn.policy_factory['orca']()
+        il_policy.multiagent_training = policy.multiagent_training
+        il_policy.safety_space = 0 if robot.visible else args.safety_space
+        robot.set_policy(il_policy)
+        env.set_robot(robot)
+        timed('il_collect_s', explorer.run_k_episodes, args.il_episodes, 'train', update_memory=True,
+              imitation_learning=True)
+        timing['il_env_steps'] = int((explorer.last_batch or {}).get('env_steps', 0))
+        il_loss = timed('il_sgd_s', trainer.optimize_epoch, args.il_epochs)
+        if il_weights:
+            torch.save(model.state_dict(), il_weights)
+        logging.info('Finish imitation learning. Experience set size: %d/%d', len(memory), memory.capacity)
     explorer.update_target_model(model)
 
     # reinforcement learning (train.py:134-170)
@@ -73,9 +91,15 @@ def run(args):
     robot.set_policy(policy)
     env.set_robot(robot)
     trainer.set_learning_rate(args.rl_learning_rate)
+    if args.resume:  # :141-145: fill the memory pool with some RL experience first
+        robot.policy.set_epsilon(args.epsilon_end)
+        timed('rl_sample_s', explorer.run_k_episodes, 100, 'train', update_memory=True, episode=0)
+        logging.info('Experience set size: %d/%d', len(memory), memory.capacity)
     episode, rl_loss = 0, None
     while episode < args.train_episodes:
-        if episode < args.epsilon_decay:
+        if args.resume:
+            epsilon = args.epsilon_end
+        elif episode < args.epsilon_decay:
             epsilon = args.epsilon_start + (args.epsilon_end - args.epsilon_start) / args.epsilon_decay * episode
         else:
             epsilon = args.epsilon_end
@@ -89,8 +113,8 @@ def run(args):
         episode += 1
         if episode % args.target_update_interval == 0:
             explorer.update_target_model(model)
-        if args.output_dir and episode % args.checkpoint_interval == 0:
-            torch.save(model.state_dict(), os.path.join(args.output_dir, 'rl_model.pth'))
+        if rl_weights and episode % args.checkpoint_interval == 0:
+            torch.save(model.state_dict(), rl_weights)
     timed('eval_s', explorer.run_k_episodes, env.case_size['test'], 'test', episode=episode)
     timing['eval_episodes'] += env.case_size['test']
     if timing['rl_sample_s'] > 0:
@@ -110,7 +134,8 @@ def parser():
     ap.add_argument('--gpu', action='store_true', help='keep the torch model / trainer on cuda:0 (rollouts always are)')
     ap.add_argument('--policy', choices=['sarl', 'cadrl', 'lstm_rl'], default='sarl')
     ap.add_argument('--with-om', action='store_true')
-    ap.add_argument('--output-dir', default=None)
+    ap.add_argument('--output-dir', default=None, help='il_model.pth / rl_model.pth as train.py writes them')
+    ap.add_argument('--resume', action='store_true', help='continue from <output-dir>/rl_model.pth (train.py:106-111)')
     ap.add_argument('--seed', type=int, default=None, help='torch.manual_seed (weights, batch order); default: unseeded')
     ap.add_argument('--timing-json', default=None, help='write losses, final stats and per-phase wall-clock here')
     for name, default in (('il-episodes', 3000), ('il-epochs', 50), ('train-episodes', 10000), ('train-batches', 100),

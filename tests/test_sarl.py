@@ -226,6 +226,29 @@ def test_train_schedule_smoke_config5(policy):
 
 
 @pytest.mark.gpu
+def test_train_checkpoints_and_resume(tmp_path):
+    """train.py's weight files (il_model.pth after imitation learning, rl_model.pth every checkpoint_interval) and
+    --resume (load rl_model.pth, 100 warm-up episodes at epsilon_end, write resumed_rl_model.pth), train.py:106-145."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('train_sarl', os.path.join(ROOT, 'examples', 'train_sarl.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    common = ['--il-episodes', '6', '--il-epochs', '2', '--train-episodes', '2', '--train-batches', '2',
+              '--evaluation-interval', '5', '--val-size', '3', '--test-size', '3', '--checkpoint-interval', '1',
+              '--batch-size', '16', '--output-dir', str(tmp_path)]
+    first = mod.run(mod.parser().parse_args(common))
+    assert first['il_loss'] is not None and (tmp_path / 'il_model.pth').exists() and (tmp_path / 'rl_model.pth').exists()
+    again = mod.run(mod.parser().parse_args(common))          # il_model.pth is there: imitation learning is skipped
+    assert again['il_loss'] is None and again['timing']['il_collect_s'] == 0.0
+    resumed = mod.run(mod.parser().parse_args(common + ['--resume']))
+    assert (tmp_path / 'resumed_rl_model.pth').exists() and resumed['memory'] > 0 and resumed['il_loss'] is None
+    state = torch.load(tmp_path / 'resumed_rl_model.pth', map_location='cpu')
+    assert 'mlp1.0.weight' in state and 'mlp3.6.bias' in state  # the reference's state_dict keys
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name,with_om', [('sarl', False), ('sarl', True), ('cadrl', False), ('lstm_rl', True)])
 def test_batched_imitation_collection_equals_sequential(name, with_om):
     """Explorer.run_k_episodes(k, 'train', update_memory=True, imitation_learning=True): the lock-step batched
