@@ -21,14 +21,45 @@ from crowdnav_amd.compat.sarl import default_policy_config  # noqa: E402
 from crowdnav_amd.compat.trainer import DeviceReplayMemory, ReplayMemory, Trainer  # noqa: E402
 
 
+def read_ini(path):
+    import configparser
+    cfg = configparser.RawConfigParser()
+    if not cfg.read(path):
+        raise SystemExit('cannot read %s' % path)
+    return cfg
+
+
+def apply_train_config(args, path):
+    """crowd_nav/configs/train.config -> the flags of this script (same names, train.py:86-96, 116-121)."""
+    cfg = read_ini(path)
+    for sec, keys, cast in (('trainer', ('batch_size',), int),
+                            ('imitation_learning', ('il_episodes', 'il_epochs'), int),
+                            ('imitation_learning', ('il_learning_rate', 'safety_space'), float),
+                            ('train', ('train_batches', 'train_episodes', 'sample_episodes', 'target_update_interval',
+                                       'evaluation_interval', 'capacity', 'epsilon_decay', 'checkpoint_interval'), int),
+                            ('train', ('rl_learning_rate', 'epsilon_start', 'epsilon_end'), float)):
+        for key in keys:
+            if cfg.has_option(sec, key):
+                setattr(args, key, cast(cfg.get(sec, key)))
+    return args
+
+
 def run(args):
+    if args.train_config:
+        args = apply_train_config(args, args.train_config)
     if args.seed is not None:  # the reference does not seed torch; runs then differ in initial weights and batch order
         torch.manual_seed(args.seed)
     device = torch.device('cuda:0' if args.gpu and torch.cuda.is_available() else 'cpu')
-    env_cfg = cn.default_env_config({('env', 'val_size'): args.val_size, ('env', 'test_size'): args.test_size})
+    if args.env_config:  # the reference's own INI files are accepted as they are (train.py:28-30, 60-75)
+        env_cfg = read_ini(args.env_config)
+    else:
+        env_cfg = cn.default_env_config({('env', 'val_size'): args.val_size, ('env', 'test_size'): args.test_size})
     policy = cn.policy_factory[args.policy]()
-    policy.configure(default_policy_config({(args.policy, 'with_om'): 'true' if args.with_om else 'false'}
-                                           if args.policy != 'cadrl' else None))
+    if args.policy_config:
+        policy.configure(read_ini(args.policy_config))
+    else:
+        policy.configure(default_policy_config({(args.policy, 'with_om'): 'true' if args.with_om else 'false'}
+                                               if args.policy != 'cadrl' else None))
     policy.set_device(device)
     env = cn.CrowdSim()
     env.configure(env_cfg)
@@ -134,6 +165,8 @@ def parser():
     ap.add_argument('--gpu', action='store_true', help='keep the torch model / trainer on cuda:0 (rollouts always are)')
     ap.add_argument('--policy', choices=['sarl', 'cadrl', 'lstm_rl'], default='sarl')
     ap.add_argument('--with-om', action='store_true')
+    for name in ('env-config', 'policy-config', 'train-config'):
+        ap.add_argument('--' + name, default=None, help='the reference\'s crowd_nav/configs/%s file' % name.replace('-', '.'))
     ap.add_argument('--output-dir', default=None, help='il_model.pth / rl_model.pth as train.py writes them')
     ap.add_argument('--resume', action='store_true', help='continue from <output-dir>/rl_model.pth (train.py:106-111)')
     ap.add_argument('--seed', type=int, default=None, help='torch.manual_seed (weights, batch order); default: unseeded')

@@ -243,3 +243,38 @@ def test_persistent_orca_policy_with_random_attributes(name):
     want = g['outcome'][:12]
     assert len(stats[0]) == int((want == 2).sum()) and len(stats[1]) == int((want == 3).sum())
     assert np.abs(np.array(stats[-1]) - g['returns'][:12]).max() <= 1e-9
+
+
+def test_train_example_reads_the_reference_ini_files_cpu(tmp_path):
+    """examples/train_sarl.py --env-config / --policy-config / --train-config take the reference's INI files as they
+    are (crowd_nav/configs/*.config): same sections and keys."""
+    import configparser
+    import importlib.util
+    import os
+    from conftest import ROOT
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import default_policy_config
+    spec = importlib.util.spec_from_file_location('train_sarl', os.path.join(ROOT, 'examples', 'train_sarl.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    train = configparser.RawConfigParser()
+    train.read_dict({'trainer': dict(batch_size=64),
+                     'imitation_learning': dict(il_episodes=7, il_policy='orca', il_epochs=3, il_learning_rate=0.02,
+                                                safety_space=0.2),
+                     'train': dict(rl_learning_rate=0.005, train_batches=9, train_episodes=11, sample_episodes=2,
+                                   target_update_interval=4, evaluation_interval=6, capacity=500, epsilon_start=0.4,
+                                   epsilon_end=0.2, epsilon_decay=8, checkpoint_interval=5)})
+    for name, cfg in (('train.config', train), ('env.config', c.default_env_config()),
+                      ('policy.config', default_policy_config())):
+        with open(tmp_path / name, 'w') as f:
+            cfg.write(f)
+    args = mod.apply_train_config(mod.parser().parse_args([]), str(tmp_path / 'train.config'))
+    assert (args.batch_size, args.il_episodes, args.il_epochs, args.train_batches, args.train_episodes) == (64, 7, 3, 9, 11)
+    assert (args.il_learning_rate, args.safety_space, args.rl_learning_rate, args.epsilon_end) == (0.02, 0.2, 0.005, 0.2)
+    assert (args.capacity, args.epsilon_decay, args.target_update_interval, args.sample_episodes) == (500, 8, 4, 2)
+    env = c.CrowdSim()
+    env.configure(mod.read_ini(str(tmp_path / 'env.config')))
+    assert env.time_limit == 25 and env.human_num == 5 and env.case_size['test'] == 500
+    policy = c.policy_factory['sarl']()
+    policy.configure(mod.read_ini(str(tmp_path / 'policy.config')))
+    assert policy.gamma == 0.9 and policy.multiagent_training and not policy.with_om
