@@ -21,12 +21,23 @@ from crowdnav_amd.compat.policy import ORCA  # noqa: E402
 from crowdnav_amd.compat.sarl import default_policy_config  # noqa: E402
 
 
+def read_ini(path):
+    import configparser
+    cfg = configparser.RawConfigParser()
+    if not cfg.read(path):
+        raise SystemExit('cannot read %s' % path)
+    return cfg
+
+
 def run(args):
     device = torch.device('cuda:0' if args.gpu and torch.cuda.is_available() else 'cpu')
-    env_cfg = cn.default_env_config({('robot', 'visible'): 'true' if args.visible else 'false'})
+    if args.env_config:  # the reference's own INI files are accepted as they are (test.py:16-17, 42-55)
+        env_cfg = read_ini(args.env_config)
+    else:
+        env_cfg = cn.default_env_config({('robot', 'visible'): 'true' if args.visible else 'false'})
     policy = cn.policy_factory[args.policy]()
     overrides = {(args.policy, 'with_om'): 'true'} if args.with_om and args.policy in ('sarl', 'lstm_rl') else {}
-    policy.configure(default_policy_config(overrides))
+    policy.configure(read_ini(args.policy_config) if args.policy_config else default_policy_config(overrides))
     if policy.trainable:
         if args.weights:
             policy.get_model().load_state_dict(torch.load(args.weights, map_location='cpu'))
@@ -72,6 +83,8 @@ def parser():
     ap.add_argument('--policy', default='orca', choices=['orca', 'linear', 'sarl', 'cadrl', 'lstm_rl'])
     ap.add_argument('--weights', default=None, help='state_dict of the value network (the reference\'s rl_model.pth)')
     ap.add_argument('--with-om', action='store_true')
+    ap.add_argument('--env-config', default=None, help="the reference's crowd_nav/configs/env.config")
+    ap.add_argument('--policy-config', default=None, help="the reference's crowd_nav/configs/policy.config")
     ap.add_argument('--gpu', action='store_true', help='keep the torch model on cuda:0 (rollouts always are)')
     ap.add_argument('--phase', default='test', choices=['train', 'val', 'test'])
     ap.add_argument('--test-case', type=int, default=None)
