@@ -183,5 +183,11 @@ def parser():
 
 
 if __name__ == '__main__':
-    logging.basicConfig(level=logging.INFO, format='%(asctime)s, %(levelname)s: %(message)s', datefmt='%Y-%m-%d %H:%M:%S')
-    print(run(parser().parse_args()))
+    cli = parser().parse_args()
+    handlers = [logging.StreamHandler(sys.stdout)]
+    if cli.output_dir:  # train.py:51-56: output.log next to the weights — what crowd_nav/utils/plot.py parses
+        os.makedirs(cli.output_dir, exist_ok=True)
+        handlers.append(logging.FileHandler(os.path.join(cli.output_dir, 'output.log'), mode='a' if cli.resume else 'w'))
+    logging.basicConfig(level=logging.INFO, handlers=handlers, format='%(asctime)s, %(levelname)s: %(message)s',
+                        datefmt='%Y-%m-%d %H:%M:%S')
+    print(run(cli))
