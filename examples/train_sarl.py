@@ -140,7 +140,8 @@ def run(args):
             timing['eval_episodes'] += env.case_size['val']
         timed('rl_sample_s', explorer.run_k_episodes, args.sample_episodes, 'train', update_memory=True, episode=episode)
         timing['rl_env_steps'] += int((explorer.last_batch or {}).get('env_steps', 0))
-        rl_loss = timed('rl_sgd_s', trainer.optimize_batch, args.train_batches)
+        if len(memory):  # (the reference's DataLoader raises on an empty memory: nothing reached a goal or collided yet)
+            rl_loss = timed('rl_sgd_s', trainer.optimize_batch, args.train_batches)
         episode += 1
         if episode % args.target_update_interval == 0:
             explorer.update_target_model(model)

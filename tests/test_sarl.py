@@ -237,7 +237,7 @@ def test_train_checkpoints_and_resume(tmp_path):
     spec.loader.exec_module(mod)
     common = ['--il-episodes', '6', '--il-epochs', '2', '--train-episodes', '2', '--train-batches', '2',
               '--evaluation-interval', '5', '--val-size', '3', '--test-size', '3', '--checkpoint-interval', '1',
-              '--batch-size', '16', '--output-dir', str(tmp_path)]
+              '--batch-size', '16', '--sample-episodes', '8', '--output-dir', str(tmp_path)]
     first = mod.run(mod.parser().parse_args(common))
     assert first['il_loss'] is not None and (tmp_path / 'il_model.pth').exists() and (tmp_path / 'rl_model.pth').exists()
     again = mod.run(mod.parser().parse_args(common))          # il_model.pth is there: imitation learning is skipped
