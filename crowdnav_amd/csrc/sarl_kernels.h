@@ -61,6 +61,7 @@ __device__ unsigned long long cn_sarl_cycles[16];
     } while (0)
 #endif
 
+constexpr int kWaveSize = 64;        // gfx950 wavefront
 constexpr int kSarlGroups = 16;      // (env, action) groups per MLP tile = MFMA tile height
 constexpr int kSarlMaxHumans = 8;    // register arrays of the occupancy map / LSTM-RL ordering; more humans: SARL without maps
                                      // (sarl_mlp_chunked_kernel streams them; one-tile kernels hold up to 5 at the shipped widths)
@@ -892,19 +893,32 @@ __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
 __global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2* goal, const double2* rv,
                                    const double* actions, const double* reward, const float* V, double* values,
                                    int* best, double* action_out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per env: lanes stride over the actions, then a butterfly keeps the largest value, lowest index on ties
+    // (= the first strict maximum of the reference's loop; NaN and -inf never win: `value > max_value` is false)
+    const int b = blockIdx.x * (blockDim.x / kWaveSize) + (threadIdx.x / kWaveSize);
+    const int lane = threadIdx.x & (kWaveSize - 1);
     if (b >= C.B) return;
-    const size_t g0 = (size_t)b * (C.H + 1);
-    int arg = -1;
-    double best_v = -__builtin_inf();
-    for (int a = 0; a < C.n_actions; ++a) {
+    double bv = -__builtin_inf();
+    int bi = -1;
+    for (int a = lane; a < C.n_actions; a += kWaveSize) {
         const double v = reward[(size_t)b * C.n_actions + a] + C.gamma_bar * (double)V[(size_t)b * C.n_actions + a];
         if (values) values[(size_t)b * C.n_actions + a] = v;
-        if (v > best_v) {
-            best_v = v;
-            arg = a;
+        if (v > bv) {
+            bv = v;
+            bi = a;
         }
     }
+#pragma unroll
+    for (int off = kWaveSize / 2; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi));
+        bv = take ? ov : bv;
+        bi = take ? oi : bi;
+    }
+    if (lane != 0) return;
+    const size_t g0 = (size_t)b * (C.H + 1);
+    int arg = bi;
     const double dy = pos[g0].y - goal[g0].y, dx = pos[g0].x - goal[g0].x;
     const bool arrived = norm2(dy, dx) < rv[g0].x;  // np.linalg.norm((py - gy, px - gx))
     if (arrived) arg = -1;
