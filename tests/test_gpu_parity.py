@@ -518,3 +518,16 @@ def test_free_running_soak_vs_oracle(amd, oracle_mod, humans, envs, rounds, radi
                 assert np.array_equal(_np(got[k]), want[k]), (k, r, t)
         s, g = (_np(x) for x in eng.get_state())
         assert np.array_equal(s, o.get_state()[0]) and np.array_equal(g, o.get_state()[1])
+
+
+@pytest.mark.gpu
+def test_survey_known_answer_velocities_on_device(amd):
+    """The same known-answer vectors (an independent float32 restatement of RVO2) through cn_step."""
+    from test_oracle_golden import SURVEY_KAT_CASE0
+    g = load_golden('resets.npz')
+    eng = amd.BatchedCrowdSim(num_envs=1, num_humans=5, robot_policy=amd.ROBOT_ORCA, robot_visible=0)
+    eng.set_state(g['test_h5_states'][:1], np.zeros(1))
+    for action, hexes in SURVEY_KAT_CASE0:
+        out = eng.step(None, update=True, want_obs=False)
+        assert tuple(_np(out['action'])[0]) == action and _np(out['reward'])[0] == 0.0
+        assert ' '.join(v.tobytes().hex() for v in _np(out['orca_vel'])[0][1:]) == hexes

@@ -118,3 +118,27 @@ def test_unicycle_robot_steps_vs_reference(oracle_mod):
     assert np.abs(state - g['next_states']).max() <= 1e-12
     assert np.abs(o.get_theta() - g['next_theta']).max() <= 1e-12
     assert np.array_equal(state[:, 1:], g['next_states'][:, 1:])  # humans do not depend on the robot's kinematics
+
+
+SURVEY_KAT_CASE0 = [  # test case 0, ORCA robot, robot invisible — an INDEPENDENT float32 restatement
+    ((-0.051465511322021484, 0.45335352420806885),
+     '7424d63eb76eca3e 54b22d3f3cac3d3c 8e4c2cbf7e45a4bd cef9a9be10f4113f 100e253ff8dc75be'),
+    ((0.08838461339473724, 0.512067437171936),
+     '937cd13e6ac1e13e d51f243f9bd3923c ea9c24bf57a289bd b972adbe7e250a3f e88f313f5b7393be'),
+    ((0.07480747997760773, 0.5604285597801208),
+     'ff69c03e5c7df23e c2471a3fb26bff3c efb71dbfd3e653bd f3b4a1be45cd053f 8fbd533fe931aabe'),
+]
+
+
+def test_survey_known_answer_velocities(oracle_mod):
+    """Two independent restatements of RVO2 (the survey's throw-away Python float32 one and this C++ oracle) agree bit
+    for bit on the first three steps of test case 0 — robot action and every human's ORCA velocity as float32 hex."""
+    g = load_golden('resets.npz')
+    assert int(g['test_h5_seeds'][0]) == 1000
+    o = oracle_mod.CrowdOracle(num_envs=1, num_humans=5, robot_policy=1, robot_visible=0)
+    o.set_state(g['test_h5_states'][:1], np.zeros(1))
+    for action, hexes in SURVEY_KAT_CASE0:
+        out = o.step(None, update=True)
+        assert tuple(out['action'][0]) == action and out['reward'][0] == 0.0
+        assert ' '.join(v.tobytes().hex() for v in out['orca_vel'][0][1:]) == hexes
+    assert tuple(o.get_state()[0][0][1][:2]) != (0.0, 0.0)
