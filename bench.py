@@ -2,21 +2,30 @@
 
 A "step" is one transition of EVERY env of the batch (4096 envs x 5 humans per GPU, ORCA humans + holonomic
 ORCA robot, in-kernel auto-reset): `--steps K` executes exactly K such batched steps per rank after W warm-up
-steps, in fused launches of `--chunk` steps each.  value = total env transitions of all ranks / wall time.
+steps, in fused launches of at most `--chunk` steps each.  value = total env transitions of all ranks / wall time.
 
     python bench.py                                        # 1 GPU
+    python bench.py --gpus N [--steps K --warmup W]        # N GPUs: re-executes itself as N ranks (127.0.0.1 rendezvous)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W             # N GPUs, one rank per GPU (RCCL)
+        bench.py --gpus N --steps K --warmup W             # the same under an external launcher (RANK/WORLD_SIZE set)
 
-Multi-GPU: the env axis is sharded (weak scaling: 4096 envs per GPU, global env ids offset by rank, no
-collective on the step path); the only exchange is one all-gather (RCCL) of the per-rank episode summaries
-at the end, inside the timed region.  The JSON line also carries `roofline` (algorithmic bytes of the
-dominant kernel over its HIP-event duration) and, at N=1, `cpu_baseline` (the CPU oracle timed on this
-host's cores on a bounded sample of the same workload).
+Before the warm-up every rank runs `--preroll` UNTIMED steps (default 200, stated in config.preroll_steps): all envs
+start their first episode in lock step, so without it a short run would time a synchronised batch in which no episode
+ends; after it the episodes are spread over all phases and the timed steps contain their share of episode ends and
+auto-resets (`episodes_finished`).
+
+Multi-GPU: the env axis is sharded (weak scaling: 4096 envs per GPU, global env ids offset by rank, no collective on the
+step path); the only exchange is one all-gather (RCCL) of the per-env episode-record blocks at the end, inside the timed
+region, followed by the job-wide summary kernel.  The JSON line also carries `roofline` (algorithmic bytes of the
+dominant kernel over its HIP-event duration), `issue_roofline` (the bound that actually limits this kernel, only when the
+committed PMC profile is of the same launch shape) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host's
+cores on a bounded sample of the same workload).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc")
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
 
 
 def algorithmic_bytes_per_env_step(H):
@@ -31,41 +43,49 @@ def algorithmic_bytes_per_env_step(H):
     return 72 * (H + 1) + 26
 
 
-def pmc_traffic_bytes(envs, humans, steps_per_launch):
-    """HBM bytes per rollout launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: separate
-    FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md §HBM).  None when no profile matches this configuration."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    if not os.path.exists(path):
+def pmc_profile(envs, humans, steps_per_launch):
+    """The committed rocprofv3 PMC record (separate FETCH_SIZE / WRITE_SIZE / SQ passes of this command, per-dispatch
+    averages of cn::rollout_kernel) whose launch shape equals the one just timed, or None: counters of a 1000-step
+    launch say nothing about a 20-step one."""
+    if not os.path.exists(PMC_PROFILE):
         return None
-    rec = json.load(open(path))
-    if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch')) != (envs, humans, steps_per_launch):
+    for rec in json.load(open(PMC_PROFILE)).get('profiles', []):
+        if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch')) == (envs, humans, steps_per_launch):
+            return rec
+    return None
+
+
+def pmc_traffic_bytes(rec):
+    """HBM bytes per rollout launch; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md §HBM."""
+    if rec is None or 'fetch_size_kb' not in rec:
         return None
     return (2 * rec['fetch_size_kb'] + rec['write_size_kb']) * 1024
 
 
-def pmc_issue(envs, humans, steps_per_launch, launch_seconds):
-    """What actually bounds the fused rollout: vector-ALU issue.  SQ_INSTS_VALU per launch (committed PMC pass) over the
-    launch time measured in this run, against 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    if not os.path.exists(path):
+def pmc_issue(rec, envs, steps_per_launch, launch_seconds):
+    """What actually bounds the fused rollout: vector-ALU issue.  SQ_INSTS_VALU per launch (committed PMC pass of the same
+    launch shape) over the launch time measured in this run, against 1024 SIMDs x one wave64 VALU instruction per 2 cycles
+    at 2.4 GHz.  The peak is for plain f32 instructions: f64 and transcendental instructions issue at half / quarter
+    rate, their shares are reported so the reader can discount it."""
+    if rec is None or 'sq_insts_valu' not in rec:
         return None
-    rec = json.load(open(path))
-    if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch')) != (envs, humans, steps_per_launch):
-        return None
-    if 'sq_insts_valu' not in rec:
-        return None
-    peak = 1024 * 2.4e9 / 4
     achieved = rec['sq_insts_valu'] / launch_seconds
-    return {'bound': 'valu-issue', 'achieved': achieved / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instructions/s',
-            'frac': achieved / peak, 'valu_per_env_step': rec['sq_insts_valu'] / (envs * steps_per_launch) }
+    out = {'bound': 'valu-issue', 'achieved': achieved / 1e9, 'peak': VALU_ISSUE_PEAK / 1e9,
+           'unit': 'G wave-instructions/s', 'frac': achieved / VALU_ISSUE_PEAK,
+           'valu_per_env_step': rec['sq_insts_valu'] / (envs * steps_per_launch)}
+    for k in ('f64_share', 'trans_share', 'lane_occupancy'):
+        if k in rec:
+            out[k] = rec[k]
+    return out
 
 
 def bench_sarl(args, world, rank, local_rank):
     """BASELINE configs[2]: 4096 envs x 5 humans, SARL value-network rollout (random-init weights), greedy phase.
-    A step = cn_sarl_select (81 lookaheads + value network per env) + cn_step + masked seeded reset."""
+    A step = cn_sarl_select (81 lookaheads + value network per env) + cn_rollout_step (transition, bookkeeping, seeded
+    auto-reset)."""
     import numpy as np
     import torch
+    import torch.distributed as dist
     import crowdnav_amd
     from crowdnav_amd import distributed as cd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
@@ -82,8 +102,11 @@ def bench_sarl(args, world, rank, local_rank):
     off, stride = cd.shard(rank, world, B)
     ro = SarlRollout(eng, 0.9, seed_base=2000, seed_mod=2 ** 32 - 2000, env_offset=off, env_stride=stride)
     steps, warm = min(args.steps, 200), min(args.warmup, 20)
+    ro.run(min(args.preroll, 60))
     ro.run(warm)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     before = int(ro.transitions.item())
     sel_ms = []
     t0 = time.perf_counter()
@@ -94,16 +117,24 @@ def bench_sarl(args, world, rank, local_rank):
         e1.record()
         sel_ms.append((e0, e1))
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     transitions = int(ro.transitions.item()) - before
+    tot = torch.tensor([float(transitions)], dtype=torch.float64, device='cuda')
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:  # real per-rank counts over the slowest rank's time
+        dist.all_reduce(tot)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     flop = 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B
     step_s = sum(a.elapsed_time(b) for a, b in sel_ms) / 1e3 / steps
     out = {
         'metric': 'env-steps/sec, %d envs x %d humans, %s value-net rollout (BASELINE configs[2])' % (B, H, args.workload),
-        'value': transitions * world / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warm,
-        'ms_per_step': elapsed * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (FP32 MFMA value network, f64 lookahead rewards)', 'data': 'synthetic',
-        'config': {'workload': '%d envs x %d humans, 81 actions, %s, random-init weights' % (B, H, args.workload)},
+        'value': float(tot.item()) / float(tmax.item()), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warm, 'ms_per_step': float(tmax.item()) * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32 (FP32 MFMA value network, f64 lookahead rewards)', 'data': 'synthetic',
+        'config': {'workload': '%d envs x %d humans, 81 actions, %s, random-init weights' % (B, H, args.workload),
+                   'preroll_steps': min(args.preroll, 60)},
         'roofline': {'bound': 'mfma', 'achieved': flop / step_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
                      'frac': flop / step_s / 1e12 / 157.3, 'traffic': None,
                      'note': 'flops of the value network / whole batched step (select + step + reset + bookkeeping)'},
@@ -149,11 +180,45 @@ def cpu_baseline(envs, humans, target_seconds=8.0):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this script as N ranks, one per GPU, rendezvous on
+    127.0.0.1 (what torch.distributed.run would set up).  Rank 0's JSON line goes to our stdout."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: the only mode the host driver supports
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:  # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8000)
     ap.add_argument('--warmup', type=int, default=1000)
+    ap.add_argument('--preroll', type=int, default=200,
+                    help='untimed steps before the warm-up that desynchronise the episodes of the batch')
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--humans', type=int, default=5)
     ap.add_argument('--chunk', type=int, default=1000, help='steps fused into one kernel launch')
@@ -162,6 +227,11 @@ def main():
     ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
                     help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.preroll < 0 or args.chunk < 1:
+        raise SystemExit('--gpus/--steps/--chunk must be >= 1, --warmup/--preroll >= 0')
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -172,9 +242,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('rank %d needs GPU %d but only %d are visible' % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -182,7 +252,10 @@ def main():
 
     B, H = args.envs, args.humans
     if args.workload != 'orca':
-        return bench_sarl(args, world, rank, local_rank)
+        bench_sarl(args, world, rank, local_rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
                                        robot_visible=1, device=local_rank, circle_radius=args.circle_radius)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
@@ -209,19 +282,19 @@ def main():
             torch.cuda.synchronize()
 
     def shard_boundary():
-        """episode records of this shard -> every rank (one RCCL all-gather), then the job-wide summary"""
-        rec, cnt = cd.pack_records(bufs)
-        rec, cnt = cd.gather_records(rec, cnt)
-        have = torch.arange(rec.shape[1], device=rec.device)[None, :] < cnt[:, None]
-        finished = bufs['ep_count'].sum().to(torch.float64)
+        """episode records of this shard (one pack kernel) -> every rank (one RCCL all-gather) -> the job-wide summary
+        of explorer.py:74-90 (one kernel): float64 [8] on the device"""
+        blocks = eng.rollout_records()
         if world > 1:
-            dist.all_reduce(finished)
-        return torch.stack([finished, (rec[:, :, 2] * have).sum(), have.sum().to(torch.float64)])
+            blocks = cd.gather_blocks(blocks)
+        return eng.records_summary(blocks)
 
+    run(args.preroll)
     run(args.warmup)
-    shard_boundary()  # warm-up of the torch / RCCL side too (lazy code-object loads, communicator setup)
+    shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
     fence()
     before = int(bufs['transitions'].item())
+    ep_before = float(shard_boundary()[0].item())
     events = []
     fence()
     t0 = time.perf_counter()
@@ -242,29 +315,35 @@ def main():
         dist.all_reduce(n)  # transitions of every shard (they differ by the few ring-dry pauses)
     total = int(n.item())
 
-    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    kernel_s = sum(e0.elapsed_time(e1) for e0, e1, _ in events) / 1e3
     launches = len(events)
-    avg_launch_s = kernel_ms / 1e3 / launches
-    bytes_per_launch = algorithmic_bytes_per_env_step(H) * B * (args.steps / launches)
-    achieved = bytes_per_launch / avg_launch_s / 1e9
+    shapes = sorted({k for _, _, k in events})
+    steps_per_launch = shapes[-1]  # = min(chunk, steps); a shorter tail launch exists when chunk does not divide steps
+    avg_launch_s = kernel_s / launches
+    achieved = algorithmic_bytes_per_env_step(H) * B * args.steps / kernel_s / 1e9
+    prof = pmc_profile(B, H, steps_per_launch) if len(shapes) == 1 and args.circle_radius == 4.0 else None
+    s = [float(v) for v in summary.cpu().tolist()]
     out = {
         'metric': 'env-steps/sec (whole node), %d envs x %d humans, ORCA step' % (B, H),
         'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 ORCA solve + f64 env step', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: %d batched envs x %d humans per GPU, ORCA humans + holonomic '
-                               'ORCA robot (visible), circle_crossing, in-kernel auto-reset' % (B, H),
-                   'envs_per_gpu': B, 'humans': H, 'steps_per_launch': args.chunk,
-                   'parallelism': 'env-axis shards x%d, all-gather of episode summaries at the end' % world},
+                               'ORCA robot (visible), circle_crossing radius %g, in-kernel auto-reset' % (B, H, args.circle_radius),
+                   'envs_per_gpu': B, 'humans': H, 'steps_per_launch': steps_per_launch, 'launches': launches,
+                   'preroll_steps': args.preroll,
+                   'parallelism': 'env-axis shards x%d, all-gather of episode records at the end' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(B, H, args.chunk),
-                     'kernel': 'cn::rollout_kernel (+ cn::ring_fill_kernel, ~2 % of the launch: one cn_rollout call)',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof),
+                     'kernel': 'cn::rollout_kernel (one cn_rollout call; + cn::ring_fill_kernel when the scenario ring '
+                               'needs topping up)',
                      'avg_launch_ms': avg_launch_s * 1e3,
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
-        'issue_roofline': pmc_issue(B, H, args.chunk, avg_launch_s),
+        'issue_roofline': pmc_issue(prof, B, steps_per_launch, avg_launch_s),
         'paused_env_steps': paused_env_steps,
-        'episodes_finished': int(summary[0].item()),
-        'mean_recorded_return': float(summary[1].item() / max(summary[2].item(), 1.0)),
+        'episodes_finished': int(s[0] - ep_before),
+        'mean_recorded_return': s[6] / max(s[1], 1.0),
+        'recorded_success_rate': s[2] / max(s[1], 1.0),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(B, H)

@@ -18,12 +18,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <utility>
 #include <vector>
 
 #include "../../include/crowdnav_amd.h"
 #include "step_kernels.h"
+#include "records_kernels.h"
 #include "sarl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -59,7 +61,7 @@ struct cn_engine {
     cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
     cn_rollout_io* io_dev;   // device copy the rollout kernels read through
     bool io_valid;
-    int steps_since_fill;    // cn_rollout_step calls since the scenario ring was last topped up
+    int steps_since_fill;    // transitions launched since the scenario ring was last topped up; < 0 = never filled
     struct cn_sarl* sarl;    // SARL decision state (sarl_abi.inc), NULL until cn_sarl_configure
     double* discount;
     int discount_len;
@@ -125,7 +127,7 @@ inline int grid_lanes(const cn_engine* e) { return (e->P.B + cn::kWave - 1) / cn
 extern "C" {
 
 const char* cn_last_error(void) { return g_err; }
-int cn_abi_version(void) { return 3; }
+int cn_abi_version(void) { return 4; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
     if (!c || !out) return fail(CN_ERR_INVALID, "cn_create: NULL argument");
@@ -165,7 +167,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->cfg = *c;
     e->stream = nullptr;
     e->io_valid = false;
-    e->steps_since_fill = 0;
+    e->steps_since_fill = -1;
     e->sarl = nullptr;
     cn::Params& P = e->P;
     P.B = c->num_envs;
@@ -237,7 +239,9 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.mt_pos, (size_t)P.B)) || (rc = dev_alloc(e, &e->probe_key, (size_t)624)) ||
         (rc = dev_alloc(e, &S.ring_pos, n * P.ring_depth)) || (rc = dev_alloc(e, &S.ring_goal, n * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_rv, n * P.ring_depth)) ||
-        (rc = dev_alloc(e, &S.ring_mt_key, (e->mt_in_lds || e->gen_wave) ? (size_t)64 : (size_t)624 * P.B * P.ring_depth)) ||
+        (rc = dev_alloc(e, &S.ring_mt_key, (e->mt_in_lds || e->gen_wave) ? (size_t)64 : (size_t)624 * cn::kRedoLanes)) ||
+        (rc = dev_alloc(e, &S.redo_list, (e->mt_in_lds || e->gen_wave) ? (size_t)1 : (size_t)P.B * P.ring_depth)) ||
+        (rc = dev_alloc(e, &S.redo_count, (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1))) {
         cn_destroy(e);
@@ -499,6 +503,33 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
         hipLaunchKernelGGL(cn::rollout_begin_kernel<false>, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C,
                            e->S, R);
     CN_HIP(hipGetLastError());
+    e->steps_since_fill = -1;
+    return CN_OK;
+}
+
+// Top the scenario ring up to ring_depth episodes ahead of every env.  An env consumes at most one ring scenario per
+// transition, so after a fill the next ring_depth transitions cannot run it dry: launches inside that budget skip the
+// fill kernels altogether (a 20-step cn_rollout call used to spend more time here than in its transitions).
+static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_steps) {
+    if (e->steps_since_fill >= 0 && e->steps_since_fill + n_steps <= e->P.ring_depth) {
+        e->steps_since_fill += n_steps;
+        return CN_OK;
+    }
+    const int fill_lanes = e->P.B * e->P.ring_depth;
+    const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
+    if (e->gen_wave) {
+        hipLaunchKernelGGL(cn::ring_fill_wave_kernel, dim3(fill_lanes), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+    } else if (e->mt_in_lds) {
+        hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
+                           e->S, R);
+    } else {
+        CN_HIP(hipMemsetAsync(e->S.redo_count, 0, sizeof(int), e->stream));
+        hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+        hipLaunchKernelGGL(cn::ring_redo_kernel, dim3(cn::kRedoLanes / cn::kWave), dim3(cn::kWave), 0, e->stream, e->P, e->C,
+                           e->S);
+    }
+    std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
+    e->steps_since_fill = n_steps;
     return CN_OK;
 }
 
@@ -513,17 +544,7 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
                                         "CN_ROBOT_EXTERNAL use cn_rollout_step(action)");
     if ((rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
-    // top the scenario ring up to ring_depth episodes ahead of every env, then run the fused transitions
-    const int fill_lanes = e->P.B * e->P.ring_depth;
-    const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
-    if (e->gen_wave)
-        hipLaunchKernelGGL(cn::ring_fill_wave_kernel, dim3(fill_lanes), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
-    else if (e->mt_in_lds)
-        hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
-                           e->S, R);
-    else
-        hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
-    std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
+    if ((rc = fill_ring_if_needed(e, R, n_steps))) return rc;  // then the fused transitions
     const cn::Params& P = e->P;
     if (e->maxl == 5 && !P.robot_unicycle && P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 &&
         P.threads == 64)  // BASELINE configs[1]: the instantiation with this geometry folded in
@@ -532,7 +553,6 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     else
         CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
     CN_HIP(hipGetLastError());
-    e->steps_since_fill = 0;
     return CN_OK;
 }
 
@@ -544,23 +564,72 @@ int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action)
     if (!action) return fail(CN_ERR_INVALID, "cn_rollout_step: action is NULL");
     if ((rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
-    // an env consumes at most one ring scenario per transition: refill every ring_depth / 2 calls
-    if (e->steps_since_fill == 0 || e->steps_since_fill >= e->P.ring_depth / 2) {
-        const int fill_lanes = e->P.B * e->P.ring_depth;
-        const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
-        if (e->gen_wave)
-            hipLaunchKernelGGL(cn::ring_fill_wave_kernel, dim3(fill_lanes), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
-        else if (e->mt_in_lds)
-            hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
-                               e->S, R);
-        else
-            hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
-        std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
-        e->steps_since_fill = 0;
-    }
-    ++e->steps_since_fill;
+    if ((rc = fill_ring_if_needed(e, R, 1))) return rc;
     CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, 1, action);
     CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
+int cn_rollout_records(cn_engine* e, const cn_rollout_io* io, int max_records, double* blocks) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if ((rc = check_io(e, io))) return rc;
+    if (max_records < 1 || !blocks) return fail(CN_ERR_INVALID, "cn_rollout_records: need max_records >= 1 and blocks");
+    if ((rc = upload_io(e, io))) return rc;
+    const int n = e->P.B * max_records;
+    hipLaunchKernelGGL(cn::records_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->P.B, max_records, e->io_dev,
+                       blocks);
+    CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
+int cn_records_summary(cn_engine* e, int64_t n_envs, int max_records, int record_capacity, const double* blocks,
+                       double* summary) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if (n_envs < 0 || max_records < 1 || record_capacity < 0 || !blocks || !summary)
+        return fail(CN_ERR_INVALID, "cn_records_summary: bad arguments");
+    hipLaunchKernelGGL(cn::records_summary_kernel, dim3(1), dim3(cn::kSummaryThreads), 0, e->stream, n_envs, max_records,
+                       record_capacity, blocks, summary);
+    CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
+// RCCL is bound at first use (dlopen of librccl.so.1: in a PyTorch-ROCm process that is the copy torch already loaded),
+// so the library itself does not depend on it.
+namespace {
+struct RcclApi {
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+    const char* (*error_string)(int);
+    bool ok;
+};
+const RcclApi* rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a{};
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
+        a.error_string = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.all_gather && a.error_string;
+        return a;
+    }();
+    return &api;
+}
+constexpr int kNcclFloat64 = 8;  // ncclDataType_t (rccl.h)
+}  // namespace
+
+int cn_gather_records(cn_engine* e, void* rccl_comm, int n_ranks, int max_records, const double* blocks,
+                      double* blocks_all) {
+    int rc = bind(e);
+    if (rc) return rc;
+    if (!rccl_comm || n_ranks < 1 || max_records < 1 || !blocks || !blocks_all)
+        return fail(CN_ERR_INVALID, "cn_gather_records: bad arguments");
+    const RcclApi* api = rccl_api();
+    if (!api->ok) return fail(CN_ERR_UNSUPPORTED, "cn_gather_records: librccl.so.1 could not be loaded");
+    const size_t n = (size_t)e->P.B * cn::record_block_doubles(max_records);
+    const int st = api->all_gather(blocks, blocks_all, n, kNcclFloat64, rccl_comm, e->stream);
+    if (st) return fail(CN_ERR_HIP, "cn_gather_records: RCCL error %d (%s)", st, api->error_string(st));
     return CN_OK;
 }
 

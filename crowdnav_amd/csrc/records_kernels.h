@@ -1,0 +1,83 @@
+// Shard-boundary kernels: what Explorer.run_k_episodes does with the finished episodes AFTER its loop
+//   /root/reference crowd_nav/utils/explorer.py:50-62 (per-episode outcome / nav time), :71-72 (discounted return),
+//   :74-90 (success / collision rate, average nav time, average return, danger frequency)
+// on the per-env record rings cn_rollout / cn_rollout_step filled.  One pack kernel turns the six typed record arrays
+// into ONE fixed-size float64 block per env (the unit the RCCL all-gather moves between shards), one single-workgroup
+// kernel reduces any such block — a shard's own or the gathered one — to the eight numbers of the log line in a fixed
+// order (bitwise reproducible, no atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/crowdnav_amd.h"
+
+namespace cn {
+
+constexpr int kRecordFields = CN_RECORD_FIELDS;  // outcome, steps, discounted return, nav time, danger steps, danger dmin sum
+
+__host__ __device__ inline size_t record_block_doubles(int K) { return 1 + (size_t)K * kRecordFields; }
+
+// blocks [B][1 + K * 6] f64: block b = { episodes env b has FINISHED (unclamped), then K records }; record j is the
+// env's j-th episode and is valid while j < min(count, record_capacity, K), zeros otherwise.
+__global__ void records_pack_kernel(int B, int K, const cn_rollout_io* io_dev, double* blocks) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * K) return;
+    const cn_rollout_io* io = io_dev;
+    const int b = idx / K, j = idx - b * K;
+    const int cap = io->record_capacity;
+    const int n = io->ep_count[b];
+    double* blk = blocks + (size_t)b * record_block_doubles(K);
+    if (j == 0) blk[0] = (double)n;
+    double* r = blk + 1 + (size_t)j * kRecordFields;
+    if (j < n && j < cap) {
+        const size_t k = (size_t)b * cap + j;
+        r[0] = io->ep_outcome ? (double)io->ep_outcome[k] : 0.0;
+        r[1] = io->ep_steps ? (double)io->ep_steps[k] : 0.0;
+        r[2] = io->ep_return ? io->ep_return[k] : 0.0;
+        r[3] = io->ep_time ? io->ep_time[k] : 0.0;
+        r[4] = io->ep_danger ? (double)io->ep_danger[k] : 0.0;
+        r[5] = io->ep_danger_dmin_sum ? io->ep_danger_dmin_sum[k] : 0.0;
+    } else {
+        for (int f = 0; f < kRecordFields; ++f) r[f] = 0.0;
+    }
+}
+
+constexpr int kSummaryThreads = 512;
+constexpr int kSummaryFields = CN_SUMMARY_FIELDS;
+
+// summary[8] = episodes finished, records held, ReachGoal / Collision / Timeout among them, sum of the successful nav
+// times, sum of the discounted returns, sum of the Danger steps.  One workgroup: thread t adds its strided items in index
+// order, then a fixed tree — the same bits for the same input on every run and every rank.
+__global__ __launch_bounds__(kSummaryThreads) void records_summary_kernel(int64_t n_envs, int K, int capacity,
+                                                                          const double* blocks, double* summary) {
+    __shared__ double part[kSummaryFields][kSummaryThreads];
+    double acc[kSummaryFields] = {};
+    for (int64_t b = threadIdx.x; b < n_envs; b += kSummaryThreads) {
+        const double* blk = blocks + (size_t)b * record_block_doubles(K);
+        const double n = blk[0];
+        acc[0] += n;
+        int held = n < (double)K ? (int)n : K;
+        held = held < capacity ? held : capacity;
+        for (int j = 0; j < held; ++j) {
+            const double* r = blk + 1 + (size_t)j * kRecordFields;
+            const int outcome = (int)r[0];
+            acc[1] += 1.0;
+            acc[2] += outcome == CN_REACH_GOAL ? 1.0 : 0.0;
+            acc[3] += outcome == CN_COLLISION ? 1.0 : 0.0;
+            acc[4] += outcome == CN_TIMEOUT ? 1.0 : 0.0;
+            acc[5] += outcome == CN_REACH_GOAL ? r[3] : 0.0;
+            acc[6] += r[2];
+            acc[7] += r[4];
+        }
+    }
+    for (int f = 0; f < kSummaryFields; ++f) part[f][threadIdx.x] = acc[f];
+    __syncthreads();
+    for (int half = kSummaryThreads / 2; half > 0; half >>= 1) {
+        if ((int)threadIdx.x < half)
+            for (int f = 0; f < kSummaryFields; ++f) part[f][threadIdx.x] += part[f][threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x < kSummaryFields) summary[threadIdx.x] = part[threadIdx.x][0];
+}
+
+}  // namespace cn

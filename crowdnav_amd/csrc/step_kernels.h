@@ -53,7 +53,9 @@ struct StateView {
     float* rsim_max_speed;  // [B]
     uint8_t* rsim_valid;    // [B]
     uint32_t* mt_key;       // [624][B]   generator state of the env's own stream
-    uint32_t* ring_mt_key;  // [624][B*D] HBM generator scratch of the fill kernel (short-chain placement)
+    uint32_t* ring_mt_key;  // [624][kRedoLanes] HBM generator scratch of ring_redo_kernel (scenarios the head generator gave up on)
+    int2* redo_list;        // [B*D] (ring index, seed) of those scenarios; redo_count [1] = how many (zeroed before a fill)
+    int* redo_count;
     int* mt_pos;            // [B]
     // scenario ring: the next ring_depth episodes of every env, generated ahead of the rollout
     double2* ring_pos;      // [B][D][A]
@@ -687,25 +689,47 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, Scenario
 
 // Scenario ring fill: one lane per (env, ring slot) generates the episode whose ordinal maps to that slot
 // if it has not been generated yet, so that ordinals [next, next + D) are resident when the rollout
-// launch that follows needs them.
+// launch that follows needs them.  HBM flavour (IN_LDS = false): the lane runs the register-only head generator; the
+// rare scenario whose rejection chain outruns its 227 words is queued in redo_list and regenerated by ring_redo_kernel
+// with a memory-backed generator from a small fixed pool (624 x kRedoLanes words, not 624 x B x D).
+constexpr int kRedoLanes = 4096;
 template <bool IN_LDS>
 __global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int D = P.ring_depth;
     if (idx >= P.B * D) return;
     const int b = idx / D, slot = idx - b * D;
-    const cn_rollout_io io = *R.io;
-    const int state = io.active[b];
+    const cn_rollout_io* io = R.io;
+    const int state = io->active[b];
     // first ordinal the rollout may still ask for (an env waiting for a scenario has not consumed ep_count yet)
-    const int next = io.ep_count[b] + (state == kWaitingScenario ? 0 : 1);
+    const int next = io->ep_count[b] + (state == kWaitingScenario ? 0 : 1);
     if (slot == 0) S.ring_filled_out[b] = next + D;
     if (state == kRetired) return;
     const int ordinal = next + ((slot - next % D) + D) % D;
     if (ordinal < S.ring_filled_in[b]) return;  // still resident from an earlier fill
-    const int64_t c = episode_id(io, b, ordinal);
-    if (io.episode_limit >= 0 && c >= io.episode_limit) return;
-    generate_scenario_lane<IN_LDS>(C, episode_seed(io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr,
-                                   S.ring_goal, S.ring_rv, S.ring_mt_key + idx, P.B * D, false, nullptr);
+    const int64_t c = episode_id(*io, b, ordinal);
+    if (io->episode_limit >= 0 && c >= io->episode_limit) return;
+    const uint32_t seed = episode_seed(*io, c);
+    const size_t base = ((size_t)b * D + slot) * P.A;
+    if (IN_LDS) {
+        generate_scenario_lane<true>(C, seed, base, S.ring_pos, nullptr, S.ring_goal, S.ring_rv, nullptr, 0, false, nullptr);
+    } else {
+        Mt19937Head head;
+        generate_scenario(C, head, seed, base, S.ring_pos, nullptr, S.ring_goal, S.ring_rv);
+        if (head.dead()) S.redo_list[atomicAdd(S.redo_count, 1)] = make_int2(idx, (int)seed);
+    }
+}
+
+// The scenarios ring_fill_kernel<false> queued: a fixed grid of kRedoLanes lanes strides over the list, each lane with
+// its own column of the word-major generator pool.
+__global__ __launch_bounds__(kWave) void ring_redo_kernel(Params P, ScenarioCfg C, StateView S) {
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *S.redo_count;
+    for (int k = lane; k < n; k += kRedoLanes) {
+        const int2 job = S.redo_list[k];
+        Mt19937 rng{S.ring_mt_key + lane, kRedoLanes, 0};
+        generate_scenario(C, rng, (uint32_t)job.y, (size_t)job.x * P.A, S.ring_pos, nullptr, S.ring_goal, S.ring_rv);
+    }
 }
 
 // ---- wave-cooperative variants (scenario_wave.h): one 64-lane workgroup per scenario -----------------------------

@@ -1,8 +1,12 @@
 """Sharding of the env axis over ranks (one process per GPU, torch.distributed; backend 'nccl' = RCCL over xGMI
 on MI355X, 'gloo' in CPU tests).  Envs never interact, so the step path has NO collective: rank r owns the global
 env ids [r*B, (r+1)*B) and seeds its episodes from the GLOBAL episode id, which makes every trajectory
-independent of the number of ranks.  The only exchange is an all-gather of fixed-size per-episode records at the
-shard boundary (end of Explorer.run_k_episodes, crowd_nav/utils/explorer.py:74-90 needs them on one rank)."""
+independent of the number of ranks.  The only exchange is ONE all-gather of fixed-size per-env record blocks at the
+shard boundary (end of Explorer.run_k_episodes, crowd_nav/utils/explorer.py:74-90 needs them on one rank).
+
+A record block is what cn_rollout_records packs per env (include/crowdnav_amd.h): float64 [1 + 6 K] =
+(episodes finished, K x RECORD_FIELDS).  pack_blocks is its host-side restatement (CPU tests, and the reference for the
+GPU test of the kernel)."""
 import torch
 import torch.distributed as dist
 
@@ -16,26 +20,41 @@ def shard(rank, world, envs_per_rank):
     return rank * envs_per_rank, world * envs_per_rank
 
 
-def pack_records(bufs, max_records=None):
-    """rollout buffers (BatchedCrowdSim.rollout_begin) -> float64 [B, K, 6] record tensor + int64 [B] counts."""
-    K = bufs['ep_outcome'].shape[1] if max_records is None else max_records
-    cols = [bufs[n][:, :K].to(torch.float64) for n in ('ep_outcome', 'ep_steps', 'ep_return', 'ep_time',
-                                                      'ep_danger', 'ep_danger_dmin_sum')]
-    return torch.stack(cols, dim=2).contiguous(), bufs['ep_count'].to(torch.int64).clamp(max=K)
+def pack_blocks(bufs, max_records=None):
+    """rollout buffers (BatchedCrowdSim.rollout_begin) -> float64 [B, 1 + 6 K] record blocks, exactly what
+    BatchedCrowdSim.rollout_records (cn_rollout_records) produces on the device."""
+    cap = bufs['ep_outcome'].shape[1]
+    K = cap if max_records is None else int(max_records)
+    counts = bufs['ep_count'].to(torch.int64)
+    cols = []
+    for n in ('ep_outcome', 'ep_steps', 'ep_return', 'ep_time', 'ep_danger', 'ep_danger_dmin_sum'):
+        c = torch.zeros(counts.shape[0], K, dtype=torch.float64, device=counts.device)
+        c[:, :min(K, cap)] = bufs[n][:, :K].to(torch.float64)
+        cols.append(c)
+    rec = torch.stack(cols, dim=2)
+    j = torch.arange(K, device=counts.device)[None, :]
+    rec = rec * ((j < counts[:, None]) & (j < cap))[:, :, None]
+    return torch.cat([counts.to(torch.float64)[:, None], rec.reshape(counts.shape[0], -1)], dim=1).contiguous()
 
 
-def gather_records(records, counts, group=None):
-    """All-gather [B, K, F] records and [B] counts from every rank; returns ([W*B, K, F], [W*B]) ordered by global
-    env id (rank-major), identical on every rank.  One collective of B*K*F*8 bytes per rank (96 KiB at 4096 envs,
-    K = 1): latency-bound, never on the step path."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return records, counts
+def split_blocks(blocks, record_capacity=None):
+    """[n, 1 + 6 K] blocks -> (records [n, K, 6], counts int64 [n] = records actually held per env)."""
+    K = (blocks.shape[1] - 1) // len(RECORD_FIELDS)
+    cap = K if record_capacity is None else min(K, int(record_capacity))
+    return blocks[:, 1:].reshape(-1, K, len(RECORD_FIELDS)), blocks[:, 0].to(torch.int64).clamp(max=cap)
+
+
+def gather_blocks(blocks, group=None):
+    """All-gather [B, 1 + 6 K] record blocks from every rank: [W*B, 1 + 6 K] ordered by global env id (rank-major),
+    identical on every rank.  ONE collective of B * (1 + 6 K) * 8 bytes per rank (224 KiB at 4096 envs, K = 1):
+    latency-bound, never on the step path.  Without an initialised process group the shard is the whole job; with one —
+    a world of one rank included — the collective really runs."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return blocks
     world = dist.get_world_size(group)
-    flat = torch.cat([records.reshape(records.shape[0], -1), counts.to(records.dtype)[:, None]], dim=1).contiguous()
-    out = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(out, flat, group=group)
-    allr = torch.cat(out, dim=0)
-    return allr[:, :-1].reshape((-1,) + tuple(records.shape[1:])), allr[:, -1].to(torch.int64)
+    out = torch.empty((world * blocks.shape[0], blocks.shape[1]), dtype=blocks.dtype, device=blocks.device)
+    dist.all_gather_into_tensor(out, blocks.contiguous(), group=group)
+    return out
 
 
 def episodes_in_global_order(records, counts, total_envs):

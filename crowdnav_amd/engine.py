@@ -203,6 +203,37 @@ class BatchedCrowdSim(object):
             self.sync()
         return self._rollout[1]
 
+    # ---------------------------------------------------------------- shard boundary (explorer.py:74-90)
+    def rollout_records(self, max_records=None):
+        """The finished episodes of this engine's rollout as ONE self-contained float64 block per env:
+        [B, 1 + 6 K] = (episodes finished, K x (outcome, steps, discounted return, nav time, danger steps, danger dmin
+        sum)); see distributed.split_blocks.  One kernel (cn_rollout_records)."""
+        if self._rollout is None:
+            raise RuntimeError('call rollout_begin() first')
+        io, bufs = self._rollout
+        K = int(bufs['ep_outcome'].shape[1] if max_records is None else max_records)
+        blocks = self._new((self.B, 1 + K * _lib.RECORD_FIELDS), torch.float64)
+        check(self._lib.cn_rollout_records(self._h, C.byref(io), K, _ptr(blocks)))
+        return blocks
+
+    def records_summary(self, blocks, record_capacity=None):
+        """float64 [8]: episodes finished, records held, ReachGoal / Collision / Timeout among them, sum of successful nav
+        times, sum of discounted returns, sum of Danger steps — of any [n, 1 + 6 K] record blocks, a shard's own or the
+        gathered ones (cn_records_summary: one workgroup, fixed summation order)."""
+        K = (int(blocks.shape[1]) - 1) // _lib.RECORD_FIELDS
+        cap = K if record_capacity is None else int(record_capacity)
+        out = self._new((_lib.SUMMARY_FIELDS,), torch.float64)
+        check(self._lib.cn_records_summary(self._h, int(blocks.shape[0]), K, cap, _ptr(blocks), _ptr(out)))
+        return out
+
+    def gather_records_rccl(self, comm, n_ranks, blocks):
+        """All-gather the record blocks of every rank over the caller's RCCL communicator (`comm`: the ncclComm_t as an
+        integer, see crowdnav_amd.rccl) on the engine's stream (cn_gather_records): [n_ranks * B, 1 + 6 K]."""
+        K = (int(blocks.shape[1]) - 1) // _lib.RECORD_FIELDS
+        out = self._new((n_ranks * self.B, int(blocks.shape[1])), torch.float64)
+        check(self._lib.cn_gather_records(self._h, C.c_void_p(int(comm)), int(n_ranks), K, _ptr(blocks), _ptr(out)))
+        return out
+
     def mt_random(self, seed, n):
         out = self._new((n,), torch.float64)
         check(self._lib.cn_mt_random(self._h, int(seed), int(n), _ptr(out)))

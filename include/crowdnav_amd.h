@@ -18,7 +18,8 @@
  *     documented otherwise.  An engine is bound to one device and is not thread-safe.
  *   - agent 0 of every env is the robot, agents 1..H are the humans; A = H + 1.
  *   - batched state layout ("state8"): double [B][A][8] = px, py, vx, vy, gx, gy, radius, v_pref
- *     (crowd_sim/envs/utils/state.py:1-50 minus theta, which is constant for the holonomic robot).
+ *     (crowd_sim/envs/utils/state.py:1-50 minus theta: the robot's heading is a separate [B] plane,
+ *     cn_set_theta / cn_get_theta; only a unicycle robot changes it).
  */
 #ifndef CROWDNAV_AMD_H
 #define CROWDNAV_AMD_H
@@ -32,7 +33,7 @@ extern "C" {
 typedef enum cn_status {
     CN_OK = 0,
     CN_ERR_INVALID = -1,     /* bad argument / config            */
-    CN_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here (e.g. unicycle robot) */
+    CN_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here (e.g. a value network under the mixed rule) */
     CN_ERR_HIP = -3,         /* a HIP runtime call failed         */
     CN_ERR_NO_DEVICE = -4    /* no gfx950 device visible          */
 } cn_status;
@@ -258,6 +259,33 @@ int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes);
  * cn_rollout's bookkeeping and seeded auto-reset from the scenario ring — `action = robot.act(ob); env.step(action)`
  * of explorer.py:41-48 without leaving the device. */
 int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Shard boundary: the statistics block of Explorer.run_k_episodes (explorer.py:50-62, 71-90) needs every finished
+ * episode on one rank.  The env axis is sharded over GPUs with NO collective on the step path (cn_rollout_io.env_offset /
+ * env_stride); the only exchange is one all-gather of fixed-size per-env record blocks when a run ends. */
+#define CN_RECORD_FIELDS 6  /* outcome (CN_*), steps, discounted return, nav time, danger steps, danger dmin sum */
+#define CN_SUMMARY_FIELDS 8
+/* doubles per env in a record block holding up to K records: { episodes finished, K x CN_RECORD_FIELDS } */
+#define CN_RECORD_BLOCK_DOUBLES(K) (1 + (K) * CN_RECORD_FIELDS)
+/* pack the record rings of io into ONE self-contained float64 block per env: blocks double
+ * [B][CN_RECORD_BLOCK_DOUBLES(max_records)]; block b = { number of episodes env b has finished (unclamped), then record j
+ * = its j-th finished episode for j < min(count, record_capacity, max_records), zeros beyond }.  One kernel. */
+int cn_rollout_records(cn_engine* e, const cn_rollout_io* io, int max_records, double* blocks);
+/* all-gather such blocks over the ranks of an RCCL communicator (rccl_comm = the caller's ncclComm_t, one rank per GPU;
+ * librccl.so.1 is bound at first use): blocks_all double [n_ranks * B][CN_RECORD_BLOCK_DOUBLES(max_records)], rank-major
+ * = ordered by global env id, identical on every rank.  ONE ncclAllGather on the engine's stream (200 KiB per rank at
+ * 4096 envs, max_records 1: latency-bound).  A reference process that owns one engine per GPU calls this where
+ * explorer.py:74 starts. */
+int cn_gather_records(cn_engine* e, void* rccl_comm, int n_ranks, int max_records, const double* blocks,
+                      double* blocks_all);
+/* explorer.py:74-90 on record blocks (a shard's own or the gathered ones): summary double [CN_SUMMARY_FIELDS] =
+ * episodes finished, records held, ReachGoal / Collision / Timeout among them, sum of the successful nav times, sum of
+ * the discounted returns, sum of the Danger steps.  record_capacity = the capacity of the rings the blocks were packed
+ * from (records beyond it are not counted).  One single-workgroup kernel, fixed summation order (bitwise reproducible;
+ * rates and averages are quotients of these). */
+int cn_records_summary(cn_engine* e, int64_t n_envs, int max_records, int record_capacity, const double* blocks,
+                       double* summary);
 
 /* numpy legacy RNG probe (np.random.seed(seed); n × np.random.random()): out double [n].  For tests. */
 int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out);

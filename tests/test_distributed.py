@@ -33,8 +33,8 @@ def _worker(rank, world, port, B, K, ret):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from crowdnav_amd import distributed as cd
     assert cd.shard(rank, world, B) == (rank * B, world * B)
-    rec, cnt = cd.pack_records(_fake_bufs(rank, B, K, world))
-    allr, allc = cd.gather_records(rec, cnt)
+    allb = cd.gather_blocks(cd.pack_blocks(_fake_bufs(rank, B, K, world)))
+    allr, allc = cd.split_blocks(allb)
     ids, vals = cd.episodes_in_global_order(allr, allc, world * B)
     ret[rank] = (allr.clone(), allc.clone(), ids.clone(), vals.clone())
     dist.barrier()
@@ -54,7 +54,7 @@ def test_gather_records_world2_gloo():
     assert allr.shape == (world * B, K, 6) and allc.tolist() == [(g % (K + 1)) for g in range(world * B)]
     # what a single process owning all 16 envs would hold
     from crowdnav_amd import distributed as cd
-    want = [cd.pack_records(_fake_bufs(r, B, K, world)) for r in range(world)]
+    want = [cd.split_blocks(cd.pack_blocks(_fake_bufs(r, B, K, world))) for r in range(world)]
     assert torch.equal(allr, torch.cat([w[0] for w in want])) and torch.equal(allc, torch.cat([w[1] for w in want]))
     # global episode order: ids strictly increasing, discounted_return column = 0.001 * id
     assert torch.all(ids[1:] > ids[:-1]) and len(ids) == int(allc.sum())
@@ -63,8 +63,28 @@ def test_gather_records_world2_gloo():
 
 def test_gather_is_identity_without_process_group():
     from crowdnav_amd import distributed as cd
-    rec, cnt = cd.pack_records(_fake_bufs(0, 4, 2, 1))
-    a, b = cd.gather_records(rec, cnt)
-    assert a is rec and b is cnt
+    blocks = cd.pack_blocks(_fake_bufs(0, 4, 2, 1))
+    assert cd.gather_blocks(blocks) is blocks
+    rec, cnt = cd.split_blocks(blocks)
+    assert rec.shape == (4, 2, 6) and cnt.tolist() == [0, 1, 2, 0]
+    assert float(rec[0].abs().sum()) == 0.0 and float(rec[1, 1].abs().sum()) == 0.0  # nothing beyond what an env holds
     with pytest.raises(ValueError):
         cd.shard(2, 2, 4)
+
+
+@pytest.mark.timeout(180)
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes itself as two ranks (what the
+    driver's N=1 shape of the command line does for N>1).  Without GPUs here every rank must stop with a clear message
+    and the parent must return non-zero instead of hanging in a rendezvous."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('this check is for the GPU-less container')
+    env['HIP_VISIBLE_DEVICES'] = ''
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=150)
+    assert p.returncode != 0
+    assert p.stderr.count('needs GPU') == 2 and 'rank 1 needs GPU 1' in p.stderr
