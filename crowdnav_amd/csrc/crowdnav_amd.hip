@@ -66,6 +66,7 @@ struct cn_engine {
     double* discount;
     int discount_len;
     uint32_t* probe_key;
+    double* summary_scratch;  // records_summary_kernel: per-workgroup partials + ticket counter
     int maxl;          // half-planes held in VGPRs by the solve phase: 5 or 10
     bool mt_in_lds;    // lane-per-scenario generators keep their MT19937 state in LDS instead of HBM
     bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
@@ -242,6 +243,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_mt_key, (e->mt_in_lds || e->gen_wave) ? (size_t)64 : (size_t)624 * cn::kRedoLanes)) ||
         (rc = dev_alloc(e, &S.redo_list, (e->mt_in_lds || e->gen_wave) ? (size_t)1 : (size_t)P.B * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.redo_count, (size_t)1)) ||
+        (rc = dev_alloc(e, &e->summary_scratch, (size_t)cn::kSummaryBlocks * cn::kSummaryFields + 1)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1))) {
         cn_destroy(e);
@@ -589,8 +591,8 @@ int cn_records_summary(cn_engine* e, int64_t n_envs, int max_records, int record
     if (rc) return rc;
     if (n_envs < 0 || max_records < 1 || record_capacity < 0 || !blocks || !summary)
         return fail(CN_ERR_INVALID, "cn_records_summary: bad arguments");
-    hipLaunchKernelGGL(cn::records_summary_kernel, dim3(1), dim3(cn::kSummaryThreads), 0, e->stream, n_envs, max_records,
-                       record_capacity, blocks, summary);
+    hipLaunchKernelGGL(cn::records_summary_kernel, dim3(cn::kSummaryBlocks), dim3(cn::kSummaryThreads), 0, e->stream, n_envs,
+                       max_records, record_capacity, blocks, summary, e->summary_scratch);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }

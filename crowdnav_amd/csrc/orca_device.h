@@ -140,6 +140,116 @@ __device__ __forceinline__ int lp_planar_reg(const float4 (&L)[MAXL], int n, flo
     return fail;
 }
 
+// ------------------------------------------------------------------ candidate form of the programs
+// RVO2's linearProgram1 on half-plane k (Appendix A.5) reads the half-planes 0..k, the speed disc and the optimisation
+// target — NOT the running result of linearProgram2: the running result only decides WHETHER half-plane k is violated, i.e.
+// whether the 1-D solution replaces it.  So the 1-D solutions ("candidates") of all half-planes of all agents can be
+// computed at once, one lane per (agent, half-plane), with the divisions of one candidate independent of each other; what
+// remains serial per agent is a scan of MAXL compare-and-select steps (lp_planar_scan).  Same operations on the same
+// operands in the same order as lp_on_line_reg, so the results are bit-identical; a half-plane the sequential program
+// never reaches merely has an unused candidate.
+//   lk: half-plane k; prev: half-planes 0.. of the same program in LDS (NJ slots are read, j >= k ignored)
+//   returns (candidate.x, candidate.y, feasible ? 1 : 0, -)
+template <int NJ>
+__device__ __forceinline__ float4 lp_line_candidate(const float4 lk, const float4* prev, int k, float radius, float ox,
+                                                    float oy, bool dir_opt) {
+    const float px = lk.x, py = lk.y, dx = lk.z, dy = lk.w;
+    const float dp = px * dx + py * dy;
+    const float disc = (dp * dp + radius * radius) - (px * px + py * py);
+    bool ok = !(disc < 0.0f);
+    const float root = sqrtf(disc);
+    float t_lo = -dp - root;
+    float t_hi = -dp + root;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 lj = prev[j];
+        const bool use = j < k;
+        const float den = dx * lj.w - dy * lj.z;
+        const float num = lj.z * (py - lj.y) - lj.w * (px - lj.x);
+        const bool parallel = fabsf(den) <= kRvoEps;
+        const float t = num / den;
+        ok = ok && !(use && parallel && num < 0.0f);
+        const bool upper = use && !parallel && den >= 0.0f;
+        const bool lower = use && !parallel && !(den >= 0.0f);
+        t_hi = (upper && t < t_hi) ? t : t_hi;
+        t_lo = (lower && t_lo < t) ? t : t_lo;
+        ok = ok && !(t_lo > t_hi);
+    }
+    float t;
+    if (dir_opt) {
+        t = (ox * dx + oy * dy > 0.0f) ? t_hi : t_lo;
+    } else {
+        t = dx * (ox - px) + dy * (oy - py);
+        t = (t < t_lo) ? t_lo : ((t > t_hi) ? t_hi : t);
+    }
+    return make_float4(px + t * dx, py + t * dy, ok ? 1.0f : 0.0f, 0.0f);
+}
+
+// linearProgram2 (Appendix A.4) as a scan over precomputed candidates: lines / cand = the agent's MAXL slots in LDS.
+// Returns the first infeasible half-plane or n; (rx, ry) enters as the start point.
+template <int MAXL>
+__device__ __forceinline__ int lp_planar_scan(const float4* lines, const float4* cand, int n, float& rx, float& ry) {
+    int fail = n;
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) {
+        const float4 lk = lines[k];
+        const float4 ck = cand[k];
+        const bool viol = k < fail && (lk.z * (lk.y - ry) - lk.w * (lk.x - rx) > 0.0f);
+        const bool feasible = ck.z != 0.0f;
+        rx = (viol && feasible) ? ck.x : rx;
+        ry = (viol && feasible) ? ck.y : ry;
+        fail = (viol && !feasible) ? k : fail;
+    }
+    return fail;
+}
+
+// linearProgram3 (Appendix A.6) in the same form, for MAXL = 5: the projection of half-plane j onto half-plane i (j < i)
+// depends on nothing but the two half-planes, and the 1-D solution of projected half-plane k of program i on nothing but
+// the projections 0..k of that program — 10 (i, j) pairs and 10 (i, k) candidates per agent, one lane each
+// (lp3_project, lp3_candidate), then one serial scan per agent (lp3_scan) of at most 5 outer and 10 inner
+// compare-and-select steps.  A projection RVO2 leaves out (parallel, same direction) is stored as an inert half-plane
+// (zero direction: never violated, and "parallel with a zero numerator" as a constraint), which keeps the slots fixed.
+__device__ __forceinline__ int lp3_program_of(int m) { return m >= 6 ? 4 : (m >= 3 ? 3 : (m >= 1 ? 2 : 1)); }  // m = i (i - 1) / 2 + j
+
+__device__ __forceinline__ float4 lp3_project(const float4 li, const float4 lj) {
+    const float d = li.z * lj.w - li.w * lj.z;
+    const bool par = fabsf(d) <= kRvoEps;
+    const bool same_dir = li.z * lj.z + li.w * lj.w > 0.0f;
+    const float t = (lj.z * (li.y - lj.y) - lj.w * (li.x - lj.x)) / d;
+    const float qx = par ? 0.5f * (li.x + lj.x) : li.x + t * li.z;
+    const float qy = par ? 0.5f * (li.y + lj.y) : li.y + t * li.w;
+    const float ex = lj.z - li.z, ey = lj.w - li.w;
+    const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
+    const bool skip = par && same_dir;
+    return make_float4(skip ? 0.0f : qx, skip ? 0.0f : qy, skip ? 0.0f : ex * inv, skip ? 0.0f : ey * inv);
+}
+
+// lines: the agent's half-planes; proj / cand: its 10 projected half-planes and their candidates, slot i (i - 1) / 2 + k
+__device__ __forceinline__ void lp3_scan(const float4* lines, const float4* proj, const float4* cand, int n, int begin,
+                                         float radius, float& rx, float& ry) {
+    float distance = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float4 li = lines[i];
+        const bool active = i >= begin && i < n && (li.z * (li.y - ry) - li.w * (li.x - rx) > distance);
+        float r2x = -li.w * radius, r2y = li.z * radius;  // linearProgram2, directionOpt: start at opt * radius
+        bool failed = false;
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float4 pk = proj[i * (i - 1) / 2 + k];
+            const float4 ck = cand[i * (i - 1) / 2 + k];
+            const bool viol = !failed && (pk.z * (pk.y - r2y) - pk.w * (pk.x - r2x) > 0.0f);
+            const bool feasible = ck.z != 0.0f;
+            r2x = (viol && feasible) ? ck.x : r2x;
+            r2y = (viol && feasible) ? ck.y : r2y;
+            failed = failed || (viol && !feasible);
+        }
+        rx = (active && !failed) ? r2x : rx;
+        ry = (active && !failed) ? r2y : ry;
+        distance = active ? li.z * (li.y - ry) - li.w * (li.x - rx) : distance;
+    }
+}
+
 // ------------------------------------------------------------------ lane-cooperative 2-D program
 // The same program with one lane per (agent, half-plane): a wave holds kWave / MAXL agents (12 at MAXL = 5), lane
 // g * MAXL + l owns half-plane l of the g-th agent of the chunk.  Per round every agent advances to its next violated

@@ -42,33 +42,42 @@ __global__ void records_pack_kernel(int B, int K, const cn_rollout_io* io_dev, d
     }
 }
 
-constexpr int kSummaryThreads = 512;
+constexpr int kSummaryThreads = 256;   // threads per workgroup
+constexpr int kSummaryBlocks = 64;     // workgroups of one summary launch
 constexpr int kSummaryFields = CN_SUMMARY_FIELDS;
 
 // summary[8] = episodes finished, records held, ReachGoal / Collision / Timeout among them, sum of the successful nav
-// times, sum of the discounted returns, sum of the Danger steps.  One workgroup: thread t adds its strided items in index
-// order, then a fixed tree — the same bits for the same input on every run and every rank.
+// times, sum of the discounted returns, sum of the Danger steps.  Thread = one (env, record) item per grid stride (all
+// loads of an item are independent: one memory round trip instead of the dependent chain a per-env loop makes), fixed tree
+// per workgroup, per-workgroup partials to `scratch`, and the LAST workgroup to arrive (ticket) adds the partials in
+// workgroup order: the same bits for the same input on every run and every rank, without a second launch.
+//   scratch: double [kSummaryBlocks][8] followed by one unsigned ticket counter (zero before the first launch; the
+//   last workgroup leaves it zero again)
 __global__ __launch_bounds__(kSummaryThreads) void records_summary_kernel(int64_t n_envs, int K, int capacity,
-                                                                          const double* blocks, double* summary) {
+                                                                          const double* blocks, double* summary,
+                                                                          double* scratch) {
     __shared__ double part[kSummaryFields][kSummaryThreads];
+    __shared__ unsigned ticket;
     double acc[kSummaryFields] = {};
-    for (int64_t b = threadIdx.x; b < n_envs; b += kSummaryThreads) {
-        const double* blk = blocks + (size_t)b * record_block_doubles(K);
-        const double n = blk[0];
-        acc[0] += n;
-        int held = n < (double)K ? (int)n : K;
-        held = held < capacity ? held : capacity;
-        for (int j = 0; j < held; ++j) {
-            const double* r = blk + 1 + (size_t)j * kRecordFields;
-            const int outcome = (int)r[0];
-            acc[1] += 1.0;
-            acc[2] += outcome == CN_REACH_GOAL ? 1.0 : 0.0;
-            acc[3] += outcome == CN_COLLISION ? 1.0 : 0.0;
-            acc[4] += outcome == CN_TIMEOUT ? 1.0 : 0.0;
-            acc[5] += outcome == CN_REACH_GOAL ? r[3] : 0.0;
-            acc[6] += r[2];
-            acc[7] += r[4];
-        }
+    const int64_t items = n_envs * K;
+    const size_t stride = record_block_doubles(K);
+    for (int64_t it = (int64_t)blockIdx.x * kSummaryThreads + threadIdx.x; it < items;
+         it += (int64_t)kSummaryBlocks * kSummaryThreads) {
+        const int64_t b = it / K;
+        const int j = (int)(it - b * K);
+        const double* blk = blocks + (size_t)b * stride;
+        const double* r = blk + 1 + (size_t)j * kRecordFields;
+        const double n = blk[0], r0 = r[0], r2 = r[2], r3 = r[3], r4 = r[4];
+        const bool held = (double)j < n && j < capacity;
+        const int outcome = (int)r0;
+        if (j == 0) acc[0] += n;
+        acc[1] += held ? 1.0 : 0.0;
+        acc[2] += (held && outcome == CN_REACH_GOAL) ? 1.0 : 0.0;
+        acc[3] += (held && outcome == CN_COLLISION) ? 1.0 : 0.0;
+        acc[4] += (held && outcome == CN_TIMEOUT) ? 1.0 : 0.0;
+        acc[5] += (held && outcome == CN_REACH_GOAL) ? r3 : 0.0;
+        acc[6] += held ? r2 : 0.0;
+        acc[7] += held ? r4 : 0.0;
     }
     for (int f = 0; f < kSummaryFields; ++f) part[f][threadIdx.x] = acc[f];
     __syncthreads();
@@ -77,7 +86,21 @@ __global__ __launch_bounds__(kSummaryThreads) void records_summary_kernel(int64_
             for (int f = 0; f < kSummaryFields; ++f) part[f][threadIdx.x] += part[f][threadIdx.x + half];
         __syncthreads();
     }
-    if (threadIdx.x < kSummaryFields) summary[threadIdx.x] = part[threadIdx.x][0];
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + kSummaryBlocks * kSummaryFields);
+    if (threadIdx.x < kSummaryFields) scratch[blockIdx.x * kSummaryFields + threadIdx.x] = part[threadIdx.x][0];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
+    __syncthreads();
+    if (ticket != kSummaryBlocks - 1) return;
+    __threadfence();
+    if (threadIdx.x < kSummaryFields) {
+        double total = 0.0;
+        for (int w = 0; w < kSummaryBlocks; ++w)
+            total += __builtin_nontemporal_load(scratch + w * kSummaryFields + threadIdx.x);
+        summary[threadIdx.x] = total;
+    }
+    if (threadIdx.x == 0) *counter = 0u;
 }
 
 }  // namespace cn

@@ -84,6 +84,8 @@ struct Smem {
     double2* act;     // [nA] (robot lanes) applied robot action
     float4* lines;    // [nA][kLineStride] ORCA half-planes, slot = neighbour rank
     float4* proj;     // [nA][kLineStride] projected half-planes (3-D fallback scratch)
+    float4* cand2;    // [nA][kLineStride] candidate form: 1-D solutions of the agent's half-planes (lp_line_candidate)
+    float4* cand3;    // [nA][kLineStride] ... and of its projected half-planes (3-D fallback)
     double* rad;      // [nA] float64 radius
     double* closest;  // [nA] (human lanes) closest boundary distance during the step
     float* hview;     // [nA] radius as a human's rvo2 sim holds it: float32(radius + 0.01 + human_safety)
@@ -101,7 +103,7 @@ struct Smem {
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
 
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs) {
-    return (size_t)nA * (16 + 16 + 16 + 2 * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 +
+    return (size_t)nA * (16 + 16 + 16 + 4 * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 +
            sizeof(double) * kMaxDiscount;
 }
 
@@ -115,6 +117,8 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
     s.proj = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
     s.sol = reinterpret_cast<float4*>(p), p += 16 * nA;
     s.res = reinterpret_cast<float4*>(p), p += 16 * nA;
     s.rad = reinterpret_cast<double*>(p), p += 8 * nA;
@@ -252,6 +256,13 @@ struct PhaseClock {};
 #define CN_COOP_LP3_10 1
 #endif
 
+// CN_PAR_LP5 (compile time): MAXL = 5 solves in candidate form (orca_device.h: lp_line_candidate / lp_planar_scan, and
+// lp3_project / lp3_scan for the infeasible agents): the 1-D solutions of every (agent, half-plane) on their own lanes, then
+// a short scan per agent, instead of one unrolled, predicated program per agent lane with its serial LDS-walking fallback.
+#ifndef CN_PAR_LP5
+#define CN_PAR_LP5 1
+#endif
+
 template <int MAXL>
 __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
                                             float robot_max_speed, bool solve, float& out_vx, float& out_vy,
@@ -259,6 +270,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     (void)clk;
     constexpr bool kCoop = (MAXL == 5) ? (CN_COOP_LP5 != 0) : (CN_COOP_LP10 != 0);
     constexpr bool kCoop3 = (MAXL == 5) ? (CN_COOP_LP3_5 != 0) : (CN_COOP_LP3_10 != 0);
+    constexpr bool kPar = (MAXL == 5) && (CN_PAR_LP5 != 0) && !kCoop;
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
     auto preferred = [&](float& pref_x, float& pref_y) {
@@ -272,7 +284,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         s.posd[L.lane] = make_double2(r.px, r.py);
         s.rad[L.lane] = r.rad;
         s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
-        if (kCoop) {
+        if (kCoop || kPar) {
             float pref_x, pref_y;
             preferred(pref_x, pref_y);
             s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
@@ -324,7 +336,65 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     CN_TICK(clk, 2);
 
     out_vx = 0.0f, out_vy = 0.0f;
-    if (kCoop) {
+    if (kPar) {
+        // candidates: lane = (agent, half-plane)
+        for (int p = threadIdx.x; p < P.nA * MAXL; p += blockDim.x) {
+            const int q = p / MAXL, k = p - q * MAXL;
+            const float4 so = s.sol[q];
+            const float4* lq = s.lines + q * kLineStride;
+            s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
+            if (k == 0) {
+                float sx, sy;
+                lp_start_point(so.z, so.x, so.y, sx, sy);
+                s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
+            }
+        }
+        __syncthreads();
+        float rx = 0.0f, ry = 0.0f;
+        int n = 0, fail = 0;
+        if (solve) {
+            n = s.count[L.lane];
+            const float4 start = s.res[L.lane];
+            rx = start.x, ry = start.y;
+            fail = lp_planar_scan<MAXL>(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, rx, ry);
+        }
+        CN_TICK(clk, 3);
+        const bool need = solve && fail < n;
+#ifdef CN_PHASE_TIMING
+        if (clk) clk->acc[9] += __popcll(__ballot(need));
+#endif
+        if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+            if (L.lane < kWave) {
+                const unsigned long long nm = __ballot(need);
+                if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
+                if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
+            }
+            __syncthreads();
+            constexpr int kPairs = MAXL * (MAXL - 1) / 2;
+            const int items = s.todo[P.nA] * kPairs;
+            for (int p = threadIdx.x; p < items; p += blockDim.x) {  // projections: lane = (agent, i, j)
+                const int t = p / kPairs, m = p - t * kPairs;
+                const int a = s.todo[t];
+                const int i = lp3_program_of(m), j = m - i * (i - 1) / 2;
+                const float4* la = s.lines + a * kLineStride;
+                s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
+            }
+            __syncthreads();
+            for (int p = threadIdx.x; p < items; p += blockDim.x) {  // their candidates: lane = (agent, i, k)
+                const int t = p / kPairs, m = p - t * kPairs;
+                const int a = s.todo[t];
+                const int i = lp3_program_of(m), base = i * (i - 1) / 2;
+                const float4 li = s.lines[a * kLineStride + i];
+                const float4* pa = s.proj + a * kLineStride + base;
+                s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
+            }
+            __syncthreads();
+            if (need)
+                lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
+                         fail, max_speed, rx, ry);
+        }
+        out_vx = rx, out_vy = ry;
+    } else if (kCoop) {
         lp_planar_coop<MAXL>(s.lines, s.count, s.sol, s.res, P.nA);
         __syncthreads();
         if (solve) {
@@ -942,7 +1012,9 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         io.cur_return[L.env] = cur_return;
         if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
+#ifndef CN_EXP_NO_TRANS_ATOMIC
         if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, (unsigned long long)transitions);
+#endif
     }
 }
 

@@ -282,8 +282,8 @@ int cn_gather_records(cn_engine* e, void* rccl_comm, int n_ranks, int max_record
 /* explorer.py:74-90 on record blocks (a shard's own or the gathered ones): summary double [CN_SUMMARY_FIELDS] =
  * episodes finished, records held, ReachGoal / Collision / Timeout among them, sum of the successful nav times, sum of
  * the discounted returns, sum of the Danger steps.  record_capacity = the capacity of the rings the blocks were packed
- * from (records beyond it are not counted).  One single-workgroup kernel, fixed summation order (bitwise reproducible;
- * rates and averages are quotients of these). */
+ * from (records beyond it are not counted).  One kernel, fixed summation order (bitwise reproducible; rates and averages
+ * are quotients of these). */
 int cn_records_summary(cn_engine* e, int64_t n_envs, int max_records, int record_capacity, const double* blocks,
                        double* summary);
 
