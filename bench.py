@@ -262,12 +262,18 @@ def main():
     bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, episode_limit=-1, record_capacity=4,
                              env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1])
 
+    # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
+    # inside the timed region costs more host time than a 20-step launch's enqueue
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ((args.steps + args.chunk - 1) // args.chunk) + 1)]
+    for ev in pool:
+        ev.record()
+
     def run(n_steps, events=None):
         left = n_steps
         while left > 0:
             n = min(args.chunk, left)
             if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = pool[2 * len(events)], pool[2 * len(events) + 1]
                 e0.record()
             eng.rollout(n)
             if events is not None:
@@ -276,6 +282,9 @@ def main():
             left -= n
 
     def fence():
+        pool[-1].record()
+        while not pool[-1].query():  # spin until the stream has drained: a blocking synchronize alone wakes up late
+            pass
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -68,6 +68,7 @@ class CnSarlConfig(C.Structure):
         ('cell_size', C.c_double), ('gamma', C.c_double), ('with_global_state', C.c_int32),
         ('mlp1_dims', C.c_int32 * 2), ('mlp2_dims', C.c_int32 * 2), ('attention_dims', C.c_int32 * 3),
         ('mlp3_dims', C.c_int32 * 4), ('model', C.c_int32), ('interaction_dims', C.c_int32 * 4),
+        ('constant_velocity_model', C.c_int32), ('reserved', C.c_int32),
     ]
 
 

@@ -274,8 +274,10 @@ class CrowdSim(_Base):
         if getattr(eng, 'sarl', None) is None:
             eng.sarl_configure(**policy.engine_kwargs())
         # re-upload the parameters only when the Trainer (or a load_state_dict) has changed them: torch bumps a
-        # tensor's _version on every in-place update
-        stamp = (id(policy.model),) + tuple(p._version for p in policy.model.parameters())
+        # tensor's _version on every eager in-place update; a replayed hipGraph step does not, so the Trainer also counts
+        # its steps on the module (_cn_weights_epoch)
+        stamp = (id(policy.model), getattr(policy.model, '_cn_weights_epoch', 0)) + tuple(
+            p._version for p in policy.model.parameters())
         if getattr(eng, '_sarl_weights_stamp', None) != stamp:
             eng.sarl_set_weights(policy.model.state_dict())
             eng._sarl_weights_stamp = stamp

@@ -53,6 +53,12 @@ class Explorer(object):
         batched_rl = (isinstance(self.robot.policy, SARL) and phase == 'train' and update_memory
                       and not imitation_learning and no_wrap and hasattr(self.env, 'engine_config')
                       and getattr(self.robot.policy, 'env', None) is self.env)
+        value_net = isinstance(self.robot.policy, SARL) or (update_memory and isinstance(self.target_policy, SARL))
+        if value_net and self._scenario_of(phase)[1] == 'mixed' and hasattr(self.env, 'engine_config'):
+            # the batched engines keep a fixed number of human slots and park the absent ones: a value network would see
+            # them as humans.  The per-episode loop below runs on the gym surface, whose sarl_action refuses the same way.
+            raise NotImplementedError('value-network policies under the mixed rule (a different number of humans per '
+                                      'episode) are outside the accelerated path')
         if batched_il:
             stats = self._run_batched_imitation(k, phase)
         elif batched_rl:

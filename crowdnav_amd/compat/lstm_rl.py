@@ -65,15 +65,15 @@ class LstmRL(SARL):
         self.cell_num = config.getint('om', 'cell_num')
         self.cell_size = config.getfloat('om', 'cell_size')
         self.om_channel_size = config.getint('om', 'om_channel_size')
-        if self.kinematics != 'holonomic' or not self.query_env:
-            raise NotImplementedError('only holonomic, query_env=true LSTM-RL is on the accelerated path')
+        if self.kinematics != 'holonomic':
+            raise NotImplementedError('only holonomic LSTM-RL is on the accelerated path')
         pairwise = config.getboolean('lstm_rl', 'with_interaction_module')
         mlp_dims = [int(x) for x in config.get('lstm_rl', 'mlp2_dims').split(', ')]
         hidden = config.getint('lstm_rl', 'global_state_dim')
         self.with_om = config.getboolean('lstm_rl', 'with_om')
         self.net_cfg = dict(gamma=self.gamma, with_om=self.with_om, cell_num=self.cell_num, cell_size=self.cell_size,
                             om_channel_size=self.om_channel_size, mlp1_dims=(hidden, 1), mlp3_dims=mlp_dims,
-                            model='lstm_rl')
+                            model='lstm_rl', query_env=self.query_env)
         if pairwise:
             mlp1_dims = [int(x) for x in config.get('lstm_rl', 'mlp1_dims').split(', ')]
             if len(mlp1_dims) != 4:
@@ -88,7 +88,9 @@ class LstmRL(SARL):
 
     def predict(self, state):
         # humans sorted by decreasing distance to the robot (lstm_rl.py:96-103); with query_env the network input comes
-        # from the env's lookahead (env order), so the sort only shapes the replay-memory state of the train phase
+        # from the env's lookahead (env order), so the sort only shapes the replay-memory state of the train phase;
+        # without it the sorted states themselves are propagated (the device sorts the same way: cn_sarl_config.
+        # constant_velocity_model)
         me = np.array(state.self_state.position)
         state.human_states = sorted(state.human_states, key=lambda h: np.linalg.norm(np.array(h.position) - me),
                                     reverse=True)

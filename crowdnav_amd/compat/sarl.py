@@ -121,13 +121,14 @@ class SARL(Policy):
                 for k in ('mlp1_dims', 'mlp2_dims', 'mlp3_dims', 'attention_dims')}
         self.with_om = config.getboolean('sarl', 'with_om')
         with_global_state = config.getboolean('sarl', 'with_global_state')
-        if self.kinematics not in ('holonomic', 'unicycle') or not self.query_env:
-            raise NotImplementedError('only query_env=true SARL is on the accelerated path')
+        if self.kinematics not in ('holonomic', 'unicycle'):
+            raise NotImplementedError('kinematics %r' % self.kinematics)
         self.model = ValueNetwork(self.input_dim(), self.self_state_dim, dims['mlp1_dims'], dims['mlp2_dims'],
                                   dims['mlp3_dims'], dims['attention_dims'], with_global_state, self.cell_size,
                                   self.cell_num)
         self.net_cfg = dict(gamma=self.gamma, with_om=self.with_om, cell_num=self.cell_num, cell_size=self.cell_size,
-                            om_channel_size=self.om_channel_size, with_global_state=with_global_state, **dims)
+                            om_channel_size=self.om_channel_size, with_global_state=with_global_state,
+                            query_env=self.query_env, **dims)
         self.multiagent_training = config.getboolean('sarl', 'multiagent_training')
         if self.with_om:
             self.name = 'OM-SARL'

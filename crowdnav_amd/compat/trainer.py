@@ -163,6 +163,7 @@ class Trainer(object):
         self._sx.copy_(inputs)
         self._sy.copy_(values)
         self._graph.replay()
+        self._bump()
         return self._sloss.detach().clone()
 
     def _loader(self):
@@ -172,11 +173,17 @@ class Trainer(object):
             self.data_loader = DataLoader(self.memory, self.batch_size, shuffle=True)
         return self.data_loader
 
+    def _bump(self):
+        """Tell device-side consumers of the parameters that they changed: a replayed graph updates them without touching
+        the tensors' version counters, so CrowdSim.sarl_action keys its re-upload on this counter as well."""
+        self.model._cn_weights_epoch = getattr(self.model, '_cn_weights_epoch', 0) + 1
+
     def _fit(self, inputs, values):
         self.optimizer.zero_grad()
         loss = self.criterion(self.model(inputs.to(self.device)), values.to(self.device))
         loss.backward()
         self.optimizer.step()
+        self._bump()
         return loss.data.item()
 
     def _fit_device(self, inputs, values):
@@ -192,6 +199,7 @@ class Trainer(object):
         loss = self.criterion(self.model(inputs), values)
         loss.backward()
         self.optimizer.step()
+        self._bump()
         return loss.detach()
 
     def _device_memory(self):

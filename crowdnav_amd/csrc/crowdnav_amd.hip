@@ -182,7 +182,9 @@ int cn_create(const cn_config* c, cn_engine** out) {
     // 187 VGPRs (2 resident waves per SIMD) and loop over many more pairs, so they get one env per wave up to
     // 4096 workgroups (H = 20: E = 1 48 M, E = 2 31 M env-steps/s)
     const bool small_lp = (P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5;
-    int e_want = env_int("CROWDNAV_AMD_ENVS_PER_WAVE", small_lp ? (P.B + 2047) / 2048 : (P.B + 4095) / 4096);
+    // (r02, candidate-form programs: their (agent, half-plane) items fill one 64-lane pass at 2 envs x 6 agents; E = 3..8
+    // take 2-3 passes and lose 25-45 % at 8192-32768 envs, so the small programs never pack more than 2 envs per wave)
+    int e_want = env_int("CROWDNAV_AMD_ENVS_PER_WAVE", small_lp ? (P.B > 2048 ? 2 : 1) : (P.B + 4095) / 4096);
     P.E = e_want < 1 ? 1 : (e_want > e_max ? e_max : e_want);
     int w_want = env_int("CROWDNAV_AMD_WAVES_PER_BLOCK", 1);
     const int w_useful = (P.E * P.A * P.NC + cn::kWave - 1) / cn::kWave;  // more waves than pair passes is waste
@@ -194,7 +196,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     P.ring_depth = env_int("CROWDNAV_AMD_RING_DEPTH", 48);
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
-    e->smem = cn::smem_bytes(P.nA, P.pairs);
+    e->smem = cn::smem_bytes(P.nA, P.pairs, e->maxl);
     e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", 0) != 0;
     e->gen_wave = env_int("CROWDNAV_AMD_WAVE_SCENARIOS", c->num_humans > 8 ? 1 : 0) != 0;
     P.robot_visible = c->robot_visible ? 1 : 0;

@@ -42,13 +42,14 @@ __device__ unsigned long long cn_sarl_cycles[16];
         sclk_acc_[k] += now_ - sclk_last_;                               \
         sclk_last_ = now_;                                               \
     } while (0)
-#define CN_SARL_CLOCK_END()                                                              \
+#define CN_SARL_CLOCK_END_N(n_)                                                          \
     do {                                                                                 \
         if (threadIdx.x == 0) {                                                          \
             for (int k_ = 0; k_ < 15; ++k_) atomicAdd(&cn_sarl_cycles[k_], sclk_acc_[k_]); \
-            atomicAdd(&cn_sarl_cycles[15], 1ull);                                        \
+            atomicAdd(&cn_sarl_cycles[15], (unsigned long long)(n_));                    \
         }                                                                                \
     } while (0)
+#define CN_SARL_CLOCK_END() CN_SARL_CLOCK_END_N(1)
 #else
 #define CN_SARL_CLOCK_BEGIN() \
     do {                      \
@@ -58,6 +59,9 @@ __device__ unsigned long long cn_sarl_cycles[16];
     } while (0)
 #define CN_SARL_CLOCK_END() \
     do {                    \
+    } while (0)
+#define CN_SARL_CLOCK_END_N(n_) \
+    do {                        \
     } while (0)
 #endif
 
@@ -108,10 +112,34 @@ struct SarlNet {
     int ks_x, ks_a, ks_b, ks_c, ks_s;
 };
 
+// The same network as 12 x 3 dwords (offsets into ONE weight arena) for the persistent kernel, whose loop keeps every
+// descriptor live in SGPRs: 12 PackedLinear structs (pointers, sizes) do not fit and spill through VGPRs into scratch.
+struct LayerRef {
+    uint32_t w, b;   // float offsets of the B fragments / the bias from SarlNetRef::base
+    uint32_t dims;   // kpad | ctiles << 8 | ksteps << 16
+};
+struct SarlNetRef {
+    const float* base;
+    LayerRef L[kSarlLayers];
+    int nf;            // mlp2 output width (per-human feature)
+    int with_global;
+    int ks_x, ks_a, ks_b, ks_c, ks_s;
+};
+__device__ __forceinline__ PackedLinear layer_of(const SarlNetRef& n, int l) {
+    const LayerRef r = n.L[l];
+    PackedLinear P;
+    P.w = n.base + r.w, P.bias = n.base + r.b;
+    P.K = 0, P.N = 0;
+    P.kpad = (int)(r.dims & 0xffu), P.ctiles = (int)((r.dims >> 8) & 0xffu), P.ksteps = (int)(r.dims >> 16);
+    return P;
+}
+
 struct SarlCfg {
     int B, H, n_actions;
     int with_om, cell_num, om_channels;
     int unicycle;  // actions are ActionRot(v, r): cadrl.py:119-125, crowd_sim.py:339-341
+    int const_vel;       // query_env = false (multi_human_rl.py:39-42): humans keep their velocity, reward = compute_reward
+    int sort_lookahead;  // ... and the joint state LstmRL.predict sorted by decreasing distance feeds the network (lstm_rl.py:96-103)
     double cell_size;
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double gamma_bar;  // pow(gamma, time_step * v_pref), computed on the host like multi_human_rl.py:52
@@ -136,18 +164,23 @@ __global__ void sarl_pack_kernel(const float* W, const float* bias, int N, int K
 // ------------------------------------------------------------------------------------ lookahead / reward
 // Occupancy map human i sees among the H humans of one env (multi_human_rl.py:109-163; the robot is not in it).
 // state_of(j, px, py, vx, vy) yields human j's state; m receives cells * channels float32 values.
-template <class StateOf>
-__device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf state_of, float* m) {
+// CAP = kSarlMaxHumans: the per-human slots are registers (loops fully unrolled); CAP = kSarlAnyHumans: any crowd the
+// engine holds (<= 63 humans), slots in private memory, runtime trip counts.
+constexpr int kSarlAnyHumans = 64;
+template <int CAP, class StateOf>
+__device__ __forceinline__ void occupancy_map_cap(const SarlCfg& C, int i, StateOf state_of, float* m) {
     const int cells = C.cell_num * C.cell_num;
     const int ch = C.om_channels;
+    const int nh = CAP == kSarlMaxHumans ? kSarlMaxHumans : C.H;
+    constexpr int kOmUnroll = CAP == kSarlMaxHumans ? kSarlMaxHumans : 1;
     double px, py, vx, vy;
     state_of(i, px, py, vx, vy);
     const double my_angle = atan2(vy, vx);
-    // every other human's cell and rotated velocity once (kSarlMaxHumans slots in registers) ...
-    int cell_of[kSarlMaxHumans];
-    double rvx[kSarlMaxHumans], rvy[kSarlMaxHumans];
-#pragma unroll
-    for (int j = 0; j < kSarlMaxHumans; ++j) {
+    // every other human's cell and rotated velocity once ...
+    int cell_of[CAP];
+    double rvx[CAP], rvy[CAP];
+#pragma unroll kOmUnroll
+    for (int j = 0; j < nh; ++j) {
         cell_of[j] = -1;
         rvx[j] = rvy[j] = 0.0;
         if (j >= C.H || j == i) continue;
@@ -169,8 +202,8 @@ __device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf s
     // ... then per cell: count, sum vx', sum vy' in visit order (python sum(): 0 + x1 + x2 ...)
     for (int cell = 0; cell < cells; ++cell) {
         double cnt = 0.0, svx = 0.0, svy = 0.0;
-#pragma unroll
-        for (int j = 0; j < kSarlMaxHumans; ++j) {
+#pragma unroll kOmUnroll
+        for (int j = 0; j < nh; ++j) {
             if (cell_of[j] != cell) continue;
             cnt += 1.0;
             svx += rvx[j];
@@ -189,23 +222,58 @@ __device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf s
     }
 }
 
+template <class StateOf>
+__device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf state_of, float* m) {
+    if (C.H <= kSarlMaxHumans)
+        occupancy_map_cap<kSarlMaxHumans>(C, i, state_of, m);
+    else
+        occupancy_map_cap<kSarlAnyHumans>(C, i, state_of, m);
+}
+
+// LstmRL.predict re-orders the humans of the joint state by DEcreasing distance to the robot (lstm_rl.py:96-103; python's
+// sorted(..., reverse=True) is stable: equal distances keep their original order).  Returns the human that sits at
+// position p of the sorted joint state: the one whose stable rank equals p.  Distances are numpy's 2-vector norm of
+// (human.position - robot.position).
+__device__ inline int human_by_decreasing_distance(const double2* pos, size_t g0, int H, int p) {
+    double d[kSarlAnyHumans];
+    for (int j = 0; j < H; ++j) d[j] = norm2(pos[g0 + 1 + j].x - pos[g0].x, pos[g0 + 1 + j].y - pos[g0].y);
+    int who = p;
+    for (int j = 0; j < H; ++j) {
+        int rank = 0;
+        for (int k = 0; k < H; ++k) rank += (d[k] > d[j] || (d[k] == d[j] && k < j)) ? 1 : 0;
+        who = rank == p ? j : who;
+    }
+    return who;
+}
+
 // Next observable state of every human (get_next_observable_state, agent.py:63-74) from the ORCA velocities,
 // and (with_om) the occupancy map each human would see among those next states.
-__global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const double2* rv, const float* orca_vel,
-                                      double* next_obs /*[B][H][5]*/, float* om /*[B][H][cells*ch]*/) {
+__global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* rv,
+                                      const float* orca_vel, double* next_obs /*[B][H][5]*/,
+                                      float* om /*[B][H][cells*ch]*/) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= C.B * C.H) return;
     const int b = idx / C.H, i = idx - b * C.H;
     const int A = C.H + 1;
+    const size_t g0 = (size_t)b * A;
+    // query_env = true: the env's lookahead (ORCA velocities, env order).  query_env = false (multi_human_rl.py:39-40):
+    // propagate(human_state, ActionXY(human_state.vx, human_state.vy)) — each human keeps its observed velocity — over
+    // state.human_states, which LstmRL.predict has sorted by decreasing distance.
     auto next_of = [&](int j, double& px, double& py, double& vx, double& vy) {
-        const size_t gj = (size_t)b * A + 1 + j;
-        vx = orca_vel[2 * gj], vy = orca_vel[2 * gj + 1];
+        const int src = C.sort_lookahead ? human_by_decreasing_distance(pos, g0, C.H, j) : j;
+        const size_t gj = g0 + 1 + src;
+        if (C.const_vel) {
+            vx = vel[gj].x, vy = vel[gj].y;
+        } else {
+            vx = orca_vel[2 * gj], vy = orca_vel[2 * gj + 1];
+        }
         px = pos[gj].x + vx * C.dt, py = pos[gj].y + vy * C.dt;
     };
     double px, py, vx, vy;
     next_of(i, px, py, vx, vy);
+    const int me = C.sort_lookahead ? human_by_decreasing_distance(pos, g0, C.H, i) : i;
     double* o = next_obs + (size_t)idx * 5;
-    o[0] = px, o[1] = py, o[2] = vx, o[3] = vy, o[4] = rv[(size_t)b * A + 1 + i].x;
+    o[0] = px, o[1] = py, o[2] = vx, o[3] = vy, o[4] = rv[g0 + 1 + me].x;
     if (C.with_om) occupancy_map(C, i, next_of, om + (size_t)idx * C.cell_num * C.cell_num * C.om_channels);
 }
 
@@ -228,6 +296,40 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
     const double rrad = rv[g0].x;
     double dmin = __builtin_inf();
     bool collision = false;
+    if (C.const_vel) {
+        // MultiHumanRL.compute_reward(next_self_state, next_human_states) (multi_human_rl.py:65-88): end-point distances
+        // only, its own hard-coded constants (-0.25, 1, 0.2, 0.5), no time limit
+        double nx = rp.x + ax * C.dt, ny = rp.y + ay * C.dt;
+        if (C.unicycle) {
+            const double th = theta[b] + rot_r;
+            nx = rp.x + rot_v * cos(th) * C.dt;  // cadrl.py:120-124: next_vx = v cos(next_theta); px + next_vx * dt
+            ny = rp.y + rot_v * sin(th) * C.dt;
+        }
+        for (int i = 1; i < A; ++i) {
+            const double2 hp = pos[g0 + i], hv = vel[g0 + i];
+            const double hx = hp.x + hv.x * C.dt, hy = hp.y + hv.y * C.dt;
+            const double dist = norm2(nx - hx, ny - hy) - rrad - rv[g0 + i].x;
+            if (dist < 0.0) {
+                collision = true;
+                break;
+            }
+            if (dist < dmin) dmin = dist;
+        }
+        const double2 gl = goal[g0];
+        const bool reaching = norm2(nx - gl.x, ny - gl.y) < rrad;
+        double r;
+        if (collision) {
+            r = -0.25;
+        } else if (reaching) {
+            r = 1.0;
+        } else if (dmin < 0.2) {
+            r = (dmin - 0.2) * 0.5 * C.dt;
+        } else {
+            r = 0.0;
+        }
+        reward[idx] = r;
+        return;
+    }
     for (int i = 1; i < A; ++i) {
         const double2 hp = pos[g0 + i], hv = vel[g0 + i];
         const double x1 = hp.x - rp.x, y1 = hp.y - rp.y;
@@ -363,7 +465,7 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
     int perm[kSarlMaxHumans];
 #pragma unroll
     for (int p = 0; p < kSarlMaxHumans; ++p) perm[p] = p;
-    if (sort_humans) {
+    if (sort_humans && C.H <= kSarlMaxHumans) {
         double d[kSarlMaxHumans];
 #pragma unroll
         for (int j = 0; j < kSarlMaxHumans; ++j)
@@ -377,10 +479,13 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
             for (int p = 0; p < kSarlMaxHumans; ++p) perm[p] = (j < C.H && rank == p) ? j : perm[p];
         }
     }
-    int me = h;  // env order unless sorted (sorting and occupancy maps are limited to kSarlMaxHumans humans)
-    if (sort_humans) {
+    const bool big = C.H > kSarlMaxHumans;  // the register permutation holds kSarlMaxHumans; larger crowds rank on demand
+    int me = h;  // env order unless sorted
+    if (sort_humans && !big) {
 #pragma unroll
         for (int p = 0; p < kSarlMaxHumans; ++p) me = (p == h) ? perm[p] : me;
+    } else if (sort_humans) {
+        me = human_by_decreasing_distance(pos, g0, C.H, h);
     }
     const size_t g1 = g0 + 1 + me;
     float f[13];
@@ -392,9 +497,13 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
     for (int k = 0; k < 13; ++k) x[k] = f[k];
     if (C.with_om) {
         auto state_of = [&](int j, double& px, double& py, double& vx, double& vy) {
-            int oj = 0;
+            int oj = j;
+            if (!big) {
 #pragma unroll
-            for (int p = 0; p < kSarlMaxHumans; ++p) oj = (p == j) ? perm[p] : oj;
+                for (int p = 0; p < kSarlMaxHumans; ++p) oj = (p == j) ? perm[p] : oj;
+            } else if (sort_humans) {
+                oj = human_by_decreasing_distance(pos, g0, C.H, j);
+            }
             const size_t gj = g0 + 1 + oj;
             px = pos[gj].x, py = pos[gj].y, vx = vel[gj].x, vy = vel[gj].y;
         };
@@ -440,9 +549,35 @@ __global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_k
 // fragment order (ks_in / ks_out k-steps per row tile).  A wave owns whole column tiles (ct = wave, wave + 16, ..)
 // and all RT row tiles of them: per k-step it reads RT A fragments from LDS (conflict-free) and issues RT
 // independent MFMAs; the B fragments of the next trip are already in flight from L2 (register double buffer).
-template <int RT>
+// Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS traffic, not for its global loads — so
+// the B fragments of the NEXT layer, requested before the barrier (dense_prefetch), stay in flight across it
+// (__syncthreads() drains vmcnt as well and would expose one L2 round trip per layer: 11 per tile).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Weights are read through GLOBAL-address-space pointers: a generic pointer whose provenance the compiler cannot see (the
+// persistent kernel rebuilds them from an arena base) turns into flat_load, which counts on lgkmcnt as well as vmcnt — and
+// lds_barrier's s_waitcnt lgkmcnt(0) would then wait for exactly the prefetch it is meant to leave in flight.
+typedef const float __attribute__((address_space(1))) * gfloat_p;
+__device__ __forceinline__ gfloat_p as_global(const float* p) { return (gfloat_p)p; }
+
+// First trip of a wave's first column tile of a layer: kSarlKChunk B fragments + the bias, requested ahead of time.
+struct BFrag {
+    float b[kSarlKChunk];
+    float bias;
+};
+__device__ __forceinline__ BFrag dense_prefetch(const PackedLinear& P, int wave, int lane) {
+    BFrag f;
+    const int ct = wave < P.ctiles ? wave : 0;  // waves without a column tile fetch tile 0 (no divergence, L2 hit)
+    const gfloat_p wfrag = as_global(P.w) + (size_t)ct * P.kpad * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < kSarlKChunk; ++j) f.b[j] = wfrag[j * 64];
+    f.bias = as_global(P.bias)[ct * 16 + (lane & 15)];
+    return f;
+}
+
+template <int RT, bool PRE = false>
 __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* in, int ks_in, float* out, int ks_out,
-                                           bool relu, const float* extra, int wave, int lane) {
+                                           bool relu, const float* extra, int wave, int lane, const BFrag* pre = nullptr) {
     const int col = lane & 15, quad = lane >> 4;
     for (int ct = wave; ct < P.ctiles; ct += kSarlThreads / 64) {
         // this lane's 4 accumulator rows of column n = ct*16 + col sit at 4 consecutive words of the out buffer
@@ -450,7 +585,8 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
         // accumulators start at zero; bias (L2) and the per-group extra term (LDS) are requested now and added in the
         // epilogue, so their latency hides behind the k loop instead of opening the column tile
         f32x4 acc[RT];
-        const float b0 = P.bias[ct * 16 + col];
+        const bool first = PRE && ct == wave;  // this tile's first trip was prefetched before the barrier
+        const float b0 = first ? pre->bias : as_global(P.bias)[ct * 16 + col];
         f32x4 addend = {b0, b0, b0, b0};
         if (extra) addend += *reinterpret_cast<const f32x4*>(extra + frag_off);
 #pragma unroll
@@ -460,25 +596,48 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
         // holds whole column tiles of its producer, zero beyond the true width, and the packed weights are zero
         // there too).  The B fragments of the next trip are requested before this trip's MFMAs issue; the
         // packed buffer carries one spare chunk so the last request stays in bounds.
-        const float* wfrag = P.w + (size_t)ct * P.kpad * 64 + lane;
+        const gfloat_p wfrag = as_global(P.w) + (size_t)ct * P.kpad * 64 + lane;
         const float* afrag = in + lane;
+        // One trip = kSarlKChunk k-steps x RT row tiles of MFMAs.  Its B fragments were requested from L2 a whole trip
+        // earlier (bnxt; measured: a second trip of lead changes nothing).  Its A fragments come from LDS in two groups so
+        // that no trip opens with a wait: the HEAD (first kHead k-steps) was requested during the previous trip, the REST
+        // is requested now and arrives while the head's MFMAs run; then the next trip's head is requested while the
+        // rest's MFMAs run.  (A whole second register set for A costs 25 VGPRs more and spills at 16 waves per CU.)
+        // The head request after the last trip reads past the row tile into whatever follows it in LDS (always inside
+        // the allocation: every MFMA input buffer is followed by another buffer) and is unused.
+        constexpr int kHead = 2;
         float bcur[kSarlKChunk], bnxt[kSarlKChunk];
+        float ah[kHead][RT], ar[kSarlKChunk - kHead][RT];
 #pragma unroll
-        for (int j = 0; j < kSarlKChunk; ++j) bcur[j] = wfrag[j * 64];
+        for (int j = 0; j < kSarlKChunk; ++j) bcur[j] = first ? pre->b[j] : wfrag[j * 64];
+#pragma unroll
+        for (int j = 0; j < kHead; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) ah[j][rt] = afrag[(rt * ks_in + j) * 64];
         for (int k0 = 0; k0 < P.kpad; k0 += kSarlKChunk) {
 #pragma unroll
             for (int j = 0; j < kSarlKChunk; ++j) bnxt[j] = wfrag[(k0 + kSarlKChunk + j) * 64];
-            __builtin_amdgcn_sched_barrier(0);  // keep the next trip's L2 requests ahead of this trip's MFMAs
-            float a[kSarlKChunk][RT];
 #pragma unroll
-            for (int j = 0; j < kSarlKChunk; ++j)
+            for (int j = kHead; j < kSarlKChunk; ++j)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[j][rt] = afrag[(rt * ks_in + k0 + j) * 64];
+                for (int rt = 0; rt < RT; ++rt) ar[j - kHead][rt] = afrag[(rt * ks_in + k0 + j) * 64];
+            __builtin_amdgcn_sched_barrier(0);  // requests first
 #pragma unroll
-            for (int j = 0; j < kSarlKChunk; ++j)
+            for (int j = 0; j < kHead; ++j)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][rt], bcur[j], acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j][rt], bcur[j], acc[rt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < kHead; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ah[j][rt] = afrag[(rt * ks_in + k0 + kSarlKChunk + j) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = kHead; j < kSarlKChunk; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j - kHead][rt], bcur[j], acc[rt], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < kSarlKChunk; ++j) bcur[j] = bnxt[j];
             __builtin_amdgcn_sched_barrier(0);
@@ -510,7 +669,7 @@ __device__ __forceinline__ void dense_vec1(const PackedLinear& P, const float* i
         const float* a = in + ((row >> 4) * ks_in) * 64 + (row & 15);
         float sum = 0.0f;
         for (int s = slice; s < P.ksteps; s += kSlices) {  // fragment (0, s): w[s * 64 + 16 j] = W[0][4 s + j]
-            const float* w = P.w + s * 64;
+            const gfloat_p w = as_global(P.w) + s * 64;
             const float* x = a + s * 64;
             sum += (x[0] * w[0] + x[16] * w[16]) + (x[32] * w[32] + x[48] * w[48]);
         }
@@ -518,7 +677,7 @@ __device__ __forceinline__ void dense_vec1(const PackedLinear& P, const float* i
     }
     __syncthreads();
     if (tid < kRows) {
-        float v = P.bias[0];
+        float v = as_global(P.bias)[0];
 #pragma unroll
         for (int s = 0; s < kSlices; ++s) v += scratch[s * kRows + tid];
         out[(tid >> 4) * ks_out * 64 + (tid & 15)] = v;
@@ -529,8 +688,149 @@ __device__ __forceinline__ void zero_lds(float* lds, size_t words, int tid) {
     for (size_t i = tid; i < words; i += kSarlThreads) lds[i] = 0.0f;
 }
 
+// Persistent form: a workgroup (one per CU: the tile's activations fill the LDS) strides over the tiles; LDS is zeroed once
+// per launch instead of once per tile (every k-padding word the MFMA loops read is either written by the producing layer —
+// whole column tiles — or zeroed explicitly below); layers are separated by lds_barrier, and every layer's first B
+// fragments are requested BEFORE the barrier that precedes it (dense_prefetch), while the previous layer's epilogue and the
+// barrier wait are still in progress.
 template <int H>
-__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, const float* X, float* V, int n_groups,
+                                                                int n_tiles) {
+    extern __shared__ float lds[];
+    float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
+    float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2
+    float* bufC = bufB + H * net.ks_b * 64;       // [H][ks_c][64]  mlp2 output (per-human feature)
+    float* gbuf = bufC + H * net.ks_c * 64;       // [ks_b][64]     mean over humans of h2
+    float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]     joint state / mlp3 ping
+    float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term / mlp3 pong
+    float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights, final value
+    float* vbuf = sbuf + H * net.ks_s * 64;       // [kSarlThreads] partial sums of the single-output layers
+
+    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    zero_lds(lds, (size_t)(vbuf - lds), tid);
+    const int nf = net.nf;
+    const int x_words = H * net.ks_x * 64;
+    float* xs = bufB;
+    BFrag pre = dense_prefetch(layer_of(net, kL_mlp1_0), wave, lane);
+    lds_barrier();
+    CN_SARL_CLOCK_BEGIN();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // Everything that depends only on the lane or on the descriptors is loop-invariant, and the compiler would hoist
+        // it: a dozen layers' worth of fragment addresses in VGPRs and pointers in SGPRs, live across the whole tile loop
+        // (128 VGPRs + scratch instead of 70).  Laundering the three ids and the arena base makes it recompute them where
+        // they are used — a few integer operations per layer.
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        SarlNetRef nn = net;
+        asm volatile("" : "+s"(nn.base));
+        const SarlNetRef* n = &nn;
+        // stage X: a straight coalesced copy (the feature kernel wrote fragment order)
+        const float* xg = X + (size_t)tile * x_words;
+        for (int i = tid; i < x_words; i += kSarlThreads) xs[i] = xg[i];
+        // k padding of the joint state (features 6 + nf .. of mlp3.0's k loop): the previous tile left mlp3.2's output there
+        for (int i = tid; i < kSarlGroups * (layer_of(*n, kL_mlp3_0).kpad * 4 - 6 - nf); i += kSarlThreads) {
+            const int g = i & 15, n = 6 + nf + (i >> 4);
+            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = 0.0f;
+        }
+        __syncthreads();  // X came from global memory: this one waits for it (and for the prefetch, an L2 hit by now)
+        CN_SARL_TICK(0);
+        // self_state = state[:, 0, :6] (sarl.py:36): features 0..5 of human 0's row of each group
+        if (tid < kSarlGroups * 6) {
+            const int g = tid & 15, n = tid >> 4;
+            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];
+        }
+        dense_mfma<H, true>(layer_of(*n, kL_mlp1_0), xs, n->ks_x, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
+        pre = dense_prefetch(layer_of(*n, kL_mlp1_2), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(1);
+        dense_mfma<H, true>(layer_of(*n, kL_mlp1_2), bufA, n->ks_a, bufB, n->ks_b, true, nullptr, wave, lane, &pre);  // h2
+        pre = dense_prefetch(layer_of(*n, kL_mlp2_0), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(2);
+        // global state: mean over the humans of a group (sarl.py:42) — elementwise over fragment offsets
+        if (n->with_global) {
+            for (int i = tid; i < n->ks_b * 64; i += kSarlThreads) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) sum += bufB[h * n->ks_b * 64 + i];
+                gbuf[i] = sum / (float)H;
+            }
+        }
+        dense_mfma<H, true>(layer_of(*n, kL_mlp2_0), bufB, n->ks_b, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
+        pre = dense_prefetch(layer_of(*n, kL_mlp2_2), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(3);
+        dense_mfma<H, true>(layer_of(*n, kL_mlp2_2), bufA, n->ks_a, bufC, n->ks_c, false, nullptr, wave, lane, &pre);  // features
+        // attention layer 0 on [h2 | global]: the global half is the same for every human of a group, so it is
+        // one 16-row product (kbuf) added to every row tile's accumulator at the matching group row
+        if (n->with_global) dense_mfma<1>(layer_of(*n, kL_att0_global), gbuf, n->ks_b, kbuf, n->ks_a, false, nullptr, wave, lane);
+        pre = dense_prefetch(layer_of(*n, kL_att0_local), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(4);
+        dense_mfma<H, true>(layer_of(*n, kL_att0_local), bufB, n->ks_b, bufA, n->ks_a, true, n->with_global ? kbuf : nullptr,
+                            wave, lane, &pre);
+        pre = dense_prefetch(layer_of(*n, kL_att_2), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(5);
+        dense_mfma<H, true>(layer_of(*n, kL_att_2), bufA, n->ks_a, bufB, n->ks_b, true, nullptr, wave, lane, &pre);
+        lds_barrier();
+        CN_SARL_TICK(6);
+        dense_vec1<H>(layer_of(*n, kL_att_4), bufB, n->ks_b, sbuf, n->ks_s, vbuf, tid);  // score (h, g) at h*ks_s*64 + g
+        pre = dense_prefetch(layer_of(*n, kL_mlp3_0), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(7);
+        // masked softmax without max subtraction (sarl.py:52-53)
+        if (tid < kSarlGroups) {
+            float e[H], total = 0.0f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float sc = sbuf[h * n->ks_s * 64 + tid];
+                e[h] = expf(sc) * (sc != 0.0f ? 1.0f : 0.0f);
+                total += e[h];
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) sbuf[h * n->ks_s * 64 + tid] = e[h] / total;
+        }
+        lds_barrier();
+        CN_SARL_TICK(8);
+        // weighted feature sum (sarl.py:60) -> joint state features 6 ..
+        for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
+            const int g = i & 15, c = i >> 4;
+            const int src = (c >> 2) * 64 + (c & 3) * 16 + g;
+            float sum = 0.0f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) sum += sbuf[h * n->ks_s * 64 + g] * bufC[h * n->ks_c * 64 + src];
+            const int n = 6 + c;
+            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = sum;
+        }
+        lds_barrier();
+        CN_SARL_TICK(9);
+        dense_mfma<1, true>(layer_of(*n, kL_mlp3_0), jbuf, n->ks_a, kbuf, n->ks_a, true, nullptr, wave, lane, &pre);
+        pre = dense_prefetch(layer_of(*n, kL_mlp3_2), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(10);
+        dense_mfma<1, true>(layer_of(*n, kL_mlp3_2), kbuf, n->ks_a, jbuf, n->ks_a, true, nullptr, wave, lane, &pre);
+        pre = dense_prefetch(layer_of(*n, kL_mlp3_4), wave, lane);
+        lds_barrier();
+        CN_SARL_TICK(11);
+        dense_mfma<1, true>(layer_of(*n, kL_mlp3_4), jbuf, n->ks_a, kbuf, n->ks_a, true, nullptr, wave, lane, &pre);
+        lds_barrier();
+        CN_SARL_TICK(12);
+        dense_vec1<1>(layer_of(*n, kL_mlp3_6), kbuf, n->ks_a, sbuf, n->ks_s, vbuf, tid);
+        pre = dense_prefetch(layer_of(*n, kL_mlp1_0), wave, lane);  // the next tile's first layer
+        lds_barrier();
+        CN_SARL_TICK(13);
+        if (tid < kSarlGroups) {
+            const size_t G = (size_t)tile * kSarlGroups + tid;
+            if (G < (size_t)n_groups) V[G] = sbuf[tid];
+        }
+        // sbuf / vbuf are next written after the next tile's first barriers: no extra barrier needed here
+    }
+    CN_SARL_CLOCK_END_N((n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+}
+
+template <int H>
+__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel_v1(SarlNet net, const float* X, float* V, int n_groups) {
     extern __shared__ float lds[];
     float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
     float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2

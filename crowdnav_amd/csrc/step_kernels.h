@@ -102,11 +102,14 @@ struct Smem {
 
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
 
-__host__ __device__ inline size_t smem_bytes(int nA, int pairs) {
-    return (size_t)nA * (16 + 16 + 16 + 4 * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 +
+// maxl: the candidate-form buffers (cand2, cand3) exist for the 5-half-plane kernels only — at 21 agents per env they
+// would cost the 10-half-plane kernels a resident workgroup per CU
+__host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl) {
+    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 4 : 2) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 +
            sizeof(double) * kMaxDiscount;
 }
 
+template <int MAXL>
 __device__ __forceinline__ Smem carve(const Params& P) {
     extern __shared__ double2 smem_raw[];
     Smem s;
@@ -117,8 +120,11 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
     s.proj = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
-    s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
-    s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.cand2 = s.cand3 = nullptr;
+    if (MAXL == 5) {
+        s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+        s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    }
     s.sol = reinterpret_cast<float4*>(p), p += 16 * nA;
     s.res = reinterpret_cast<float4*>(p), p += 16 * nA;
     s.rad = reinterpret_cast<double*>(p), p += 8 * nA;
@@ -581,7 +587,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
 
 template <int MAXL>
 __global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, float* out_vel) {
-    const Smem s = carve(P);
+    const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, 
 
 template <int MAXL, bool UNI>
 __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, StepIo io) {
-    const Smem s = carve(P);
+    const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);
@@ -909,7 +915,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     if (HEADLINE) {
         P.A = 6, P.NC = 5, P.E = 2, P.nA = 12, P.pairs = 60, P.threads = 64;
     }
-    const Smem s = carve(P);
+    const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);

@@ -254,11 +254,12 @@ CADRL_PARAM_ORDER = tuple('value_network.%d.%s' % (i, p) for i in (0, 2, 4, 6) f
 
 def _sarl_configure(self, actions, gamma=0.9, with_om=False, cell_num=4, cell_size=1.0, om_channel_size=3,
                     with_global_state=True, mlp1_dims=(150, 100), mlp2_dims=(100, 50), attention_dims=(100, 100, 1),
-                    mlp3_dims=(150, 100, 100, 1), model='sarl', interaction_dims=None):
+                    mlp3_dims=(150, 100, 100, 1), model='sarl', interaction_dims=None, query_env=True):
     """SARL.configure (or model='cadrl': mlp3_dims = [cadrl] mlp_dims; model='lstm_rl': mlp1_dims[0] = hidden width,
     mlp3_dims = [lstm_rl] mlp2_dims, interaction_dims = [lstm_rl] mlp1_dims when with_interaction_module) +
     build_action_space for
-    this engine.  actions: [K, 2] float64 ActionXY table (host)."""
+    this engine.  actions: [K, 2] float64 ActionXY table (host).  query_env=False: [action_space] query_env = false, the
+    constant-velocity human model + MultiHumanRL.compute_reward instead of the env's lookahead."""
     acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(-1, 2))
     cfg = _lib.CnSarlConfig(n_actions=len(acts), with_om=int(bool(with_om)), cell_num=int(cell_num),
                             om_channel_size=int(om_channel_size), cell_size=float(cell_size), gamma=float(gamma),
@@ -266,7 +267,8 @@ def _sarl_configure(self, actions, gamma=0.9, with_om=False, cell_num=4, cell_si
                             mlp1_dims=(C.c_int32 * 2)(*mlp1_dims), mlp2_dims=(C.c_int32 * 2)(*mlp2_dims),
                             attention_dims=(C.c_int32 * 3)(*attention_dims), mlp3_dims=(C.c_int32 * 4)(*mlp3_dims),
                             model={'sarl': 0, 'cadrl': 1, 'lstm_rl': 2}[model],
-                            interaction_dims=(C.c_int32 * 4)(*(interaction_dims or (0, 0, 0, 0))))
+                            interaction_dims=(C.c_int32 * 4)(*(interaction_dims or (0, 0, 0, 0))),
+                            constant_velocity_model=0 if query_env else 1, reserved=0)
     check(self._lib.cn_sarl_configure(self._h, C.byref(cfg), acts.ctypes.data_as(C.c_void_p)))
     self.sarl = dict(n_actions=len(acts), in_dim=13 + (cell_num ** 2 * om_channel_size if with_om else 0),
                      actions=acts, model=model, pairwise=bool(interaction_dims))

@@ -215,6 +215,14 @@ typedef struct cn_sarl_config {
     int32_t model;              /* CN_MODEL_SARL (0), CN_MODEL_CADRL (1) or CN_MODEL_LSTM_RL (2) */
     int32_t interaction_dims[4];/* CN_MODEL_LSTM_RL only: [lstm_rl] mlp1_dims (150, 100, 100, 50) when
                                    with_interaction_module, else all 0 */
+    int32_t constant_velocity_model; /* 0: [action_space] query_env = true — next human states and reward from the env's
+                                   onestep_lookahead (multi_human_rl.py:37-38).  1: query_env = false — every human keeps
+                                   its observed velocity for one step and the reward is MultiHumanRL.compute_reward
+                                   (multi_human_rl.py:39-42, 65-88: end-point distances, constants -0.25 / 1 / 0.2 / 0.5, no
+                                   time limit); for CN_MODEL_LSTM_RL the humans then enter the network in the order
+                                   LstmRL.predict sorted them (decreasing distance to the robot, lstm_rl.py:96-103).
+                                   SARL / LSTM-RL only: CADRL.predict always queries the env. */
+    int32_t reserved;
 } cn_sarl_config;
 
 /* replaces SARL.configure + CADRL.build_action_space: actions_host = double [n_actions][2] (ActionXY table, HOST

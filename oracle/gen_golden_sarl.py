@@ -53,11 +53,20 @@ def generate(name, with_om, robot_visible, cases, max_steps, policy_name='sarl',
             # re-derive the intermediates with the reference's own functions (nothing is patched)
             from crowd_sim.envs.utils.state import JointState
             js = JointState(robot.get_full_state(), ob)
+            if policy_name == 'lstm_rl':  # LstmRL.predict sorts the joint state it hands to MultiHumanRL.predict
+                me = np.array(js.self_state.position)
+                js.human_states = sorted(js.human_states, key=lambda h: np.linalg.norm(np.array(h.position) - me),
+                                         reverse=True)
             rewards, inputs, outs, nobs = [], [], [], None
             om = None
             for a in policy.action_space:
                 nself = policy.propagate(js.self_state, a)
-                nh, reward, _, _ = env.onestep_lookahead(a)
+                if policy.query_env:
+                    nh, reward, _, _ = env.onestep_lookahead(a)
+                else:  # multi_human_rl.py:39-42
+                    from crowd_sim.envs.utils.action import ActionXY
+                    nh = [policy.propagate(h, ActionXY(h.vx, h.vy)) for h in js.human_states]
+                    reward = policy.compute_reward(nself, nh)
                 batch = torch.cat([torch.Tensor([nself + h]) for h in nh], dim=0)
                 x = policy.rotate(batch).unsqueeze(0)
                 if with_om:
@@ -109,3 +118,10 @@ if __name__ == '__main__':
     generate('lstm_rl2_om.npz', with_om=True, robot_visible=True, cases=[13, 14], max_steps=8, policy_name='lstm_rl',
              extra={('lstm_rl', 'with_interaction_module'): 'true'})  # lstm_rl.ValueNetwork2
     generate('sarl_h12.npz', with_om=False, robot_visible=True, cases=[15, 16], max_steps=6, human_num=12)  # streamed humans
+    # [action_space] query_env = false: constant-velocity human model + MultiHumanRL.compute_reward
+    noq = {('action_space', 'query_env'): 'false'}
+    generate('sarl_noquery_om.npz', with_om=True, robot_visible=True, cases=[17, 18, 19], max_steps=12, extra=noq)
+    generate('lstm_rl_noquery_om.npz', with_om=True, robot_visible=True, cases=[20, 21], max_steps=12,
+             policy_name='lstm_rl', extra=noq)
+    generate('sarl_noquery_unicycle.npz', with_om=False, robot_visible=False, cases=[22, 23], max_steps=10,
+             kinematics='unicycle', extra=noq)

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header(built):
     assert built.CnConfig.device.offset == C.sizeof(built.CnConfig) - 12
     assert built.CnConfig.robot_kinematics.offset == C.sizeof(built.CnConfig) - 8
     assert C.sizeof(built.CnRolloutIo) == 8 + 8 + 8 + 8 + 8 + 13 * 8
-    assert C.sizeof(built.CnSarlConfig) == 16 + 16 + 4 + 8 + 8 + 12 + 16 + 4 + 16 + 4  # 104: ints, 2 doubles, dims, pad
+    assert C.sizeof(built.CnSarlConfig) == 16 + 16 + 4 + 8 + 8 + 12 + 16 + 4 + 16 + 4 + 8  # 112: ints, 2 doubles, dims, pad, model flags
 
 
 def test_no_cpu_fallback(built):

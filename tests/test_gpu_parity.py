@@ -289,6 +289,51 @@ def test_config4_shard_size_4096x20(amd, oracle_mod):
     assert still.sum() >= n // 2 and np.abs(s_full[:n][still] - o.get_state()[0][still]).max() <= 1e-9
 
 
+def test_config4_reference_geometry_20_humans_on_the_4m_circle(amd, oracle_mod):
+    """BASELINE configs[3] at the reference's own geometry (env.config: 20 humans on the circle of radius 4, where the
+    rejection sampling needs 28 k draws per scenario on average and 0.8 M for the worst of these seeds): the seeded
+    reset (wave-cooperative generator) against the oracle's plain MT19937 — same draw counts, positions 1e-12 —, then the
+    dense 21-agent crowd step for step (bit-identical velocities, rewards, states; the 10-half-plane programs and their
+    3-D fallback are busy from the first step), then the fused rollout with auto-reset from the scenario ring."""
+    n = 64
+    cfg = dict(num_humans=20, robot_visible=1, circle_radius=4.0)
+    seeds = 1000 + np.arange(n)  # the 'test' phase seeds (crowd_sim.py:272-276)
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=1, **cfg)
+    want_draws = o.reset(seeds)
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_ORCA, **cfg)
+    draws = _np(eng.reset(seeds))
+    assert np.array_equal(draws.astype(np.uint64), want_draws) and want_draws.max() > 100000
+    s0 = o.get_state()[0]
+    assert np.abs(_np(eng.get_state()[0]) - s0).max() <= 1e-12
+    eng.set_state(s0, np.zeros(n))
+    for t in range(100):
+        got = eng.step(None, update=True, want_obs=False)
+        want = o.step(None, update=True)
+        assert np.array_equal(_np(got['orca_vel']).view(np.uint32), want['orca_vel'].view(np.uint32)), t
+        for k in ('reward', 'done', 'info', 'dmin'):
+            assert np.array_equal(_np(got[k]), want[k]), (k, t)
+    assert np.array_equal(_np(eng.get_state()[0]), o.get_state()[0])
+    # fused rollout with in-kernel auto-reset: 16 envs x 120 steps, episodes of ~15-40 steps end and restart from the ring
+    m, K = 16, 12
+    eng2 = amd.BatchedCrowdSim(num_envs=m, robot_policy=amd.ROBOT_ORCA, **cfg)
+    bufs = eng2.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=-1, record_capacity=K)
+    for k in (30, 30, 60):
+        eng2.rollout(k)
+    eng2.sync()
+    o2 = oracle_mod.CrowdOracle(num_envs=m, robot_policy=1, **cfg)
+    o2.reset(1000 + np.arange(m))
+    ep_index, cur_steps, cur_ret = np.zeros(m, np.int32), np.zeros(m, np.int32), np.zeros(m, np.float64)
+    total, rec = o2.rollout(120, 1000, 500, K, ep_index, cur_steps, cur_ret)
+    assert int(_np(bufs['transitions'])[0]) == total == m * 120
+    cnt = _np(bufs['ep_count'])
+    assert np.array_equal(cnt, rec['count']) and cnt.sum() >= m
+    for b in range(m):
+        k = min(cnt[b], K)
+        assert np.array_equal(_np(bufs['ep_outcome'])[b, :k], rec['outcome'][b, :k])
+        assert np.array_equal(_np(bufs['ep_steps'])[b, :k], rec['steps'][b, :k])
+    assert np.abs(_np(eng2.get_state()[0]) - o2.get_state()[0]).max() <= 1e-9
+
+
 @pytest.fixture
 def wave_scenarios(monkeypatch):
     """Force the wave-per-scenario generators (default only for H > 8) so that they are checked on every fixture."""
