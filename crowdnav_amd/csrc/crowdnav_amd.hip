@@ -25,6 +25,7 @@
 
 #include "../../include/crowdnav_amd.h"
 #include "step_kernels.h"
+#include "rollout_fused.h"
 #include "records_kernels.h"
 #include "sarl_kernels.h"
 
@@ -537,6 +538,28 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
     return CN_OK;
 }
 
+// The transitions themselves: the four-barrier fused kernel (rollout_fused.h) for the small-crowd geometries it covers,
+// with BASELINE configs[1]'s geometry folded in as compile-time constants; the general phase kernel otherwise.
+static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, const double* action) {
+    const cn::Params& P = e->P;
+    static const bool use_fused = env_int("CROWDNAV_AMD_FUSED", 1) != 0;
+    const bool headline = P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 && P.threads == 64;
+    if (use_fused && e->maxl == 5 && !P.robot_unicycle && P.NC <= cn::kFusedMaxNC && P.pairs <= cn::kWave &&
+        P.nA * 5 <= cn::kWave && P.threads == cn::kWave) {
+        if (headline)
+            hipLaunchKernelGGL((cn::rollout_fused_kernel<true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
+                               n_steps, action);
+        else
+            hipLaunchKernelGGL((cn::rollout_fused_kernel<false>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
+                               n_steps, action);
+    } else if (e->maxl == 5 && !P.robot_unicycle && headline) {
+        hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
+                           n_steps, action);
+    } else {
+        CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, action);
+    }
+}
+
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     int rc = bind(e);
     if (rc) return rc;
@@ -549,13 +572,7 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
     if ((rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     if ((rc = fill_ring_if_needed(e, R, n_steps))) return rc;  // then the fused transitions
-    const cn::Params& P = e->P;
-    if (e->maxl == 5 && !P.robot_unicycle && P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 &&
-        P.threads == 64)  // BASELINE configs[1]: the instantiation with this geometry folded in
-        hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S,
-                           R, n_steps, (const double*)nullptr);
-    else
-        CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, (const double*)nullptr);
+    launch_rollout(e, R, n_steps, nullptr);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -569,7 +586,7 @@ int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action)
     if ((rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     if ((rc = fill_ring_if_needed(e, R, 1))) return rc;
-    CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, 1, action);
+    launch_rollout(e, R, 1, action);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }

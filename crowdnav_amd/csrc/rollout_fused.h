@@ -1,0 +1,349 @@
+// The fused rollout for the small-crowd geometries (<= 5 candidate neighbours per agent, one wave per workgroup,
+// holonomic robot): the same transition as step_core / rollout_kernel (step_kernels.h) — same functions for every number
+// it computes — with FOUR LDS exchange points per step instead of nine:
+//
+//   [stage]   agent lanes   float32 view of the agents, preferred velocities        (written at the END of the previous step)
+//   pairs     pair lanes    the agent's candidate distances in registers (no d2 round trip), rank, half-plane   -> barrier 1
+//   cands     (agent, half-plane) lanes   1-D solutions (lp_line_candidate)                                     -> barrier 2
+//   solve     agent lanes   scan (+ candidate-form 3-D fallback for the infeasible ones, 3 barriers only then);
+//                           the robot's action reaches its env's lanes by a wave shuffle, not through LDS;
+//                           float64 swept distance / goal distance                                             -> barrier 3
+//   reduce    agent lanes   EVERY lane of an env reduces the env's distances to reward / done / info itself (idle lanes
+//                           otherwise), so the episode bookkeeping that decides what the agents do next — advance, load the
+//                           next scenario from the ring, pause — needs no flag broadcast; integrate; stage the next step
+//                                                                                                                -> barrier 4
+// Per-env episode state (global_time, episodes finished, ring fill level, running / waiting / retired) is replicated on
+// the env's lanes; only the robot lane keeps the return / danger accumulators and writes records.
+// Launch conditions (cn_rollout / cn_rollout_step check them, everything else runs rollout_kernel): 5-half-plane
+// instantiation, NC <= 5, pairs <= 64, nA * 5 <= 64, 64 threads, holonomic robot.
+#pragma once
+#include "step_kernels.h"
+
+namespace cn {
+
+constexpr int kFusedMaxNC = 5;
+
+struct EpisodeRegs {  // replicated on every agent lane of the env
+    double gtime;
+    int state, ep_count, ring_filled;
+};
+
+__device__ __forceinline__ void stage_agent(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
+                                            float robot_max_speed, bool solve) {
+    if (L.lane >= P.nA) return;
+    // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
+    const double gdx = r.gx - r.px, gdy = r.gy - r.py;
+    const double speed = norm2(gdx, gdy);
+    const float pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
+    const float pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
+    const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
+    s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
+    s.posd[L.lane] = make_double2(r.px, r.py);
+    s.rad[L.lane] = r.rad;
+    s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
+    s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
+}
+
+template <bool HEADLINE>
+__global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, StateView S, RolloutView R, int n_steps,
+                                                              const double* ext_action) {
+    constexpr int MAXL = 5;
+    Params P = P_in;
+    if (HEADLINE) {  // BASELINE configs[1]: 5 humans + robot, 2 envs per wave, 60 pairs, as compile-time constants
+        P.A = 6, P.NC = 5, P.E = 2, P.nA = 12, P.pairs = 60, P.threads = 64;
+    }
+    const Smem s = carve<MAXL>(P);
+    const Lane L = lane_of(P);
+    AgentRegs r = {};
+    if (L.valid) load_agent(S, L.gi, r);
+    float robot_max_speed = 0.0f;
+    if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
+    build_pairs(P, s);
+
+    const bool robot = L.valid && L.a == 0;
+    // the ~20 pointers of the io block are needed at launch start / end and when an episode ends: they are re-read from
+    // the device copy there (scalar loads) instead of occupying SGPRs across the step loop
+    const cn_rollout_io* iop = R.io;
+    double theta = robot ? S.theta[L.env] : 0.0;
+    EpisodeRegs ep{0.0, kRetired, 0, 0};
+    double cur_return = 0.0, cur_dsum = 0.0;
+    int cur_steps = 0, cur_danger = 0;
+    if (L.valid) {
+        ep.gtime = S.gtime[L.env];
+        ep.state = iop->active[L.env];
+        ep.ep_count = iop->ep_count[L.env];
+        ep.ring_filled = S.ring_filled_in[L.env];
+    }
+    if (robot) {
+        cur_steps = iop->cur_steps[L.env];
+        cur_return = iop->cur_return[L.env];
+        if (iop->cur_danger) cur_danger = iop->cur_danger[L.env];
+        if (iop->cur_danger_dmin_sum) cur_dsum = iop->cur_danger_dmin_sum[L.env];
+    }
+    if (L.valid && ep.state == kWaitingScenario && ep.ep_count < ep.ring_filled) {  // the fill kernel has just produced it
+        load_from_ring(P, S, L, ep.ep_count % P.ring_depth, r);
+        ep.state = kRunning;
+        ep.gtime = 0.0;
+        theta = 1.5707963267948966;
+    }
+    unsigned int transitions = 0;
+    for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
+    __syncthreads();  // pinfo, rview
+    // this pair lane's row: the lanes of its agent's NC candidates (8 bits each) and which of them exist
+    int my_info = 0;
+    unsigned long long row_lanes = 0ull;
+    unsigned row_exists = 0u;
+    if (L.lane < P.pairs) {
+        my_info = s.pinfo[L.lane];
+        const int c = (my_info >> 16) & 0xff;
+        for (int k = 0; k < P.NC; ++k) {
+            const int ik = s.pinfo[L.lane - c + k];
+            row_lanes |= (unsigned long long)((ik >> 8) & 0xff) << (8 * k);
+            row_exists |= (unsigned)((ik >> 24) & 1) << k;
+        }
+    }
+    stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca));
+    __syncthreads();
+
+#ifdef CN_PHASE_TIMING
+    PhaseClock clock = {};
+    PhaseClock* clk = &clock;
+    clock.last = __builtin_readcyclecounter();
+#else
+    PhaseClock* clk = nullptr;
+    (void)clk;
+#endif
+    const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
+    for (int step = 0; step < n_steps; ++step) {
+        const bool running = L.valid && ep.state == kRunning;
+        const bool solve = running && (L.a > 0 || P.robot_orca);
+
+        // ---- pairs: candidate distances (Appendix A.2), stable rank = RVO2's sorted-insertion slot, half-plane (A.3)
+        if (L.lane < P.pairs) {
+            const int q = my_info & 0xff, c = (my_info >> 16) & 0xff;
+            const int ol = (my_info >> 8) & 0xff;
+            const float4 me = s.kin[q];
+            const float4 other = s.kin[ol];  // (read directly: selecting it out of the row below makes hipcc index a stack copy)
+            const float odx = me.x - other.x, ody = me.y - other.y;
+            const float mine = ((my_info >> 24) & 1) ? odx * odx + ody * ody : std::numeric_limits<float>::infinity();
+            float d2[kFusedMaxNC];
+#pragma unroll
+            for (int k = 0; k < kFusedMaxNC; ++k) {
+                d2[k] = std::numeric_limits<float>::infinity();
+                if (k < P.NC) {
+                    const float4 ot = s.kin[(int)((row_lanes >> (8 * k)) & 0xffull)];
+                    const float dx = me.x - ot.x, dy = me.y - ot.y;
+                    d2[k] = ((row_exists >> k) & 1u) ? dx * dx + dy * dy : std::numeric_limits<float>::infinity();
+                }
+            }
+            int rank = 0, within = 0;
+#pragma unroll
+            for (int k = 0; k < kFusedMaxNC; ++k) {
+                const float v = d2[k];
+                const bool in = v < range_sq;  // +inf beyond NC: never in range
+                within += in ? 1 : 0;
+                rank += (in && (v < mine || (v == mine && k < c))) ? 1 : 0;
+            }
+            if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
+            if (mine < range_sq && rank < P.orca.max_neighbors) {
+                const bool robot_sim = (my_info >> 25) & 1;
+                const float rsum = robot_sim ? s.rview[q] + s.rview[ol] : s.hview[q] + s.hview[ol];
+                s.lines[q * kLineStride + rank] =
+                    make_half_plane(P.orca, me.x, me.y, me.z, me.w, other.x, other.y, other.z, other.w, rsum);
+            }
+        }
+        __syncthreads();
+        CN_TICK(clk, 2);
+
+        // ---- candidates: lane = (agent, half-plane)
+        if (L.lane < P.nA * MAXL) {
+            const int q = L.lane / MAXL, k = L.lane - q * MAXL;
+            const float4 so = s.sol[q];
+            const float4* lq = s.lines + q * kLineStride;
+            s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
+            if (k == 0) {
+                float sx, sy;
+                lp_start_point(so.z, so.x, so.y, sx, sy);
+                s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
+            }
+        }
+        __syncthreads();
+
+        // ---- solve: scan, then the candidate-form fallback for the infeasible agents
+        float rx = 0.0f, ry = 0.0f;
+        int n = 0, fail = 0;
+        if (solve) {
+            n = s.count[L.lane];
+            const float4 start = s.res[L.lane];
+            rx = start.x, ry = start.y;
+            fail = lp_planar_scan<MAXL>(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, rx, ry);
+        }
+        CN_TICK(clk, 3);
+        const bool need = solve && fail < n;
+        const unsigned long long nm = __ballot(need);
+#ifdef CN_PHASE_TIMING
+        clock.acc[9] += __popcll(nm);
+#endif
+        if (nm != 0ull) {  // wave-uniform: some agent of this wave was infeasible
+            constexpr int kPairs = MAXL * (MAXL - 1) / 2;
+            if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
+            __syncthreads();
+            const int items = __popcll(nm) * kPairs;
+            for (int p = L.lane; p < items; p += kWave) {  // projections: lane = (agent, i, j)
+                const int t = p / kPairs, m = p - t * kPairs;
+                const int a = s.todo[t];
+                const int i = lp3_program_of(m), j = m - i * (i - 1) / 2;
+                const float4* la = s.lines + a * kLineStride;
+                s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
+            }
+            __syncthreads();
+            for (int p = L.lane; p < items; p += kWave) {  // their candidates: lane = (agent, i, k)
+                const int t = p / kPairs, m = p - t * kPairs;
+                const int a = s.todo[t];
+                const int i = lp3_program_of(m), base = i * (i - 1) / 2;
+                const float4 li = s.lines[a * kLineStride + i];
+                const float4* pa = s.proj + a * kLineStride + base;
+                s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
+            }
+            __syncthreads();
+            if (need)
+                lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
+                         fail, s.sol[L.lane].z, rx, ry);
+        }
+        CN_TICK(clk, 8);
+
+        // ---- the robot's action reaches every lane of its env (wave shuffle; caller-supplied actions: one load per lane)
+        double act_x, act_y;
+        if (P.robot_orca) {
+            act_x = (double)__shfl(rx, L.ebase);
+            act_y = (double)__shfl(ry, L.ebase);
+        } else {
+            act_x = L.valid ? ext_action[2 * (size_t)L.env] : 0.0;
+            act_y = L.valid ? ext_action[2 * (size_t)L.env + 1] : 0.0;
+        }
+        const double new_vx = (L.a == 0) ? act_x : (double)rx;
+        const double new_vy = (L.a == 0) ? act_y : (double)ry;
+
+        // ---- one float64 distance per agent lane (crowd_sim.py:331-351 for a human, :364-366 for the robot)
+        if (L.valid) {
+            const bool human = L.a > 0;
+            const double2 rp = s.posd[L.ebase];
+            const double x1 = r.px - rp.x, y1 = r.py - rp.y;
+            const double wx = r.vx - act_x, wy = r.vy - act_y;
+            const double x2 = x1 + wx * P.dt, y2 = y1 + wy * P.dt;
+            const double sx = x2 - x1, sy = y2 - y1;
+            double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
+            u = (u > 1.0) ? 1.0 : ((u < 0.0) ? 0.0 : u);
+            const bool degenerate = (sx == 0.0 && sy == 0.0);  // utils.py:11-13
+            const double cx = degenerate ? 0.0 - x1 : (x1 + u * sx) - 0.0;
+            const double cy = degenerate ? 0.0 - y1 : (y1 + u * sy) - 0.0;
+            const double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+            const double d = norm2(human ? cx : endx - r.gx, human ? cy : endy - r.gy);
+            s.closest[L.lane] = human ? d - r.rad - s.rad[L.ebase] : d;
+        }
+        __syncthreads();
+        CN_TICK(clk, 5);
+
+        // ---- reduce (every lane of the env, identically), integrate, episode bookkeeping, stage the next step
+        if (running) {
+            // the reference stops scanning at the first colliding human (dmin keeps the minimum seen before it)
+            double dmin = std::numeric_limits<double>::infinity();
+            bool collision = false;
+            for (int i = 1; i < P.A; ++i) {
+                const double c = s.closest[L.ebase + i];
+                const bool hit = c < 0.0;
+                dmin = (!collision && !hit && c < dmin) ? c : dmin;
+                collision = collision || hit;
+            }
+            const bool reaching = s.closest[L.ebase] < s.rad[L.ebase];
+            double reward;
+            int done, info;
+            if (ep.gtime >= P.time_limit - 1.0) {
+                reward = 0.0, done = 1, info = CN_TIMEOUT;
+            } else if (collision) {
+                reward = P.collision_penalty, done = 1, info = CN_COLLISION;
+            } else if (reaching) {
+                reward = P.success_reward, done = 1, info = CN_REACH_GOAL;
+            } else if (dmin < P.discomfort_dist) {
+                reward = (dmin - P.discomfort_dist) * P.discomfort_factor * P.dt;
+                done = 0, info = CN_DANGER;
+            } else {
+                reward = 0.0, done = 0, info = CN_NOTHING;
+            }
+            ep.gtime += P.dt;
+            r.px = r.px + new_vx * P.dt;  // Agent.step (agent.py:127-135)
+            r.py = r.py + new_vy * P.dt;
+            r.vx = new_vx;
+            r.vy = new_vy;
+            if (L.a == 0) {
+                ++transitions;
+                const double disc = cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0;
+                cur_return = cur_return + disc * reward;  // python sum(): left to right
+                ++cur_steps;
+                if (info == CN_DANGER) {
+                    ++cur_danger;
+                    cur_dsum += dmin;
+                }
+            }
+            if (done) {  // explorer.py:50-72: record, then the env's next episode
+                const cn_rollout_io io = *iop;
+                if (L.a == 0) {
+                    if (io.record_capacity > 0) {
+                        const size_t k = (size_t)L.env * io.record_capacity + (ep.ep_count % io.record_capacity);
+                        if (io.ep_outcome) io.ep_outcome[k] = (uint8_t)info;
+                        if (io.ep_steps) io.ep_steps[k] = cur_steps;
+                        if (io.ep_return) io.ep_return[k] = cur_return;
+                        if (io.ep_time) io.ep_time[k] = (info == CN_TIMEOUT) ? P.time_limit : ep.gtime;
+                        if (io.ep_danger) io.ep_danger[k] = cur_danger;
+                        if (io.ep_danger_dmin_sum) io.ep_danger_dmin_sum[k] = cur_dsum;
+                    }
+                    cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
+                }
+                ++ep.ep_count;
+                ep.gtime = 0.0;
+                const int64_t c = episode_id(io, L.env, ep.ep_count);
+                if (io.episode_limit >= 0 && c >= io.episode_limit) {
+                    ep.state = kRetired;
+                } else if (ep.ep_count < ep.ring_filled) {
+                    load_from_ring(P, S, L, ep.ep_count % P.ring_depth, r);
+                    theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
+                } else {
+                    ep.state = kWaitingScenario;  // ring ran dry: pause this env until the next launch has refilled it
+                }
+            }
+        }
+        stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca));
+        __syncthreads();
+        CN_TICK(clk, 7);
+    }
+#ifdef CN_PHASE_TIMING
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        for (int k = 0; k < 10; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
+        atomicAdd(&cn_phase_cycles[15], 1ull);
+    }
+#endif
+
+    if (L.valid) {
+        S.pos[L.gi] = make_double2(r.px, r.py);
+        S.vel[L.gi] = make_double2(r.vx, r.vy);
+        S.goal[L.gi] = make_double2(r.gx, r.gy);
+        S.rv[L.gi] = make_double2(r.rad, r.vpref);
+    }
+    if (robot) {
+        const cn_rollout_io io = *iop;
+        S.gtime[L.env] = ep.gtime;
+        S.theta[L.env] = theta;
+        if (P.robot_orca) S.rsim_valid[L.env] = 1;
+        io.active[L.env] = (uint8_t)ep.state;
+        io.ep_count[L.env] = ep.ep_count;
+        io.cur_steps[L.env] = cur_steps;
+        io.cur_return[L.env] = cur_return;
+        if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
+        if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
+#ifndef CN_EXP_NO_TRANS_ATOMIC
+        if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, (unsigned long long)transitions);
+#endif
+    }
+}
+
+}  // namespace cn
