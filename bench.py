@@ -223,6 +223,9 @@ def main():
     ap.add_argument('--humans', type=int, default=5)
     ap.add_argument('--chunk', type=int, default=1000, help='steps fused into one kernel launch')
     ap.add_argument('--circle-radius', type=float, default=4.0, help='scenario circle radius (reference default 4)')
+    ap.add_argument('--seed-base', type=int, default=2000, help="episode c is seeded seed_base + c %% seed_mod (default: the "
+                    "'train' phase numbering of crowd_sim.py:272-276, unbounded)")
+    ap.add_argument('--seed-mod', type=int, default=2 ** 32 - 2000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
                     help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
@@ -259,7 +262,7 @@ def main():
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
                                        robot_visible=1, device=local_rank, circle_radius=args.circle_radius)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
-    bufs = eng.rollout_begin(seed_base=2000, seed_mod=2 ** 32 - 2000, episode_limit=-1, record_capacity=4,
+    bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=4,
                              env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1])
 
     # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
@@ -293,7 +296,7 @@ def main():
     def shard_boundary():
         """episode records of this shard (one pack kernel) -> every rank (one RCCL all-gather) -> the job-wide summary
         of explorer.py:74-90 (one kernel): float64 [8] on the device"""
-        blocks = eng.rollout_records()
+        blocks = eng.rollout_records(max_records=1)  # one (the env's latest-slot) episode per env: 56 B per env to exchange
         if world > 1:
             blocks = cd.gather_blocks(blocks)
         return eng.records_summary(blocks)
@@ -340,6 +343,7 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: %d batched envs x %d humans per GPU, ORCA humans + holonomic '
                                'ORCA robot (visible), circle_crossing radius %g, in-kernel auto-reset' % (B, H, args.circle_radius),
                    'envs_per_gpu': B, 'humans': H, 'steps_per_launch': steps_per_launch, 'launches': launches,
+                   'episode_seeds': '%d + c %% %d' % (args.seed_base, args.seed_mod),
                    'preroll_steps': args.preroll,
                    'parallelism': 'env-axis shards x%d, all-gather of episode records at the end' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

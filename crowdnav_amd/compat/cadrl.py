@@ -36,8 +36,8 @@ class CADRL(SARL):
         self.cell_num = config.getint('om', 'cell_num')
         self.cell_size = config.getfloat('om', 'cell_size')
         self.om_channel_size = config.getint('om', 'om_channel_size')
-        if self.kinematics != 'holonomic':
-            raise NotImplementedError('only holonomic CADRL is on the accelerated path')
+        if self.kinematics not in ('holonomic', 'unicycle'):
+            raise NotImplementedError('kinematics %r' % self.kinematics)
         mlp_dims = [int(x) for x in config.get('cadrl', 'mlp_dims').split(', ')]
         self.model = ValueNetwork(self.joint_state_dim, mlp_dims)
         self.net_cfg = dict(gamma=self.gamma, mlp3_dims=mlp_dims, model='cadrl')
@@ -48,7 +48,7 @@ class CADRL(SARL):
         """Single-human training input (cadrl.py:174-185)."""
         assert len(state.human_states) == 1
         row = torch.Tensor(state.self_state + state.human_states[0]).to(self.device)
-        return rotate(row.unsqueeze(0)).squeeze(dim=0)
+        return rotate(row.unsqueeze(0), self.kinematics).squeeze(dim=0)
 
 
 # CADRL exposes no attention weights: CrowdSim.reset/step probe for the attribute (crowd_sim.py:301-304)

@@ -268,9 +268,8 @@ class CrowdSim(_Base):
     def sarl_action(self, policy):
         """Greedy SARL decision for the current device state: (best index | -1 stop | -2 invalid, 81 values)."""
         eng = self._eng
-        if self._rule == 'mixed':
-            raise NotImplementedError('value-network policies under the mixed rule (a different number of humans per '
-                                      'episode) are outside the accelerated path')
+        if self._rule == 'mixed' and eng.H != 5:
+            raise NotImplementedError('value networks under the mixed rule need the 5 human slots the rule can draw')
         if getattr(eng, 'sarl', None) is None:
             eng.sarl_configure(**policy.engine_kwargs())
         # re-upload the parameters only when the Trainer (or a load_state_dict) has changed them: torch bumps a

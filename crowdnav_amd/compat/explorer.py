@@ -53,12 +53,13 @@ class Explorer(object):
         batched_rl = (isinstance(self.robot.policy, SARL) and phase == 'train' and update_memory
                       and not imitation_learning and no_wrap and hasattr(self.env, 'engine_config')
                       and getattr(self.robot.policy, 'env', None) is self.env)
-        value_net = isinstance(self.robot.policy, SARL) or (update_memory and isinstance(self.target_policy, SARL))
-        if value_net and self._scenario_of(phase)[1] == 'mixed' and hasattr(self.env, 'engine_config'):
-            # the batched engines keep a fixed number of human slots and park the absent ones: a value network would see
-            # them as humans.  The per-episode loop below runs on the gym surface, whose sarl_action refuses the same way.
-            raise NotImplementedError('value-network policies under the mixed rule (a different number of humans per '
-                                      'episode) are outside the accelerated path')
+        value_net = isinstance(self.robot.policy, SARL) or isinstance(self.target_policy, SARL)
+        if value_net and update_memory and self._scenario_of(phase)[1] == 'mixed' and hasattr(self.env, 'engine_config'):
+            # Acting under the mixed rule works (the kernels mask an episode's absent humans); FILLING A REPLAY MEMORY does
+            # not: the states would hold a different number of humans per episode, which the reference cannot batch either
+            # (its DataLoader stacks them; train.config keeps train_val_sim = circle_crossing).
+            raise NotImplementedError('replay states under the mixed rule are ragged (a different number of humans per '
+                                      'episode): train on circle_crossing / square_crossing as the reference does')
         if batched_il:
             stats = self._run_batched_imitation(k, phase)
         elif batched_rl:

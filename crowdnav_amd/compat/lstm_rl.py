@@ -65,8 +65,8 @@ class LstmRL(SARL):
         self.cell_num = config.getint('om', 'cell_num')
         self.cell_size = config.getfloat('om', 'cell_size')
         self.om_channel_size = config.getint('om', 'om_channel_size')
-        if self.kinematics != 'holonomic':
-            raise NotImplementedError('only holonomic LSTM-RL is on the accelerated path')
+        if self.kinematics not in ('holonomic', 'unicycle'):
+            raise NotImplementedError('kinematics %r' % self.kinematics)
         pairwise = config.getboolean('lstm_rl', 'with_interaction_module')
         mlp_dims = [int(x) for x in config.get('lstm_rl', 'mlp2_dims').split(', ')]
         hidden = config.getint('lstm_rl', 'global_state_dim')

@@ -71,7 +71,8 @@ constexpr int kSarlMaxHumans = 8;    // register arrays of the occupancy map / L
                                      // (sarl_mlp_chunked_kernel streams them; one-tile kernels hold up to 5 at the shipped widths)
 constexpr int kSarlThreads = 1024;   // 16 waves per MLP workgroup (4 per SIMD: one wave's LDS/L2 waits hide behind the others' MFMAs)
 constexpr int kSarlKChunk = 5;       // k-steps per trip of the MFMA loop (= B fragments prefetched at a time): K = 100 is 25 k-steps
-constexpr int kSarlLayers = 12;      // packed linear layers (attention.0 is split into its two K halves)
+constexpr int kSarlLayers = 12;
+constexpr int kSarlChunk5 = 5;       // row tiles per chunk of the streamed (any number of humans) kernels      // packed linear layers (attention.0 is split into its two K halves)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -235,8 +236,9 @@ __device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf s
 // position p of the sorted joint state: the one whose stable rank equals p.  Distances are numpy's 2-vector norm of
 // (human.position - robot.position).
 __device__ inline int human_by_decreasing_distance(const double2* pos, size_t g0, int H, int p) {
-    double d[kSarlAnyHumans];
-    for (int j = 0; j < H; ++j) d[j] = norm2(pos[g0 + 1 + j].x - pos[g0].x, pos[g0 + 1 + j].y - pos[g0].y);
+    double d[kSarlAnyHumans];  // a parked (absent) human sorts behind every present one
+    for (int j = 0; j < H; ++j)
+        d[j] = is_parked(pos[g0 + 1 + j]) ? -1.0 - j : norm2(pos[g0 + 1 + j].x - pos[g0].x, pos[g0 + 1 + j].y - pos[g0].y);
     int who = p;
     for (int j = 0; j < H; ++j) {
         int rank = 0;
@@ -407,7 +409,8 @@ __device__ __forceinline__ void rotate_row(float px, float py, float vx, float v
 // store instruction writes 16 consecutive words per (tile, h).
 __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
                                     const double2* rv, const double* theta, const double* actions,
-                                    const double* next_obs, const float* om, float* X, size_t n_tiles) {
+                                    const double* next_obs, const float* om, float* X, size_t n_tiles,
+                                    int* hcount /*[n_tiles * 16] humans present per group*/) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_tiles * C.H * kSarlGroups) return;
     const int g = (int)(idx % kSarlGroups);
@@ -417,7 +420,14 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     float* x = X + ((tile * C.H + h) * ks_x) * 64 + g;
     if (G >= (size_t)C.B * C.n_actions) {  // padding groups of the last tile: finite zeros
         for (int n = 0; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+        if (h == 0) hcount[tile * kSarlGroups + g] = C.H;
         return;
+    }
+    if (h == 0) {  // len(state.human_states): under the `mixed` rule the env's absent humans are parked behind the present ones
+        const size_t e0 = (G / C.n_actions) * (size_t)(C.H + 1);
+        int present = 0;
+        for (int j = 0; j < C.H; ++j) present += is_parked(pos[e0 + 1 + j]) ? 0 : 1;
+        hcount[tile * kSarlGroups + g] = present;
     }
     const int a = (int)(G % C.n_actions);
     const int b = (int)(G / C.n_actions);
@@ -469,7 +479,8 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
         double d[kSarlMaxHumans];
 #pragma unroll
         for (int j = 0; j < kSarlMaxHumans; ++j)
-            d[j] = j < C.H ? norm2(pos[g0 + 1 + j].x - pos[g0].x, pos[g0 + 1 + j].y - pos[g0].y) : -1.0;
+            d[j] = (j < C.H && !is_parked(pos[g0 + 1 + j])) ? norm2(pos[g0 + 1 + j].x - pos[g0].x, pos[g0 + 1 + j].y - pos[g0].y)
+                                                            : -1.0 - j;
 #pragma unroll
         for (int j = 0; j < kSarlMaxHumans; ++j) {
             int rank = 0;
@@ -695,7 +706,7 @@ __device__ __forceinline__ void zero_lds(float* lds, size_t words, int tid) {
 // barrier wait are still in progress.
 template <int H>
 __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, const float* X, float* V, int n_groups,
-                                                                int n_tiles) {
+                                                                int n_tiles, const int* hcount) {
     extern __shared__ float lds[];
     float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
     float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2
@@ -705,6 +716,7 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, 
     float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term / mlp3 pong
     float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights, final value
     float* vbuf = sbuf + H * net.ks_s * 64;       // [kSarlThreads] partial sums of the single-output layers
+    int* hc = reinterpret_cast<int*>(vbuf + kSarlThreads);  // [16] humans present per group (H unless the `mixed` rule)
 
     int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     zero_lds(lds, (size_t)(vbuf - lds), tid);
@@ -727,6 +739,7 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, 
         // stage X: a straight coalesced copy (the feature kernel wrote fragment order)
         const float* xg = X + (size_t)tile * x_words;
         for (int i = tid; i < x_words; i += kSarlThreads) xs[i] = xg[i];
+        if (tid < kSarlGroups) hc[tid] = hcount[(size_t)tile * kSarlGroups + tid];
         // k padding of the joint state (features 6 + nf .. of mlp3.0's k loop): the previous tile left mlp3.2's output there
         for (int i = tid; i < kSarlGroups * (layer_of(*n, kL_mlp3_0).kpad * 4 - 6 - nf); i += kSarlThreads) {
             const int g = i & 15, n = 6 + nf + (i >> 4);
@@ -750,10 +763,11 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, 
         // global state: mean over the humans of a group (sarl.py:42) — elementwise over fragment offsets
         if (n->with_global) {
             for (int i = tid; i < n->ks_b * 64; i += kSarlThreads) {
+                const int cnt = hc[i & 15];
                 float sum = 0.0f;
 #pragma unroll
-                for (int h = 0; h < H; ++h) sum += bufB[h * n->ks_b * 64 + i];
-                gbuf[i] = sum / (float)H;
+                for (int h = 0; h < H; ++h) sum += h < cnt ? bufB[h * n->ks_b * 64 + i] : 0.0f;
+                gbuf[i] = sum / (float)cnt;
             }
         }
         dense_mfma<H, true>(layer_of(*n, kL_mlp2_0), bufB, n->ks_b, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
@@ -782,10 +796,11 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, 
         // masked softmax without max subtraction (sarl.py:52-53)
         if (tid < kSarlGroups) {
             float e[H], total = 0.0f;
+            const int cnt = hc[tid];
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 const float sc = sbuf[h * n->ks_s * 64 + tid];
-                e[h] = expf(sc) * (sc != 0.0f ? 1.0f : 0.0f);
+                e[h] = h < cnt ? expf(sc) * (sc != 0.0f ? 1.0f : 0.0f) : 0.0f;  // an absent human carries no weight
                 total += e[h];
             }
 #pragma unroll
@@ -1065,7 +1080,8 @@ __host__ inline size_t sarl_mlp_chunked_lds_bytes(const SarlNet& net) {
 }
 
 template <int H>
-__global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+__global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups,
+                                                                 const int* hcount) {
     extern __shared__ float lds[];
     float* bufA = lds;
     float* bufB = bufA + H * net.ks_a * 64;
@@ -1086,15 +1102,65 @@ __global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, co
     dense_mfma<H>(net.L[kL_mlp3_6], bufA, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
     __syncthreads();
     if (tid < kSarlGroups) {
+        const int cnt = hcount[tile * kSarlGroups + tid];  // humans present (H unless the `mixed` rule)
         float m = sbuf[tid];
 #pragma unroll
         for (int h = 1; h < H; ++h) {
             const float v = sbuf[h * net.ks_s * 64 + tid];
-            m = v < m ? v : m;  // torch.min over dim 0: the first minimum's value
+            m = (h < cnt && v < m) ? v : m;  // torch.min over dim 0: the first minimum's value
         }
         const size_t G = tile * kSarlGroups + tid;
         if (G < (size_t)n_groups) V[G] = m;
     }
+}
+
+// cadrl.ValueNetwork for MORE humans than the one-tile kernel holds (H > kSarlMaxHumans): the humans of a tile's 16
+// groups stream through in chunks of HC row tiles, the per-group minimum (cadrl.py:162-163) accumulates in LDS.  Rows of a
+// partial last chunk run on zero inputs and are left out of the minimum.
+template <int HC>
+__global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_chunked_kernel(SarlNet net, const float* X, float* V,
+                                                                         int n_groups) {
+    extern __shared__ float lds[];
+    const int H = net.H;
+    float* bufA = lds;                             // [HC][ks_a][64]
+    float* bufB = bufA + HC * net.ks_a * 64;       // [HC][ks_b][64]
+    float* sbuf = bufB + HC * net.ks_b * 64;       // [HC][ks_s][64]
+    float* vmin = sbuf + HC * net.ks_s * 64;       // [16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t tile = blockIdx.x;
+    const float* xg = X + tile * H * net.ks_x * 64;
+    zero_lds(lds, (size_t)HC * (net.ks_a + net.ks_b + net.ks_s) * 64 + 16, tid);
+    __syncthreads();
+    for (int h0 = 0; h0 < H; h0 += HC) {
+        const int nh = H - h0 < HC ? H - h0 : HC;
+        for (int i = tid; i < HC * net.ks_x * 64; i += kSarlThreads)
+            bufB[i] = (i / (net.ks_x * 64) < nh) ? xg[(size_t)h0 * net.ks_x * 64 + i] : 0.0f;
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp3_0], bufB, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp3_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp3_4], bufB, net.ks_b, bufA, net.ks_a, true, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<HC>(net.L[kL_mlp3_6], bufA, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
+        __syncthreads();
+        if (tid < kSarlGroups) {
+            float m = h0 == 0 ? sbuf[tid] : vmin[tid];
+            for (int rt = (h0 == 0 ? 1 : 0); rt < nh; ++rt) {
+                const float v = sbuf[rt * net.ks_s * 64 + tid];
+                m = v < m ? v : m;  // torch.min over dim 0: the first minimum's value
+            }
+            vmin[tid] = m;
+        }
+        __syncthreads();
+    }
+    if (tid < kSarlGroups) {
+        const size_t G = tile * kSarlGroups + tid;
+        if (G < (size_t)n_groups) V[G] = vmin[tid];
+    }
+}
+__host__ inline size_t cadrl_mlp_chunked_lds_bytes(const SarlNet& net) {
+    return sizeof(float) * ((size_t)kSarlChunk5 * (net.ks_a + net.ks_b + net.ks_s) * 64 + 16);
 }
 
 // lstm_rl.ValueNetwork1 / ValueNetwork2 (lstm_rl.py:9-66): an LSTM over the humans of a group (in the order the lookahead returns
@@ -1102,7 +1168,8 @@ __global__ __launch_bounds__(kSarlThreads) void cadrl_mlp_kernel(SarlNet net, co
 // weight_ih / bias_ih, L[kL_mlp1_2] = weight_hh / bias_hh (torch gate order i, f, g, o), L[kL_mlp3_*] = the head.
 // Row tile t of X is human t of the 16 groups = LSTM time step t, so each step is a 16-row product.
 template <int H>
-__global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+__global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, const float* X, float* V, int n_groups,
+                                                                const int* hcount) {
     extern __shared__ float lds[];
     const int hid = net.L[kL_mlp1_2].K;                   // hidden width (50)
     const int ks_h = sarl_ks(hid), ks_g = net.L[kL_mlp1_0].ctiles * 4;
@@ -1152,6 +1219,87 @@ __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, con
         __syncthreads();
         for (int i = tid; i < hid * kSarlGroups; i += kSarlThreads) {
             const int g = i & 15, j = i >> 4;
+            if (t >= hcount[tile * kSarlGroups + g]) continue;  // `mixed` rule: this group's episode has fewer humans
+            auto at = [&](int n) { return gates[(n >> 2) * 64 + (n & 3) * 16 + g]; };
+            const float ig = 1.0f / (1.0f + expf(-at(j)));
+            const float fg = 1.0f / (1.0f + expf(-at(hid + j)));
+            const float gg = tanhf(at(2 * hid + j));
+            const float og = 1.0f / (1.0f + expf(-at(3 * hid + j)));
+            const float c = fg * cbuf[i] + ig * gg;
+            cbuf[i] = c;
+            hbuf[(j >> 2) * 64 + (j & 3) * 16 + g] = og * tanhf(c);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < hid * kSarlGroups; i += kSarlThreads) {
+        const int g = i & 15, j = i >> 4, n = 6 + j;
+        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = hbuf[(j >> 2) * 64 + (j & 3) * 16 + g];
+    }
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
+    __syncthreads();
+    dense_mfma<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, false, nullptr, wave, lane);
+    __syncthreads();
+    if (tid < kSarlGroups) {
+        const size_t G = tile * kSarlGroups + tid;
+        if (G < (size_t)n_groups) V[G] = sbuf[tid];
+    }
+}
+
+// lstm_rl.ValueNetwork1 / ValueNetwork2 for ANY number of humans (H > kSarlMaxHumans): the LSTM is sequential over the
+// humans anyway, so human t's input row tile is staged (and, with the interaction module, passed through mlp1 as 16-row
+// products) right before LSTM step t; nothing is sized by H.
+__global__ __launch_bounds__(kSarlThreads) void lstm_mlp_anyh_kernel(SarlNet net, const float* X, float* V, int n_groups) {
+    extern __shared__ float lds[];
+    const int H = net.H;
+    const int hid = net.L[kL_mlp1_2].K;
+    const int ks_h = sarl_ks(hid), ks_g = net.L[kL_mlp1_0].ctiles * 4;
+    float* xs = lds;                                       // [ks_x][64]   this step's input row tile
+    float* pbuf = xs + net.ks_x * 64;                      // [ks_b][64]   ValueNetwork2.mlp1 ping
+    float* qbuf = pbuf + net.ks_b * 64;                    // [ks_c][64]   ... pong
+    float* gates = qbuf + net.ks_c * 64;                   // [ks_g][64]
+    float* hbuf = gates + ks_g * 64;                       // [ks_h][64]
+    float* cbuf = hbuf + ks_h * 64;                        // [hid][16]
+    float* jbuf = cbuf + hid * kSarlGroups;                // [ks_a][64]
+    float* kbuf = jbuf + net.ks_a * 64;                    // [ks_a][64]
+    float* sbuf = kbuf + net.ks_a * 64;                    // [ks_s][64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t tile = blockIdx.x;
+    zero_lds(lds, (size_t)((sbuf + net.ks_s * 64) - lds), tid);
+    __syncthreads();
+    const float* xg = X + tile * H * net.ks_x * 64;
+    const bool pairwise = net.L[kL_mlp2_0].w != nullptr;
+    for (int t = 0; t < H; ++t) {
+        for (int i = tid; i < net.ks_x * 64; i += kSarlThreads) xs[i] = xg[(size_t)t * net.ks_x * 64 + i];
+        __syncthreads();
+        if (t == 0 && tid < kSarlGroups * 6) {  // self_state = state[:, 0, :6]
+            const int g = tid & 15, n = tid >> 4;
+            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];
+        }
+        const float* lstm_in = xs;
+        int ks_in = net.ks_x;
+        if (pairwise) {
+            dense_mfma<1>(net.L[kL_mlp2_0], xs, net.ks_x, pbuf, net.ks_b, true, nullptr, wave, lane);
+            __syncthreads();
+            dense_mfma<1>(net.L[kL_mlp2_2], pbuf, net.ks_b, qbuf, net.ks_c, true, nullptr, wave, lane);
+            __syncthreads();
+            dense_mfma<1>(net.L[kL_att_2], qbuf, net.ks_c, pbuf, net.ks_b, true, nullptr, wave, lane);
+            __syncthreads();
+            dense_mfma<1>(net.L[kL_att_4], pbuf, net.ks_b, qbuf, net.ks_c, false, nullptr, wave, lane);
+            __syncthreads();
+            lstm_in = qbuf;
+            ks_in = net.ks_c;
+        }
+        dense_mfma<1>(net.L[kL_mlp1_0], lstm_in, ks_in, gates, ks_g, false, nullptr, wave, lane);
+        __syncthreads();
+        dense_mfma<1>(net.L[kL_mlp1_2], hbuf, ks_h, gates, ks_g, false, gates, wave, lane);
+        __syncthreads();
+        for (int i = tid; i < hid * kSarlGroups; i += kSarlThreads) {
+            const int g = i & 15, j = i >> 4;
             auto at = [&](int n) { return gates[(n >> 2) * 64 + (n & 3) * 16 + g]; };
             const float ig = 1.0f / (1.0f + expf(-at(j)));
             const float fg = 1.0f / (1.0f + expf(-at(hid + j)));
@@ -1184,7 +1332,7 @@ __global__ __launch_bounds__(kSarlThreads) void lstm_mlp_kernel(SarlNet net, con
 
 __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
     const size_t H = (size_t)net.H;
-    return sizeof(float) * (64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a) + kSarlThreads);
+    return sizeof(float) * (64 * (H * (net.ks_a + net.ks_b + net.ks_c + net.ks_s) + net.ks_b + 2 * net.ks_a) + kSarlThreads + 16);
 }
 
 // ------------------------------------------------------------------------------------ action selection

@@ -141,7 +141,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
                 for (int k = 0; k < i; ++k) {
                     const double2 p = s.ppos[k], g = s.pgoal[k];
                     const double min_dist = radius + s.prad[k] + c.discomfort_dist;
-                    if (norm2(x - p.x, y - p.y) < min_dist || norm2(x - g.x, y - g.y) < min_dist) {
+                    if (closer_than(x - p.x, y - p.y, min_dist) || closer_than(x - g.x, y - g.y, min_dist)) {
                         collide = true;
                         break;
                     }
@@ -178,7 +178,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
                     bool collide = false;
                     for (int k = 0; k < i; ++k) {
                         const double2 q = pass == 0 ? s.ppos[k] : s.pgoal[k];
-                        if (norm2(x - q.x, y - q.y) < radius + s.prad[k] + c.discomfort_dist) {
+                        if (closer_than(x - q.x, y - q.y, radius + s.prad[k] + c.discomfort_dist)) {
                             collide = true;
                             break;
                         }

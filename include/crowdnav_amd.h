@@ -184,9 +184,9 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
  * SARL robot decision (crowd_nav/policy/sarl.py:9-86 on top of multi_human_rl.py:11-63, cadrl.py:82-222).
  * Needs robot_policy == CN_ROBOT_EXTERNAL: the chosen action is then applied with cn_step(action). */
 /* value network behind cn_sarl_select:
- *   CN_MODEL_SARL   sarl.ValueNetwork (attention over humans, sarl.py:9-65); any num_humans: crowds beyond one tile's
- *                   LDS (6+ humans at the shipped widths) stream through in chunks; occupancy maps up to 8 humans.
- *                   CADRL and LSTM-RL: up to 8 humans.
+ *   CN_MODEL_SARL   sarl.ValueNetwork (attention over humans, sarl.py:9-65).  Every model takes any num_humans the engine
+ *                   holds (<= 63): crowds beyond one tile's LDS (6+ humans at the shipped SARL widths, 9+ for CADRL /
+ *                   LSTM-RL) stream through the tile in chunks; occupancy maps and LSTM-RL's distance ordering likewise.
  *   CN_MODEL_CADRL  cadrl.ValueNetwork: one MLP per (robot, human) pair, value = min over humans
  *                   (crowd_nav/policy/cadrl.py:22-29, 156-168); only mlp3_dims (= [cadrl] mlp_dims), n_actions, gamma
  *                   are read; cn_sarl_set_weights then takes 8 pointers (value_network.{0,2,4,6}.{weight,bias})

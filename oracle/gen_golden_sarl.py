@@ -118,6 +118,10 @@ if __name__ == '__main__':
     generate('lstm_rl2_om.npz', with_om=True, robot_visible=True, cases=[13, 14], max_steps=8, policy_name='lstm_rl',
              extra={('lstm_rl', 'with_interaction_module'): 'true'})  # lstm_rl.ValueNetwork2
     generate('sarl_h12.npz', with_om=False, robot_visible=True, cases=[15, 16], max_steps=6, human_num=12)  # streamed humans
+    # crowds beyond the one-tile kernels (more than 8 humans): occupancy maps, LSTM-RL ordering, CADRL minimum
+    generate('sarl_om_h12.npz', with_om=True, robot_visible=True, cases=[24], max_steps=6, human_num=12)
+    generate('lstm_rl_om_h12.npz', with_om=True, robot_visible=True, cases=[25], max_steps=6, policy_name='lstm_rl', human_num=12)
+    generate('cadrl_h12.npz', with_om=False, robot_visible=True, cases=[26], max_steps=6, policy_name='cadrl', human_num=12)
     # [action_space] query_env = false: constant-velocity human model + MultiHumanRL.compute_reward
     noq = {('action_space', 'query_env'): 'false'}
     generate('sarl_noquery_om.npz', with_om=True, robot_visible=True, cases=[17, 18, 19], max_steps=12, extra=noq)

@@ -1,0 +1,44 @@
+"""bench.py's JSON line must be true under ANY --steps / --chunk: PMC-derived fields (roofline.traffic, issue_roofline) are
+only attached when a committed rocprofv3 record describes exactly the launch shape that was timed, and the vector-issue
+peak is the MI355X figure (SIMD-32: one wave64 VALU instruction per 2 cycles)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_pmc_fields_only_for_the_profiled_launch_shape(tmp_path, monkeypatch):
+    import bench
+    prof = tmp_path / 'traffic.json'
+    prof.write_text(json.dumps({'profiles': [
+        dict(envs=4096, humans=5, steps_per_launch=1000, fetch_size_kb=1000.0, write_size_kb=500.0, sq_insts_valu=2.0e9),
+        dict(envs=4096, humans=5, steps_per_launch=20, fetch_size_kb=100.0, write_size_kb=50.0, sq_insts_valu=4.0e7)]}))
+    monkeypatch.setattr(bench, 'PMC_PROFILE', str(prof))
+    assert bench.pmc_profile(4096, 5, 100) is None          # a 100-step launch has no profile: no traffic, no issue roofline
+    assert bench.pmc_traffic_bytes(None) is None and bench.pmc_issue(None, 4096, 100, 1e-3) is None
+    short = bench.pmc_profile(4096, 5, 20)
+    assert bench.pmc_traffic_bytes(short) == (2 * 100.0 + 50.0) * 1024   # FETCH_SIZE doubled (gfx950 correction)
+    issue = bench.pmc_issue(short, 4096, 20, 100e-6)
+    assert issue['peak'] == 1024 * 2.4 / 2                   # G wave-instructions/s: 2 cycles per wave64 VALU op
+    assert abs(issue['achieved'] - 4.0e7 / 100e-6 / 1e9) < 1e-9 and 0.0 < issue['frac'] < 1.0
+    assert abs(issue['valu_per_env_step'] - 4.0e7 / (4096 * 20)) < 1e-9
+    long = bench.pmc_profile(4096, 5, 1000)
+    assert long['sq_insts_valu'] == 2.0e9 and bench.pmc_profile(4096, 20, 1000) is None
+
+
+def test_committed_pmc_profile_is_well_formed():
+    import bench
+    if not os.path.exists(bench.PMC_PROFILE):
+        return
+    doc = json.load(open(bench.PMC_PROFILE))
+    shapes = [(p['envs'], p['humans'], p['steps_per_launch']) for p in doc['profiles']]
+    assert len(shapes) == len(set(shapes))
+    for p in doc['profiles']:
+        assert p['fetch_size_kb'] > 0 and p['write_size_kb'] > 0 and p['sq_insts_valu'] > 0
+
+
+def test_algorithmic_bytes_follow_the_survey():
+    import bench
+    assert bench.algorithmic_bytes_per_env_step(5) == 458 and bench.algorithmic_bytes_per_env_step(20) == 1538

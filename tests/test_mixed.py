@@ -178,3 +178,67 @@ def test_gym_surface_mixed_rule():
         assert len(ob) == eps[3]['count'] and abs(reward - eps[3]['rewards'][t]) <= 1e-9  # start differs by <= 1e-12
         t += 1
     assert t == len(eps[3]['actions'])
+
+
+# ---- value networks acting under the mixed rule (a different number of humans per episode) -----------------------------
+def _parked_states(states):
+    """fixture rows padded with NaN -> the engine's representation: absent humans parked at rest far away, behind the
+    present ones (scenario_device.h: kParkedX)."""
+    s = states.copy()
+    for b in range(len(s)):
+        for i in range(1, 6):
+            if np.isnan(s[b, i, 0]):
+                x = 1.0e6 + 100.0 * i
+                s[b, i] = [x, 1.0e6, 0.0, 0.0, x, 1.0e6, 0.3, 1.0]
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('policy', ['sarl', 'cadrl', 'lstm_rl'])
+def test_value_networks_mask_the_absent_humans_of_a_mixed_episode(policy):
+    """SARL (attention: mean and softmax over the humans present), CADRL (minimum over them) and LSTM-RL (one LSTM step per
+    human present) on episodes with 1, 2, 3 and 5 humans, vs the unmodified reference acting under test_sim = mixed."""
+    import torch
+    import crowdnav_amd
+    from crowdnav_amd.compat import cadrl, lstm_rl, sarl
+    g = load_golden('mixed_sarl.npz')
+    pre = policy + '_'
+    states = _parked_states(g[pre + 'states'])
+    n = len(states)
+    assert sorted(set(g[pre + 'count'].tolist())) == [1, 2, 3, 5]
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1,
+                                       scenario_rule=crowdnav_amd.MIXED)
+    eng.set_state(states, g[pre + 'gtime'])
+    assert np.array_equal(eng.human_count().cpu().numpy(), g[pre + 'count'])
+    params = {k[len(pre + 'param_'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre + 'param_')}
+    if policy == 'sarl':
+        net = sarl.ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+        cfg = {}
+    elif policy == 'cadrl':
+        net = cadrl.ValueNetwork(13, [150, 100, 100, 1])
+        cfg = dict(model='cadrl', mlp3_dims=(150, 100, 100, 1))
+    else:
+        net = lstm_rl.ValueNetwork1(13, 6, [150, 100, 100, 1], 50)
+        cfg = dict(model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
+    net.load_state_dict(params)
+    eng.sarl_configure(actions=g[pre + 'action_space'], gamma=0.9, **cfg)
+    eng.sarl_set_weights(net.state_dict())
+    out = eng.sarl_select()
+    eng.sync()
+    values = out['values'].cpu().numpy()
+    assert np.abs(values - g[pre + 'values']).max() <= 1e-6
+    top2 = np.sort(g[pre + 'values'], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 4e-6
+    assert clear.sum() >= n // 4
+    assert np.array_equal(out['best'].cpu().numpy()[clear], g[pre + 'best'][clear])
+    assert np.array_equal(out['action'].cpu().numpy()[clear], g[pre + 'action'][clear])
+
+
+@pytest.mark.gpu
+def test_mixed_value_networks_need_five_slots():
+    import crowdnav_amd
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=4, num_humans=6, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                       scenario_rule=crowdnav_amd.MIXED)
+    acts = np.zeros((81, 2))
+    with pytest.raises(crowdnav_amd.CrowdNavAmdError):
+        eng.sarl_configure(actions=acts)  # 6 slots stream through the chunked kernel, which does not mask
