@@ -348,8 +348,8 @@ def main():
                    'parallelism': 'env-axis shards x%d, all-gather of episode records at the end' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof),
-                     'kernel': 'cn::rollout_kernel (one cn_rollout call; + cn::ring_fill_kernel when the scenario ring '
-                               'needs topping up)',
+                     'kernel': 'cn::rollout_fused_kernel (one cn_rollout call; + cn::ring_fill_kernel when the scenario '
+                               'ring needs topping up)' if H <= 5 else 'cn::rollout_kernel<10> (+ cn::ring_fill_wave_kernel)',
                      'avg_launch_ms': avg_launch_s * 1e3,
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
         'issue_roofline': pmc_issue(prof, B, steps_per_launch, avg_launch_s),
