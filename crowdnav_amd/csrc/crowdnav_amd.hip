@@ -61,6 +61,7 @@ struct cn_engine {
     hipStream_t stream;
     cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
     cn_rollout_io* io_dev;   // device copy the rollout kernels read through
+    cn::StateView* S_dev;    // device copy of S (the fused rollout kernel re-reads state pointers instead of holding them)
     bool io_valid;
     int steps_since_fill;    // transitions launched since the scenario ring was last topped up; < 0 = never filled
     struct cn_sarl* sarl;    // SARL decision state (sarl_abi.inc), NULL until cn_sarl_configure
@@ -248,9 +249,14 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.redo_count, (size_t)1)) ||
         (rc = dev_alloc(e, &e->summary_scratch, (size_t)cn::kSummaryBlocks * cn::kSummaryFields + 1)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
-        (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1))) {
+        (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1)) ||
+        (rc = dev_alloc(e, &e->S_dev, (size_t)1))) {
         cn_destroy(e);
         return rc;
+    }
+    if (hipMemcpy(e->S_dev, &e->S, sizeof(cn::StateView), hipMemcpyHostToDevice) != hipSuccess) {
+        cn_destroy(e);
+        return fail(CN_ERR_HIP, "cn_create: state view upload failed");
     }
     e->discount = nullptr;
     e->discount_len = 0;
@@ -547,11 +553,11 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     if (use_fused && e->maxl == 5 && !P.robot_unicycle && P.NC <= cn::kFusedMaxNC && P.pairs <= cn::kWave &&
         P.nA * 5 <= cn::kWave && P.threads == cn::kWave) {
         if (headline)
-            hipLaunchKernelGGL((cn::rollout_fused_kernel<true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
-                               n_steps, action);
+            hipLaunchKernelGGL((cn::rollout_fused_kernel<true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
+                               (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
         else
-            hipLaunchKernelGGL((cn::rollout_fused_kernel<false>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
-                               n_steps, action);
+            hipLaunchKernelGGL((cn::rollout_fused_kernel<false>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
+                               (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else if (e->maxl == 5 && !P.robot_unicycle && headline) {
         hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
                            n_steps, action);

@@ -189,16 +189,23 @@ __device__ __forceinline__ float4 lp_line_candidate(const float4 lk, const float
 // Returns the first infeasible half-plane or n; (rx, ry) enters as the start point.
 template <int MAXL>
 __device__ __forceinline__ int lp_planar_scan(const float4* lines, const float4* cand, int n, float& rx, float& ry) {
+    // all LDS requests first, then selects only: a short-circuit `k < fail && ...` makes hipcc branch around the loads and
+    // pay one LDS round trip per half-plane
+    float4 lk[MAXL], ck[MAXL];
+#pragma unroll
+    for (int k = 0; k < MAXL; ++k) {
+        lk[k] = lines[k];
+        ck[k] = cand[k];
+    }
     int fail = n;
 #pragma unroll
     for (int k = 0; k < MAXL; ++k) {
-        const float4 lk = lines[k];
-        const float4 ck = cand[k];
-        const bool viol = k < fail && (lk.z * (lk.y - ry) - lk.w * (lk.x - rx) > 0.0f);
-        const bool feasible = ck.z != 0.0f;
-        rx = (viol && feasible) ? ck.x : rx;
-        ry = (viol && feasible) ? ck.y : ry;
-        fail = (viol && !feasible) ? k : fail;
+        const float det = lk[k].z * (lk[k].y - ry) - lk[k].w * (lk[k].x - rx);
+        const bool viol = (k < fail) & (det > 0.0f);
+        const bool feasible = ck[k].z != 0.0f;
+        rx = (viol & feasible) ? ck[k].x : rx;
+        ry = (viol & feasible) ? ck[k].y : ry;
+        fail = (viol & !feasible) ? k : fail;
     }
     return fail;
 }
@@ -228,25 +235,34 @@ __device__ __forceinline__ float4 lp3_project(const float4 li, const float4 lj) 
 __device__ __forceinline__ void lp3_scan(const float4* lines, const float4* proj, const float4* cand, int n, int begin,
                                          float radius, float& rx, float& ry) {
     float distance = 0.0f;
+    float4 li[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) li[i] = lines[i];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const float4 li = lines[i];
-        const bool active = i >= begin && i < n && (li.z * (li.y - ry) - li.w * (li.x - rx) > distance);
-        float r2x = -li.w * radius, r2y = li.z * radius;  // linearProgram2, directionOpt: start at opt * radius
+        float4 pk[4], ck[4];  // program i's projected half-planes and their candidates: requested before they are needed
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            pk[k] = proj[i * (i - 1) / 2 + k];
+            ck[k] = cand[i * (i - 1) / 2 + k];
+        }
+        const float viol_i = li[i].z * (li[i].y - ry) - li[i].w * (li[i].x - rx);
+        const bool active = (i >= begin) & (i < n) & (viol_i > distance);
+        float r2x = -li[i].w * radius, r2y = li[i].z * radius;  // linearProgram2, directionOpt: start at opt * radius
         bool failed = false;
 #pragma unroll
         for (int k = 0; k < i; ++k) {
-            const float4 pk = proj[i * (i - 1) / 2 + k];
-            const float4 ck = cand[i * (i - 1) / 2 + k];
-            const bool viol = !failed && (pk.z * (pk.y - r2y) - pk.w * (pk.x - r2x) > 0.0f);
-            const bool feasible = ck.z != 0.0f;
-            r2x = (viol && feasible) ? ck.x : r2x;
-            r2y = (viol && feasible) ? ck.y : r2y;
-            failed = failed || (viol && !feasible);
+            const float det = pk[k].z * (pk[k].y - r2y) - pk[k].w * (pk[k].x - r2x);
+            const bool viol = !failed & (det > 0.0f);
+            const bool feasible = ck[k].z != 0.0f;
+            r2x = (viol & feasible) ? ck[k].x : r2x;
+            r2y = (viol & feasible) ? ck[k].y : r2y;
+            failed = failed | (viol & !feasible);
         }
-        rx = (active && !failed) ? r2x : rx;
-        ry = (active && !failed) ? r2y : ry;
-        distance = active ? li.z * (li.y - ry) - li.w * (li.x - rx) : distance;
+        rx = (active & !failed) ? r2x : rx;
+        ry = (active & !failed) ? r2y : ry;
+        const float pen = li[i].z * (li[i].y - ry) - li[i].w * (li[i].x - rx);
+        distance = active ? pen : distance;
     }
 }
 

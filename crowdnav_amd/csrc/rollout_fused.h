@@ -45,8 +45,12 @@ __device__ __forceinline__ void stage_agent(const Params& P, const Smem& s, cons
 }
 
 template <bool HEADLINE>
-__global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, StateView S, RolloutView R, int n_steps,
-                                                              const double* ext_action) {
+__global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
+                                                              RolloutView R, int n_steps, const double* ext_action) {
+    // The 17 state pointers are needed before and after the step loop and when an episode ends — never inside a step — so
+    // they stay in the engine's device copy of the StateView and are re-read where used (scalar loads) instead of holding
+    // 34 SGPRs (and spilling as many into VGPR lanes) across the loop.  ring_filled_in is the one pointer the host swaps
+    // between launches, hence a direct argument.
     constexpr int MAXL = 5;
     Params P = P_in;
     if (HEADLINE) {  // BASELINE configs[1]: 5 humans + robot, 2 envs per wave, 60 pairs, as compile-time constants
@@ -55,24 +59,27 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, State
     const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
-    if (L.valid) load_agent(S, L.gi, r);
     float robot_max_speed = 0.0f;
-    if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
+    {
+        const StateView S = *Sd;
+        if (L.valid) load_agent(S, L.gi, r);
+        if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
+    }
     build_pairs(P, s);
 
     const bool robot = L.valid && L.a == 0;
     // the ~20 pointers of the io block are needed at launch start / end and when an episode ends: they are re-read from
     // the device copy there (scalar loads) instead of occupying SGPRs across the step loop
     const cn_rollout_io* iop = R.io;
-    double theta = robot ? S.theta[L.env] : 0.0;
+    double theta = robot ? Sd->theta[L.env] : 0.0;
     EpisodeRegs ep{0.0, kRetired, 0, 0};
     double cur_return = 0.0, cur_dsum = 0.0;
     int cur_steps = 0, cur_danger = 0;
     if (L.valid) {
-        ep.gtime = S.gtime[L.env];
+        ep.gtime = Sd->gtime[L.env];
         ep.state = iop->active[L.env];
         ep.ep_count = iop->ep_count[L.env];
-        ep.ring_filled = S.ring_filled_in[L.env];
+        ep.ring_filled = ring_filled_in[L.env];
     }
     if (robot) {
         cur_steps = iop->cur_steps[L.env];
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, State
         if (iop->cur_danger_dmin_sum) cur_dsum = iop->cur_danger_dmin_sum[L.env];
     }
     if (L.valid && ep.state == kWaitingScenario && ep.ep_count < ep.ring_filled) {  // the fill kernel has just produced it
-        load_from_ring(P, S, L, ep.ep_count % P.ring_depth, r);
+        load_from_ring(P, *Sd, L, ep.ep_count % P.ring_depth, r);
         ep.state = kRunning;
         ep.gtime = 0.0;
         theta = 1.5707963267948966;
@@ -89,18 +96,25 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, State
     unsigned int transitions = 0;
     for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
     __syncthreads();  // pinfo, rview
-    // this pair lane's row: the lanes of its agent's NC candidates (8 bits each) and which of them exist
+    // this pair lane's row: the kin slots of its agent's candidates (8 bits each).  A pair that does not exist (robot
+    // invisible to the humans, env beyond the batch, fewer than 5 candidates) points at slot nA = (+inf, +inf): its squared
+    // distance is +inf without a select, so the pair phase below has no data-dependent control flow at all.
     int my_info = 0;
-    unsigned long long row_lanes = 0ull;
-    unsigned row_exists = 0u;
+    unsigned long long row_slots = 0ull;
+    int my_slot = P.nA;
+    if (L.lane == 0) s.kin[P.nA] = make_float4(std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), 0.0f, 0.0f);
     if (L.lane < P.pairs) {
         my_info = s.pinfo[L.lane];
         const int c = (my_info >> 16) & 0xff;
-        for (int k = 0; k < P.NC; ++k) {
-            const int ik = s.pinfo[L.lane - c + k];
-            row_lanes |= (unsigned long long)((ik >> 8) & 0xff) << (8 * k);
-            row_exists |= (unsigned)((ik >> 24) & 1) << k;
+        for (int k = 0; k < kFusedMaxNC; ++k) {
+            int slot = P.nA;
+            if (k < P.NC) {
+                const int ik = s.pinfo[L.lane - c + k];
+                slot = ((ik >> 24) & 1) ? ((ik >> 8) & 0xff) : P.nA;
+            }
+            row_slots |= (unsigned long long)slot << (8 * k);
         }
+        my_slot = (int)((row_slots >> (8 * c)) & 0xffull);
     }
     stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca));
     __syncthreads();
@@ -122,35 +136,31 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, State
         if (L.lane < P.pairs) {
             const int q = my_info & 0xff, c = (my_info >> 16) & 0xff;
             const int ol = (my_info >> 8) & 0xff;
+            const bool robot_sim = (my_info >> 25) & 1;
+            // every LDS request of the phase first, none of them behind a condition
             const float4 me = s.kin[q];
-            const float4 other = s.kin[ol];  // (read directly: selecting it out of the row below makes hipcc index a stack copy)
-            const float odx = me.x - other.x, ody = me.y - other.y;
-            const float mine = ((my_info >> 24) & 1) ? odx * odx + ody * ody : std::numeric_limits<float>::infinity();
-            float d2[kFusedMaxNC];
+            const float4 other = s.kin[my_slot];
+            float4 ot[kFusedMaxNC];
 #pragma unroll
-            for (int k = 0; k < kFusedMaxNC; ++k) {
-                d2[k] = std::numeric_limits<float>::infinity();
-                if (k < P.NC) {
-                    const float4 ot = s.kin[(int)((row_lanes >> (8 * k)) & 0xffull)];
-                    const float dx = me.x - ot.x, dy = me.y - ot.y;
-                    d2[k] = ((row_exists >> k) & 1u) ? dx * dx + dy * dy : std::numeric_limits<float>::infinity();
-                }
-            }
+            for (int k = 0; k < kFusedMaxNC; ++k) ot[k] = s.kin[(int)((row_slots >> (8 * k)) & 0xffull)];
+            const float* view = robot_sim ? s.rview : s.hview;
+            const float rsum = view[q] + view[ol];
+            const float odx = me.x - other.x, ody = me.y - other.y;
+            const float mine = odx * odx + ody * ody;
             int rank = 0, within = 0;
 #pragma unroll
             for (int k = 0; k < kFusedMaxNC; ++k) {
-                const float v = d2[k];
-                const bool in = v < range_sq;  // +inf beyond NC: never in range
-                within += in ? 1 : 0;
-                rank += (in && (v < mine || (v == mine && k < c))) ? 1 : 0;
+                const float dx = me.x - ot[k].x, dy = me.y - ot[k].y;
+                const float v = dx * dx + dy * dy;  // +inf for a pair that does not exist: never in range
+                const int in = v < range_sq ? 1 : 0;
+                const int before = (v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (k < c ? 1 : 0));
+                within += in;
+                rank += in & before;
             }
             if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
-            if (mine < range_sq && rank < P.orca.max_neighbors) {
-                const bool robot_sim = (my_info >> 25) & 1;
-                const float rsum = robot_sim ? s.rview[q] + s.rview[ol] : s.hview[q] + s.hview[ol];
+            if (mine < range_sq && rank < P.orca.max_neighbors)
                 s.lines[q * kLineStride + rank] =
                     make_half_plane(P.orca, me.x, me.y, me.z, me.w, other.x, other.y, other.z, other.w, rsum);
-            }
         }
         __syncthreads();
         CN_TICK(clk, 2);
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, State
                 if (io.episode_limit >= 0 && c >= io.episode_limit) {
                     ep.state = kRetired;
                 } else if (ep.ep_count < ep.ring_filled) {
-                    load_from_ring(P, S, L, ep.ep_count % P.ring_depth, r);
+                    load_from_ring(P, *Sd, L, ep.ep_count % P.ring_depth, r);
                     theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
                 } else {
                     ep.state = kWaitingScenario;  // ring ran dry: pause this env until the next launch has refilled it
@@ -323,6 +333,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, State
     }
 #endif
 
+    const StateView S = *Sd;
     if (L.valid) {
         S.pos[L.gi] = make_double2(r.px, r.py);
         S.vel[L.gi] = make_double2(r.vx, r.vy);

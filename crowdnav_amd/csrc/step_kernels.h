@@ -79,7 +79,7 @@ struct StepIo {
 
 // ---------------------------------------------------------------------------------------------- LDS carve-up
 struct Smem {
-    float4* kin;      // [nA] float32(px, py, vx, vy)
+    float4* kin;      // [nA + 1] float32(px, py, vx, vy); slot nA = (+inf, +inf, 0, 0): the "candidate" of a pair that does not exist
     double2* posd;    // [nA] float64 position
     double2* act;     // [nA] (robot lanes) applied robot action
     float4* lines;    // [nA][kLineStride] ORCA half-planes, slot = neighbour rank
@@ -105,7 +105,7 @@ constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the disc
 // maxl: the candidate-form buffers (cand2, cand3) exist for the 5-half-plane kernels only — at 21 agents per env they
 // would cost the 10-half-plane kernels a resident workgroup per CU
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl) {
-    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 4 : 2) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 +
+    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 4 : 2) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 + 16 +
            sizeof(double) * kMaxDiscount;
 }
 
@@ -115,7 +115,7 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     Smem s;
     char* p = reinterpret_cast<char*>(smem_raw);
     const int nA = P.nA;
-    s.kin = reinterpret_cast<float4*>(p), p += 16 * nA;
+    s.kin = reinterpret_cast<float4*>(p), p += 16 * (nA + 1);
     s.posd = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
