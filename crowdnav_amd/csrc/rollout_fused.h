@@ -42,6 +42,9 @@ __device__ __forceinline__ void stage_agent(const Params& P, const Smem& s, cons
     s.rad[L.lane] = r.rad;
     s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
     s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
+    float sx, sy;  // linearProgram2's start point (Appendix A.4): a function of the preferred velocity only
+    lp_start_point(max_speed, pref_x, pref_y, sx, sy);
+    s.res[L.lane] = make_float4(sx, sy, 0.0f, 0.0f);
 }
 
 template <bool HEADLINE>
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
         ep.ep_count = iop->ep_count[L.env];
         ep.ring_filled = ring_filled_in[L.env];
     }
-    if (robot) {
+    if (L.valid) {  // (every lane of the env: the accumulators are carried redundantly, see the reduce phase)
         cur_steps = iop->cur_steps[L.env];
         cur_return = iop->cur_return[L.env];
         if (iop->cur_danger) cur_danger = iop->cur_danger[L.env];
@@ -171,11 +174,6 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             const float4 so = s.sol[q];
             const float4* lq = s.lines + q * kLineStride;
             s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
-            if (k == 0) {
-                float sx, sy;
-                lp_start_point(so.z, so.x, so.y, sx, sy);
-                s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
-            }
         }
         __syncthreads();
 
@@ -196,26 +194,53 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
 #endif
         if (nm != 0ull) {  // wave-uniform: some agent of this wave was infeasible
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
-            if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
-            __syncthreads();
-            const int items = __popcll(nm) * kPairs;
-            for (int p = L.lane; p < items; p += kWave) {  // projections: lane = (agent, i, j)
-                const int t = p / kPairs, m = p - t * kPairs;
-                const int a = s.todo[t];
-                const int i = lp3_program_of(m), j = m - i * (i - 1) / 2;
-                const float4* la = s.lines + a * kLineStride;
-                s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
-            }
-            __syncthreads();
-            for (int p = L.lane; p < items; p += kWave) {  // their candidates: lane = (agent, i, k)
-                const int t = p / kPairs, m = p - t * kPairs;
-                const int a = s.todo[t];
+            const int n_todo = __popcll(nm);
+            if (n_todo * kPairs <= kWave) {
+                // one pass: item = lane = (t, m); the t-th infeasible agent is the t-th set bit of the ballot (scalar bit
+                // tricks, no LDS list), and the item's half-planes are requested once for both stages
+                const int t = L.lane / kPairs, m = L.lane - t * kPairs;
+                int a = 0;
+                unsigned long long rest = nm;
+#pragma unroll
+                for (int u = 0; u < kWave / kPairs; ++u) {
+                    const int bit = rest ? __ffsll((long long)rest) - 1 : 0;
+                    a = (u == t) ? bit : a;
+                    rest &= rest - 1ull;
+                }
+                const bool item = L.lane < n_todo * kPairs;
                 const int i = lp3_program_of(m), base = i * (i - 1) / 2;
-                const float4 li = s.lines[a * kLineStride + i];
-                const float4* pa = s.proj + a * kLineStride + base;
-                s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
+                const float4* la = s.lines + a * kLineStride;
+                const float4 li = la[i], lj = la[m - base];
+                const float radius = s.sol[a].z;
+                if (item) s.proj[a * kLineStride + m] = lp3_project(li, lj);
+                __syncthreads();
+                if (item) {
+                    const float4* pa = s.proj + a * kLineStride + base;
+                    s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, radius, -li.w, li.z, true);
+                }
+                __syncthreads();
+            } else {
+                if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
+                __syncthreads();
+                const int items = n_todo * kPairs;
+                for (int p = L.lane; p < items; p += kWave) {  // projections: lane = (agent, i, j)
+                    const int t = p / kPairs, m = p - t * kPairs;
+                    const int a = s.todo[t];
+                    const int i = lp3_program_of(m), j = m - i * (i - 1) / 2;
+                    const float4* la = s.lines + a * kLineStride;
+                    s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
+                }
+                __syncthreads();
+                for (int p = L.lane; p < items; p += kWave) {  // their candidates: lane = (agent, i, k)
+                    const int t = p / kPairs, m = p - t * kPairs;
+                    const int a = s.todo[t];
+                    const int i = lp3_program_of(m), base = i * (i - 1) / 2;
+                    const float4 li = s.lines[a * kLineStride + i];
+                    const float4* pa = s.proj + a * kLineStride + base;
+                    s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (need)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
                          fail, s.sol[L.lane].z, rx, ry);
@@ -256,45 +281,41 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
 
         // ---- reduce (every lane of the env, identically), integrate, episode bookkeeping, stage the next step
         if (running) {
+            // LDS requests first: the env's distances, the robot's radius, this step's discount factor
+            const double goal_dist = s.closest[L.ebase];
+            const double robot_rad = s.rad[L.ebase];
+            const double disc_t = s.disc[cur_steps < kMaxDiscount ? cur_steps : kMaxDiscount - 1];
             // the reference stops scanning at the first colliding human (dmin keeps the minimum seen before it)
             double dmin = std::numeric_limits<double>::infinity();
             bool collision = false;
             for (int i = 1; i < P.A; ++i) {
                 const double c = s.closest[L.ebase + i];
                 const bool hit = c < 0.0;
-                dmin = (!collision && !hit && c < dmin) ? c : dmin;
-                collision = collision || hit;
+                dmin = (!collision & !hit & (c < dmin)) ? c : dmin;
+                collision = collision | hit;
             }
-            const bool reaching = s.closest[L.ebase] < s.rad[L.ebase];
-            double reward;
-            int done, info;
-            if (ep.gtime >= P.time_limit - 1.0) {
-                reward = 0.0, done = 1, info = CN_TIMEOUT;
-            } else if (collision) {
-                reward = P.collision_penalty, done = 1, info = CN_COLLISION;
-            } else if (reaching) {
-                reward = P.success_reward, done = 1, info = CN_REACH_GOAL;
-            } else if (dmin < P.discomfort_dist) {
-                reward = (dmin - P.discomfort_dist) * P.discomfort_factor * P.dt;
-                done = 0, info = CN_DANGER;
-            } else {
-                reward = 0.0, done = 0, info = CN_NOTHING;
-            }
+            // crowd_sim.py:364-389 as a priority chain of selects (timeout > collision > goal > danger > nothing): the
+            // same values as the if / elif ladder without its nested branches
+            const bool timeout = ep.gtime >= P.time_limit - 1.0;
+            const bool reaching = goal_dist < robot_rad;
+            const bool danger = dmin < P.discomfort_dist;
+            double reward = danger ? (dmin - P.discomfort_dist) * P.discomfort_factor * P.dt : 0.0;
+            int info = danger ? CN_DANGER : CN_NOTHING;
+            reward = reaching ? P.success_reward : reward, info = reaching ? CN_REACH_GOAL : info;
+            reward = collision ? P.collision_penalty : reward, info = collision ? CN_COLLISION : info;
+            reward = timeout ? 0.0 : reward, info = timeout ? CN_TIMEOUT : info;
+            const bool done = timeout | collision | reaching;
             ep.gtime += P.dt;
             r.px = r.px + new_vx * P.dt;  // Agent.step (agent.py:127-135)
             r.py = r.py + new_vy * P.dt;
             r.vx = new_vx;
             r.vy = new_vy;
-            if (L.a == 0) {
-                ++transitions;
-                const double disc = cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0;
-                cur_return = cur_return + disc * reward;  // python sum(): left to right
-                ++cur_steps;
-                if (info == CN_DANGER) {
-                    ++cur_danger;
-                    cur_dsum += dmin;
-                }
-            }
+            // return / danger accumulators: every lane of the env carries them (only the robot lane's copy is written out)
+            ++transitions;
+            cur_return = cur_return + (cur_steps < kMaxDiscount ? disc_t : 0.0) * reward;  // python sum(): left to right
+            ++cur_steps;
+            cur_danger += info == CN_DANGER ? 1 : 0;
+            cur_dsum = info == CN_DANGER ? cur_dsum + dmin : cur_dsum;
             if (done) {  // explorer.py:50-72: record, then the env's next episode
                 const cn_rollout_io io = *iop;
                 if (L.a == 0) {
@@ -307,8 +328,8 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                         if (io.ep_danger) io.ep_danger[k] = cur_danger;
                         if (io.ep_danger_dmin_sum) io.ep_danger_dmin_sum[k] = cur_dsum;
                     }
-                    cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
                 }
+                cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
                 ++ep.ep_count;
                 ep.gtime = 0.0;
                 const int64_t c = episode_id(io, L.env, ep.ep_count);
