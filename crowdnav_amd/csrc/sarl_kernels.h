@@ -586,17 +586,21 @@ __device__ __forceinline__ BFrag dense_prefetch(const PackedLinear& P, int wave,
     return f;
 }
 
+// wave0 / nwaves: the waves [wave0, wave0 + nwaves) share the layer's column tiles (default: the whole workgroup); the others
+// return at once — the pipelined kernel runs two layers of different tiles side by side on disjoint wave ranges.
 template <int RT, bool PRE = false>
 __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* in, int ks_in, float* out, int ks_out,
-                                           bool relu, const float* extra, int wave, int lane, const BFrag* pre = nullptr) {
+                                           bool relu, const float* extra, int wave, int lane, const BFrag* pre = nullptr,
+                                           int wave0 = 0, int nwaves = kSarlThreads / 64) {
     const int col = lane & 15, quad = lane >> 4;
-    for (int ct = wave; ct < P.ctiles; ct += kSarlThreads / 64) {
+    if (wave < wave0 || wave >= wave0 + nwaves) return;
+    for (int ct = wave - wave0; ct < P.ctiles; ct += nwaves) {
         // this lane's 4 accumulator rows of column n = ct*16 + col sit at 4 consecutive words of the out buffer
         const int frag_off = ((ct * 4 + (col >> 2)) * 64) + (col & 3) * 16 + quad * 4;
         // accumulators start at zero; bias (L2) and the per-group extra term (LDS) are requested now and added in the
         // epilogue, so their latency hides behind the k loop instead of opening the column tile
         f32x4 acc[RT];
-        const bool first = PRE && ct == wave;  // this tile's first trip was prefetched before the barrier
+        const bool first = PRE && ct == wave - wave0;  // this tile's first trip was prefetched before the barrier
         const float b0 = first ? pre->bias : as_global(P.bias)[ct * 16 + col];
         f32x4 addend = {b0, b0, b0, b0};
         if (extra) addend += *reinterpret_cast<const f32x4*>(extra + frag_off);
@@ -843,6 +847,154 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, 
     }
     CN_SARL_CLOCK_END_N((n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
 }
+
+// The value head of tile t - 1 (mlp3: three 16-row layers + the single-output layer, 13 k of a tile's 84 k ticks when run
+// on its own: 16 rows cannot fill the workgroup) runs on the waves that idle during tile t's 7-column-tile layers:
+//   slot of tile t            main waves 0..6 (0..9)      side waves
+//   mlp1.2                    h2                          7..15: mlp3.0 (t - 1)   jbuf -> mbuf
+//   mean + mlp2.0                                         7..13: mlp3.2 (t - 1)   mbuf -> jbuf
+//   mlp2.2 + att0 global      features, global term       7..13: mlp3.4 (t - 1)   jbuf -> mbuf
+//   att0 local                                            15:    mlp3.6 (t - 1)   mbuf -> V   (one wave, shuffles)
+// The side chain has its own pong buffer (mbuf: kbuf carries tile t's global attention term in the same slots) and the
+// joint state of tile t is written — self features from registers, weighted sum, zero padding — only in tile t's last slot,
+// after the side chain has consumed the previous one.  The last tile's head runs after the loop on all waves.
+__device__ __forceinline__ void value_head_on_one_wave(const PackedLinear& P, const float* in, float* V, size_t tile,
+                                                       int n_groups, int lane) {
+    const int row = lane & 15, slice = lane >> 4;  // 4 k slices of the 16 rows
+    float sum = 0.0f;
+    for (int s = slice; s < P.ksteps; s += 4) {
+        const gfloat_p w = as_global(P.w) + s * 64;
+        const float* x = in + s * 64 + row;
+        sum += (x[0] * w[0] + x[16] * w[16]) + (x[32] * w[32] + x[48] * w[48]);
+    }
+    float v = as_global(P.bias)[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v += __shfl(sum, row + 16 * j);
+    const size_t G = tile * kSarlGroups + row;
+    if (slice == 0 && G < (size_t)n_groups) V[G] = v;
+}
+
+template <int H>
+__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_pipe_kernel(SarlNetRef net, const float* X, float* V, int n_groups,
+                                                                     int n_tiles, const int* hcount) {
+    extern __shared__ float lds[];
+    float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
+    float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2
+    float* bufC = bufB + H * net.ks_b * 64;       // [H][ks_c][64]  mlp2 output (per-human feature)
+    float* gbuf = bufC + H * net.ks_c * 64;       // [ks_b][64]     mean over humans of h2
+    float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]     joint state / value-head ping
+    float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term
+    float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights
+    float* vbuf = sbuf + H * net.ks_s * 64;       // [kSarlThreads] partial sums of attention.4
+    int* hc = reinterpret_cast<int*>(vbuf + kSarlThreads);  // [16]
+    float* mbuf = reinterpret_cast<float*>(hc + 16);        // [ks_a][64]     value-head pong (side chain)
+
+    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    zero_lds(lds, (size_t)(mbuf + net.ks_a * 64 - lds), tid);
+    const int nf = net.nf;
+    const int x_words = H * net.ks_x * 64;
+    float* xs = bufB;
+    BFrag pre = dense_prefetch(layer_of(net, kL_mlp1_0), wave, lane);
+    lds_barrier();
+    int prev_tile = -1;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        SarlNetRef nn = net;
+        asm volatile("" : "+s"(nn.base));
+        const SarlNetRef* n = &nn;
+        const bool side = prev_tile >= 0;  // a previous tile's value head is pending
+        const float* xg = X + (size_t)tile * x_words;
+        for (int i = tid; i < x_words; i += kSarlThreads) xs[i] = xg[i];
+        if (tid < kSarlGroups) hc[tid] = hcount[(size_t)tile * kSarlGroups + tid];
+        __syncthreads();  // X came from global memory
+        // self_state = state[:, 0, :6] (sarl.py:36): kept in a register until the joint state of this tile is assembled
+        float self_val = 0.0f;
+        if (tid < kSarlGroups * 6) {
+            const int g = tid & 15, f = tid >> 4;
+            self_val = xs[(f >> 2) * 64 + (f & 3) * 16 + g];
+        }
+        dense_mfma<H, true>(layer_of(*n, kL_mlp1_0), xs, n->ks_x, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
+        pre = dense_prefetch(layer_of(*n, kL_mlp1_2), wave, lane);
+        lds_barrier();
+        dense_mfma<H, true>(layer_of(*n, kL_mlp1_2), bufA, n->ks_a, bufB, n->ks_b, true, nullptr, wave, lane, &pre);  // h2
+        if (side) dense_mfma<1>(layer_of(*n, kL_mlp3_0), jbuf, n->ks_a, mbuf, n->ks_a, true, nullptr, wave, lane, nullptr, 7, 9);
+        pre = dense_prefetch(layer_of(*n, kL_mlp2_0), wave, lane);
+        lds_barrier();
+        if (n->with_global) {
+            for (int i = tid; i < n->ks_b * 64; i += kSarlThreads) {
+                const int cnt = hc[i & 15];
+                float sum = 0.0f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) sum += h < cnt ? bufB[h * n->ks_b * 64 + i] : 0.0f;
+                gbuf[i] = sum / (float)cnt;
+            }
+        }
+        dense_mfma<H, true>(layer_of(*n, kL_mlp2_0), bufB, n->ks_b, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
+        if (side) dense_mfma<1>(layer_of(*n, kL_mlp3_2), mbuf, n->ks_a, jbuf, n->ks_a, true, nullptr, wave, lane, nullptr, 7, 7);
+        pre = dense_prefetch(layer_of(*n, kL_mlp2_2), wave, lane);
+        lds_barrier();
+        dense_mfma<H, true>(layer_of(*n, kL_mlp2_2), bufA, n->ks_a, bufC, n->ks_c, false, nullptr, wave, lane, &pre);  // features
+        if (n->with_global) dense_mfma<1>(layer_of(*n, kL_att0_global), gbuf, n->ks_b, kbuf, n->ks_a, false, nullptr, wave, lane);
+        if (side) dense_mfma<1>(layer_of(*n, kL_mlp3_4), jbuf, n->ks_a, mbuf, n->ks_a, true, nullptr, wave, lane, nullptr, 7, 7);
+        pre = dense_prefetch(layer_of(*n, kL_att0_local), wave, lane);
+        lds_barrier();
+        dense_mfma<H, true>(layer_of(*n, kL_att0_local), bufB, n->ks_b, bufA, n->ks_a, true, n->with_global ? kbuf : nullptr,
+                            wave, lane, &pre);
+        if (side && wave == 15) value_head_on_one_wave(layer_of(*n, kL_mlp3_6), mbuf, V, (size_t)prev_tile, n_groups, lane);
+        pre = dense_prefetch(layer_of(*n, kL_att_2), wave, lane);
+        lds_barrier();
+        dense_mfma<H, true>(layer_of(*n, kL_att_2), bufA, n->ks_a, bufB, n->ks_b, true, nullptr, wave, lane, &pre);
+        lds_barrier();
+        dense_vec1<H>(layer_of(*n, kL_att_4), bufB, n->ks_b, sbuf, n->ks_s, vbuf, tid);  // score (h, g) at h*ks_s*64 + g
+        pre = dense_prefetch(layer_of(*n, kL_mlp1_0), wave, lane);  // the next tile's first layer
+        lds_barrier();
+        // masked softmax without max subtraction (sarl.py:52-53)
+        if (tid < kSarlGroups) {
+            float e[H], total = 0.0f;
+            const int cnt = hc[tid];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float sc = sbuf[h * n->ks_s * 64 + tid];
+                e[h] = h < cnt ? expf(sc) * (sc != 0.0f ? 1.0f : 0.0f) : 0.0f;
+                total += e[h];
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) sbuf[h * n->ks_s * 64 + tid] = e[h] / total;
+        }
+        lds_barrier();
+        // the joint state of this tile: self features, weighted feature sum (sarl.py:60), zero k padding
+        if (tid < kSarlGroups * 6) {
+            const int g = tid & 15, f = tid >> 4;
+            jbuf[(f >> 2) * 64 + (f & 3) * 16 + g] = self_val;
+        }
+        for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
+            const int g = i & 15, c = i >> 4;
+            const int src = (c >> 2) * 64 + (c & 3) * 16 + g;
+            float sum = 0.0f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) sum += sbuf[h * n->ks_s * 64 + g] * bufC[h * n->ks_c * 64 + src];
+            const int f = 6 + c;
+            jbuf[(f >> 2) * 64 + (f & 3) * 16 + g] = sum;
+        }
+        for (int i = tid; i < kSarlGroups * (layer_of(*n, kL_mlp3_0).kpad * 4 - 6 - nf); i += kSarlThreads) {
+            const int g = i & 15, f = 6 + nf + (i >> 4);
+            jbuf[(f >> 2) * 64 + (f & 3) * 16 + g] = 0.0f;
+        }
+        lds_barrier();
+        prev_tile = tile;
+    }
+    if (prev_tile >= 0) {  // the last tile's value head, on the whole workgroup
+        dense_mfma<1>(layer_of(net, kL_mlp3_0), jbuf, net.ks_a, mbuf, net.ks_a, true, nullptr, wave, lane);
+        lds_barrier();
+        dense_mfma<1>(layer_of(net, kL_mlp3_2), mbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
+        lds_barrier();
+        dense_mfma<1>(layer_of(net, kL_mlp3_4), jbuf, net.ks_a, mbuf, net.ks_a, true, nullptr, wave, lane);
+        lds_barrier();
+        if (wave == 15) value_head_on_one_wave(layer_of(net, kL_mlp3_6), mbuf, V, (size_t)prev_tile, n_groups, lane);
+    }
+}
+__host__ inline size_t sarl_mlp_pipe_extra_lds_bytes(const SarlNet& net) { return sizeof(float) * 64 * (size_t)net.ks_a; }
 
 template <int H>
 __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel_v1(SarlNet net, const float* X, float* V, int n_groups) {

@@ -321,11 +321,11 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         const float mine = s.d2[p];
         const float* row = s.d2 + (p - c);
         int rank = 0, within = 0;
-        for (int k = 0; k < P.NC; ++k) {
+        for (int k = 0; k < P.NC; ++k) {  // (bitwise, not short-circuit: no branch per candidate)
             const float v = row[k];
-            const bool in = v < range_sq;
-            within += in ? 1 : 0;
-            rank += (in && (v < mine || (v == mine && k < c))) ? 1 : 0;
+            const int in = v < range_sq ? 1 : 0;
+            within += in;
+            rank += in & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (k < c ? 1 : 0)));
         }
         if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
         if (mine < range_sq && rank < P.orca.max_neighbors) {
