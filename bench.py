@@ -226,6 +226,8 @@ def main():
     ap.add_argument('--seed-base', type=int, default=2000, help="episode c is seeded seed_base + c %% seed_mod (default: the "
                     "'train' phase numbering of crowd_sim.py:272-276, unbounded)")
     ap.add_argument('--seed-mod', type=int, default=2 ** 32 - 2000)
+    ap.add_argument('--async-fill', action='store_true',
+                    help='CN_FLAG_ASYNC_SCENARIO_FILL: scenario generation on side streams (crowds of more than 8 humans)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
                     help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
@@ -260,7 +262,8 @@ def main():
             dist.destroy_process_group()
         return
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
-                                       robot_visible=1, device=local_rank, circle_radius=args.circle_radius)
+                                       robot_visible=1, device=local_rank, circle_radius=args.circle_radius,
+                                       flags=crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL if args.async_fill else 0)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
     bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=4,
                              env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1])
@@ -344,6 +347,7 @@ def main():
                                'ORCA robot (visible), circle_crossing radius %g, in-kernel auto-reset' % (B, H, args.circle_radius),
                    'envs_per_gpu': B, 'humans': H, 'steps_per_launch': steps_per_launch, 'launches': launches,
                    'episode_seeds': '%d + c %% %d' % (args.seed_base, args.seed_mod),
+                   'scenario_fill': 'asynchronous (side streams, per-slot ready flags)' if args.async_fill else 'before each launch',
                    'preroll_steps': args.preroll,
                    'parallelism': 'env-axis shards x%d, all-gather of episode records at the end' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

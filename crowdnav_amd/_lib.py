@@ -19,6 +19,7 @@ ROBOT_EXTERNAL, ROBOT_ORCA = 0, 1
 CIRCLE_CROSSING, SQUARE_CROSSING, MIXED = 0, 1, 2
 HOLONOMIC, UNICYCLE = 0, 1
 RECORD_FIELDS, SUMMARY_FIELDS = 6, 8
+FLAG_ASYNC_SCENARIO_FILL = 1
 
 
 class CrowdNavAmdError(RuntimeError):
@@ -43,7 +44,7 @@ class CnConfig(C.Structure):
         ('human_radius', C.c_double), ('human_v_pref', C.c_double),
         ('robot_radius', C.c_double), ('robot_v_pref', C.c_double),
         ('randomize_attributes', C.c_int32), ('device', C.c_int32),
-        ('robot_kinematics', C.c_int32), ('reserved', C.c_int32),
+        ('robot_kinematics', C.c_int32), ('flags', C.c_int32),
     ]
 
 

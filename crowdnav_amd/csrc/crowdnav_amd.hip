@@ -62,6 +62,13 @@ struct cn_engine {
     cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
     cn_rollout_io* io_dev;   // device copy the rollout kernels read through
     cn::StateView* S_dev;    // device copy of S (the fused rollout kernel re-reads state pointers instead of holding them)
+    // CN_FLAG_ASYNC_SCENARIO_FILL: fill kernels go round-robin over side streams (a launch stuck on a hard scenario must
+    // not hold back the next one) and start once the previous transition kernel has written its episode counters
+    static constexpr int kFillStreams = 8;
+    bool async_fill;
+    hipStream_t fill_streams[kFillStreams];
+    hipEvent_t rollout_done;
+    int next_fill_stream;
     bool io_valid;
     int steps_since_fill;    // transitions launched since the scenario ring was last topped up; < 0 = never filled
     struct cn_sarl* sarl;    // SARL decision state (sarl_abi.inc), NULL until cn_sarl_configure
@@ -172,6 +179,10 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->io_valid = false;
     e->steps_since_fill = -1;
     e->sarl = nullptr;
+    e->async_fill = false;
+    e->rollout_done = nullptr;
+    e->next_fill_stream = 0;
+    for (int i = 0; i < cn_engine::kFillStreams; ++i) e->fill_streams[i] = nullptr;
     cn::Params& P = e->P;
     P.B = c->num_envs;
     P.A = c->num_humans + 1;
@@ -204,6 +215,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
     P.robot_visible = c->robot_visible ? 1 : 0;
     P.robot_orca = c->robot_policy == CN_ROBOT_ORCA;
     P.robot_unicycle = c->robot_kinematics == CN_UNICYCLE;
+    e->async_fill = (c->flags & CN_FLAG_ASYNC_SCENARIO_FILL) != 0 && e->gen_wave;
+    P.async_fill = e->async_fill ? 1 : 0;
     P.dt = c->time_step;
     P.time_limit = c->time_limit;
     P.success_reward = c->success_reward;
@@ -249,6 +262,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.redo_count, (size_t)1)) ||
         (rc = dev_alloc(e, &e->summary_scratch, (size_t)cn::kSummaryBlocks * cn::kSummaryFields + 1)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
+        (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1)) ||
         (rc = dev_alloc(e, &e->S_dev, (size_t)1))) {
         cn_destroy(e);
@@ -257,6 +272,15 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (hipMemcpy(e->S_dev, &e->S, sizeof(cn::StateView), hipMemcpyHostToDevice) != hipSuccess) {
         cn_destroy(e);
         return fail(CN_ERR_HIP, "cn_create: state view upload failed");
+    }
+    if (e->async_fill) {
+        bool ok = hipEventCreateWithFlags(&e->rollout_done, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < cn_engine::kFillStreams; ++i)
+            ok = hipStreamCreateWithFlags(&e->fill_streams[i], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) {
+            cn_destroy(e);
+            return fail(CN_ERR_HIP, "cn_create: side streams for the asynchronous scenario fill");
+        }
     }
     e->discount = nullptr;
     e->discount_len = 0;
@@ -275,6 +299,12 @@ int cn_destroy(cn_engine* e) {
     if (!e) return CN_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
+    for (int i = 0; i < cn_engine::kFillStreams; ++i)
+        if (e->fill_streams[i]) {
+            (void)hipStreamSynchronize(e->fill_streams[i]);
+            (void)hipStreamDestroy(e->fill_streams[i]);
+        }
+    if (e->rollout_done) (void)hipEventDestroy(e->rollout_done);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->discount) (void)hipFree(e->discount);
     sarl_release(e);
@@ -292,6 +322,8 @@ int cn_sync(cn_engine* e) {
     int rc = bind(e);
     if (rc) return rc;
     CN_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < cn_engine::kFillStreams; ++i)
+        if (e->fill_streams[i]) CN_HIP(hipStreamSynchronize(e->fill_streams[i]));
     int gen_error = 0;
     CN_HIP(hipMemcpy(&gen_error, e->C.error, sizeof(int), hipMemcpyDeviceToHost));
     if (gen_error) {
@@ -522,6 +554,21 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
 // transition, so after a fill the next ring_depth transitions cannot run it dry: launches inside that budget skip the
 // fill kernels altogether (a 20-step cn_rollout call used to spend more time here than in its transitions).
 static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_steps) {
+    if (e->async_fill) {
+        // a fill launch per transition launch, on the next side stream, ordered after the PREVIOUS transition kernel (whose
+        // episode counters it reads) and beside the one about to be launched; nobody waits for it
+        hipStream_t fs = e->fill_streams[e->next_fill_stream];
+        e->next_fill_stream = (e->next_fill_stream + 1) % cn_engine::kFillStreams;
+        CN_HIP(hipEventRecord(e->rollout_done, e->stream));
+        CN_HIP(hipStreamWaitEvent(fs, e->rollout_done, 0));
+        // (tried and dropped: 4 workgroups per env walking its slots in order — 4.0 M instead of 20.8 M env-steps/s at the
+        // reference geometry, a workgroup stuck on a hard scenario delays its env's later slots; a claim-then-work-list pair
+        // of kernels hung on the GPU box and was not pursued)
+        hipLaunchKernelGGL(cn::ring_fill_wave_async_kernel, dim3(e->P.B * e->P.ring_depth), dim3(cn::kWave), 0, fs, e->P, e->C,
+                           e->S, R);
+        e->steps_since_fill = 0;
+        return CN_OK;
+    }
     if (e->steps_since_fill >= 0 && e->steps_since_fill + n_steps <= e->P.ring_depth) {
         e->steps_since_fill += n_steps;
         return CN_OK;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
         if (iop->cur_danger_dmin_sum) cur_dsum = iop->cur_danger_dmin_sum[L.env];
     }
     if (L.valid && ep.state == kWaitingScenario && ep.ep_count < ep.ring_filled) {  // the fill kernel has just produced it
+        // (the asynchronous fill is for the wave generators, more than 8 humans: never this kernel)
         load_from_ring(P, *Sd, L, ep.ep_count % P.ring_depth, r);
         ep.state = kRunning;
         ep.gtime = 0.0;

@@ -563,7 +563,11 @@ __global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_k
 // Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS traffic, not for its global loads — so
 // the B fragments of the NEXT layer, requested before the barrier (dense_prefetch), stay in flight across it
 // (__syncthreads() drains vmcnt as well and would expose one L2 round trip per layer: 11 per tile).
+#ifndef CN_EXP_NO_BARRIER
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 
 // Weights are read through GLOBAL-address-space pointers: a generic pointer whose provenance the compiler cannot see (the
 // persistent kernel rebuilds them from an arena base) turns into flat_load, which counts on lgkmcnt as well as vmcnt — and
@@ -630,12 +634,24 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) ah[j][rt] = afrag[(rt * ks_in + j) * 64];
         for (int k0 = 0; k0 < P.kpad; k0 += kSarlKChunk) {
+#ifndef CN_EXP_NO_B
 #pragma unroll
             for (int j = 0; j < kSarlKChunk; ++j) bnxt[j] = wfrag[(k0 + kSarlKChunk + j) * 64];
+#else
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j) bnxt[j] = bcur[j] + 1.0f;
+#endif
+#ifndef CN_EXP_NO_A
 #pragma unroll
             for (int j = kHead; j < kSarlKChunk; ++j)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) ar[j - kHead][rt] = afrag[(rt * ks_in + k0 + j) * 64];
+#else
+#pragma unroll
+            for (int j = kHead; j < kSarlKChunk; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ar[j - kHead][rt] = ah[0][rt] + (float)(k0 + j);
+#endif
             __builtin_amdgcn_sched_barrier(0);  // requests first
 #pragma unroll
             for (int j = 0; j < kHead; ++j)
@@ -643,10 +659,12 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j][rt], bcur[j], acc[rt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef CN_EXP_NO_A
 #pragma unroll
             for (int j = 0; j < kHead; ++j)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) ah[j][rt] = afrag[(rt * ks_in + k0 + kSarlKChunk + j) * 64];
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = kHead; j < kSarlKChunk; ++j)
@@ -666,7 +684,11 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
             }
+#ifndef CN_EXP_NO_EPILOGUE
             *reinterpret_cast<f32x4*>(out + rt * ks_out * 64 + frag_off) = v;
+#else
+            if (v[0] == 123.456f) *reinterpret_cast<f32x4*>(out + rt * ks_out * 64 + frag_off) = v;
+#endif
         }
     }
 }

@@ -37,6 +37,7 @@ struct Params {
     int ring_depth;    // scenarios kept ahead per env
     int robot_visible, robot_orca;
     int robot_unicycle;  // external robot actions are ActionRot(v, r) (agent.py:115-135)
+    int async_fill;      // CN_FLAG_ASYNC_SCENARIO_FILL: ring slots are published one by one (StateView::ring_ready)
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double robot_safety, human_safety;
     OrcaParams orca;
@@ -63,6 +64,8 @@ struct StateView {
     double2* ring_rv;
     int* ring_filled_in;    // [B] episode ordinals < this have been generated (read side)
     int* ring_filled_out;   // [B] (written by the fill kernel; the host swaps the two)
+    int* ring_ready;        // [B*D] async fill: ordinal + 1 of the scenario a slot holds, stored with release once it is complete
+    int* ring_claim;        // [B*D] async fill: ordinal + 1 some fill launch is generating (or has generated) for the slot
 };
 
 struct StepIo {
@@ -841,6 +844,11 @@ __global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, Sce
         S.gtime[b] = 0.0;
         S.mt_pos[b] = -1;
     }
+    if (P.async_fill)
+        for (int t = threadIdx.x; t < P.ring_depth; t += blockDim.x) {  // nothing resident, nothing claimed
+            S.ring_ready[(size_t)b * P.ring_depth + t] = 0;
+            S.ring_claim[(size_t)b * P.ring_depth + t] = 0;
+        }
     if (!on) return;
     generate_scenario_wave(C, scratch, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
 }
@@ -863,6 +871,44 @@ __global__ __launch_bounds__(kWave) void ring_fill_wave_kernel(Params P, Scenari
                            S.ring_goal, S.ring_rv);
 }
 
+// Asynchronous flavour (CN_FLAG_ASYNC_SCENARIO_FILL): runs on a side stream NEXT to the transition kernel.  A slot is
+// claimed for the ordinal the env will need there (an earlier fill launch may still be working on it: atomicCAS on
+// ring_claim), generated, and published with a device-scope release store of ordinal + 1 to ring_ready.  Only slots whose
+// scenario the env consumed before the transition kernel running beside the fill was launched are ever overwritten.
+__global__ __launch_bounds__(kWave) void ring_fill_wave_async_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
+    __shared__ WaveScratch scratch;
+    __shared__ int go;
+    const int idx = blockIdx.x;  // workgroup = (env, slot)
+    const int D = P.ring_depth;
+    const int b = idx / D, slot = idx - b * D;
+    const cn_rollout_io* io = R.io;
+    const int state = io->active[b];
+    if (state == kRetired) return;
+    const int next = io->ep_count[b] + (state == kWaitingScenario ? 0 : 1);
+    const int ordinal = next + ((slot - next % D) + D) % D;
+    const int64_t c = episode_id(*io, b, ordinal);
+    if (io->episode_limit >= 0 && c >= io->episode_limit) return;
+    if (threadIdx.x == 0) {
+        const int want = ordinal + 1;
+        const int have = S.ring_claim[idx];
+        go = (have < want && atomicCAS(&S.ring_claim[idx], have, want) == have) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!go) return;  // resident already, or another launch is generating exactly this scenario
+    generate_scenario_wave(C, scratch, episode_seed(*io, c), ((size_t)b * D + slot) * P.A, S.ring_pos, nullptr, S.ring_goal,
+                           S.ring_rv);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&S.ring_ready[idx], ordinal + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Is scenario `ordinal` of env b resident?  Synchronous fill: the launch-time fill level; asynchronous: the slot's own flag
+// (acquire at device scope: the scenario data written by the concurrently running fill kernel is visible after it).
+__device__ __forceinline__ bool scenario_ready(const Params& P, const StateView& S, int env, int ordinal, int ring_filled) {
+    if (!P.async_fill) return ordinal < ring_filled;
+    const int* flag = S.ring_ready + (size_t)env * P.ring_depth + ordinal % P.ring_depth;
+    return __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == ordinal + 1;
+}
+
 __device__ __forceinline__ void load_from_ring(const Params& P, const StateView& S, const Lane& L, int slot,
                                                AgentRegs& r) {
     const size_t ri = ((size_t)L.env * P.ring_depth + slot) * P.A + L.a;
@@ -872,8 +918,8 @@ __device__ __forceinline__ void load_from_ring(const Params& P, const StateView&
 
 // Episode end on the robot lane (explorer.py:50-72): append the record, pick the next episode.  Returns the
 // per-env flag: 0 = stop stepping (retired, or waiting for the ring to be refilled), 2 + slot = load ring slot.
-__device__ __forceinline__ int finish_episode(const RolloutView R, int env, int ring_depth, int ring_filled,
-                                          double time_limit, int info, double gtime, int& ep_count,
+__device__ __forceinline__ int finish_episode(const Params& P, const StateView& S, const RolloutView R, int env, int ring_depth,
+                                          int ring_filled, double time_limit, int info, double gtime, int& ep_count,
                                           int cur_steps, double cur_return, int cur_danger, double cur_dsum,
                                           int& state) {
     const cn_rollout_io io = *R.io;
@@ -892,8 +938,8 @@ __device__ __forceinline__ int finish_episode(const RolloutView R, int env, int 
         state = kRetired;
         return 0;
     }
-    if (ep_count < ring_filled) return 2 + ep_count % ring_depth;
-    state = kWaitingScenario;  // ring ran dry: pause this env until the next launch has refilled it
+    if (scenario_ready(P, S, env, ep_count, ring_filled)) return 2 + ep_count % ring_depth;
+    state = kWaitingScenario;  // ring ran dry (or this scenario is still being generated): pause until a later launch
     return 0;
 }
 
@@ -938,7 +984,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         if (io.cur_danger_dmin_sum) cur_dsum = io.cur_danger_dmin_sum[L.env];
         ring_filled = S.ring_filled_in[L.env];
         int f = state == kRunning ? 1 : 0;
-        if (state == kWaitingScenario && ep_count < ring_filled) {  // the fill kernel has just produced it
+        if (state == kWaitingScenario && scenario_ready(P, S, L.env, ep_count, ring_filled)) {  // produced since
             f = 2 + ep_count % P.ring_depth;
             state = kRunning;
             gtime = 0.0;
@@ -980,7 +1026,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
                 cur_dsum += res.dmin;
             }
             if (res.done) {
-                next_flag = finish_episode(R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
+                next_flag = finish_episode(P, S, R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
                                            cur_steps, cur_return, cur_danger, cur_dsum, state);
                 cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
                 gtime = 0.0;

@@ -22,7 +22,7 @@ _DEFAULTS = dict(
     robot_policy=_lib.ROBOT_ORCA, robot_safety_space=0.0, human_safety_space=0.0, neighbor_dist=10.0,
     max_neighbors=10, scenario_rule=_lib.CIRCLE_CROSSING, time_horizon=5.0, time_horizon_obst=5.0,
     circle_radius=4.0, square_width=10.0, human_radius=0.3, human_v_pref=1.0, robot_radius=0.3,
-    robot_v_pref=1.0, randomize_attributes=0, device=0, robot_kinematics=_lib.HOLONOMIC, reserved=0)
+    robot_v_pref=1.0, randomize_attributes=0, device=0, robot_kinematics=_lib.HOLONOMIC, flags=0)
 
 
 def default_config(**overrides):

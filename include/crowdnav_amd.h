@@ -77,8 +77,18 @@ typedef struct cn_config {
     int32_t device;               /* HIP device ordinal */
     int32_t robot_kinematics;     /* CN_HOLONOMIC: actions are ActionXY(vx, vy); CN_UNICYCLE: ActionRot(v, r)
                                      (agent.py:115-135; CN_ROBOT_EXTERNAL only - the ORCA policy is holonomic) */
-    int32_t reserved;
+    int32_t flags;                /* CN_FLAG_* */
 } cn_config;
+
+/* cn_config.flags */
+/* Generate the scenarios of cn_rollout / cn_rollout_step's auto-resets ASYNCHRONOUSLY: the fill kernels run on the engine's
+ * own side streams next to the transition kernels and publish every scenario on its own (per-slot ready flag, release /
+ * acquire at device scope), so a launch never waits for the hardest scenario of the batch — only the env whose NEXT
+ * scenario is not ready yet pauses (it steps again in a later launch).  Trajectories and episode records are unchanged;
+ * how many transitions a launch executes becomes timing-dependent.  For crowds whose rejection sampling
+ * (crowd_sim.py:155-176) is heavy-tailed: 20 humans on the 4 m circle need 28 k random() calls per scenario on average and
+ * 10+ M for the worst.  More than 8 humans only (the wave-cooperative generators). */
+#define CN_FLAG_ASYNC_SCENARIO_FILL 1
 
 typedef struct cn_engine cn_engine;
 

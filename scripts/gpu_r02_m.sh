@@ -1,0 +1,16 @@
+mkdir -p gpurun_out/r02m && cd /tmp && export TMPDIR=/tmp
+REPO=$GRAFT_REPO_ROOT; OUT=$REPO/gpurun_out/r02m; cd $REPO
+timeout 600 python -m pytest tests/test_boundary.py tests/test_gpu_parity.py -m gpu -q -x > $OUT/pytest_gpu.log 2>&1 < /dev/null; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+tail -n 8 $OUT/pytest_gpu.log | grep -v "version\|Hostname\|Librccl"
+run() { name=$1; shift; ( export "$@"; timeout 200 python bench.py --no-cpu-baseline $BARGS > $OUT/$name.log 2>&1 < /dev/null ); echo -n "$name: "; timeout 20 python scripts/bench_line.py $OUT/$name.log; grep -o '"paused_env_steps": [0-9]*, "episodes_finished": [0-9]*' $OUT/$name.log; }
+S="--seed-base 1000 --seed-mod 1024"
+BARGS="--humans 20 --circle-radius 4 --steps 4000 --warmup 200 --chunk 100 --preroll 100 $S --async-fill"
+run h20_r4_async_c100 X=1
+BARGS="--humans 20 --circle-radius 4 --steps 4000 --warmup 200 --chunk 400 --preroll 100 $S --async-fill"
+run h20_r4_async_c400 X=1
+BARGS="--humans 20 --circle-radius 4 --steps 8000 --warmup 400 --chunk 1000 --preroll 100 $S --async-fill"
+run h20_r4_async_c1000 X=1
+BARGS="--humans 20 --circle-radius 4 --steps 4000 --warmup 200 --chunk 400 --preroll 100 --async-fill"
+run h20_r4_async_c400_train_seeds X=1
+BARGS="--humans 20 --circle-radius 12 --steps 2000 --warmup 500 --chunk 500 --async-fill"
+run h20_r12_async X=1

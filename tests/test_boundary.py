@@ -160,3 +160,34 @@ def test_c_abi_gather_over_a_caller_owned_rccl_communicator(amd):
             eng.gather_records_rccl(0, 1, blocks)  # NULL communicator
     finally:
         rccl.comm_destroy(comm)
+
+
+def test_asynchronous_scenario_fill_changes_timing_not_trajectories(amd, oracle_mod):
+    """CN_FLAG_ASYNC_SCENARIO_FILL (crowds of more than 8 humans): the fill kernels run beside the transition kernels on
+    side streams and publish every scenario on its own; an env whose next scenario is not ready pauses.  Whatever the
+    timing, every episode an env DID finish is the oracle's episode (same outcome, length, return), in order, and the env
+    states are those of the oracle after the same number of that env's transitions — here checked through the records."""
+    B, K, launches, n = 96, 24, 30, 10
+    cfg = dict(num_humans=10, circle_radius=3.2, robot_visible=1)
+    eng = amd.BatchedCrowdSim(num_envs=B, robot_policy=amd.ROBOT_ORCA, flags=amd.FLAG_ASYNC_SCENARIO_FILL, **cfg)
+    bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=-1, record_capacity=K)
+    for _ in range(launches):
+        eng.rollout(n)
+    eng.sync()
+    total = int(_np(bufs['transitions'])[0])
+    assert 0 < total <= B * launches * n
+    o = oracle_mod.CrowdOracle(num_envs=B, robot_policy=1, **cfg)
+    o.reset(1000 + np.arange(B))
+    ep_index, cur_steps, cur_ret = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.float64)
+    _, rec = o.rollout(launches * n, 1000, 500, K, ep_index, cur_steps, cur_ret)
+    cnt = _np(bufs['ep_count'])
+    assert (cnt <= rec['count']).all()                      # a paused env is behind, never ahead
+    assert cnt.sum() >= 0.8 * rec['count'].sum() >= B       # and pauses are the exception at this geometry
+    for b in range(B):
+        k = min(cnt[b], K)
+        assert np.array_equal(_np(bufs['ep_outcome'])[b, :k], rec['outcome'][b, :k])
+        assert np.array_equal(_np(bufs['ep_steps'])[b, :k], rec['steps'][b, :k])
+        assert np.allclose(_np(bufs['ep_return'])[b, :k], rec['ret'][b, :k], rtol=0, atol=1e-9)
+    # the synchronous engine on the same seeds: identical to the oracle transition for transition
+    eng2, bufs2 = _rollout(amd, B, [n] * launches, K=K, **{k: v for k, v in cfg.items() if k != 'robot_visible'})
+    assert int(_np(bufs2['transitions'])[0]) == B * launches * n and np.array_equal(_np(bufs2['ep_count']), rec['count'])
