@@ -343,8 +343,9 @@ def main():
         'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 ORCA solve + f64 env step', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]: %d batched envs x %d humans per GPU, ORCA humans + holonomic '
-                               'ORCA robot (visible), circle_crossing radius %g, in-kernel auto-reset' % (B, H, args.circle_radius),
+        'config': {'workload': 'BASELINE configs[%d]: %d batched envs x %d humans per GPU, ORCA humans + holonomic '
+                               'ORCA robot (visible), circle_crossing radius %g, in-kernel auto-reset'
+                               % (1 if (B, H) == (4096, 5) else 3 if H == 20 else 1, B, H, args.circle_radius),
                    'envs_per_gpu': B, 'humans': H, 'steps_per_launch': steps_per_launch, 'launches': launches,
                    'episode_seeds': '%d + c %% %d' % (args.seed_base, args.seed_mod),
                    'scenario_fill': 'asynchronous (side streams, per-slot ready flags)' if args.async_fill else 'before each launch',

@@ -1,16 +1,17 @@
 # round-2 evidence: GPU tests, smoke, bench lines, rocprofv3 kernel traces + separate PMC passes for both launch shapes
 mkdir -p gpurun_out/r02prof && cd /tmp && export TMPDIR=/tmp
 REPO=$GRAFT_REPO_ROOT; OUT=$REPO/gpurun_out/r02prof; cd $REPO
-timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 < /dev/null; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+timeout 300 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1 < /dev/null; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 tail -n 4 $OUT/pytest_gpu.log | grep -v "version\|Hostname\|Librccl"
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1 < /dev/null; echo "smoke rc=$?" >> $OUT/smoke.log; tail -n 2 $OUT/smoke.log
-timeout 600 python bench.py > $OUT/bench_default.log 2>&1 < /dev/null
+timeout 200 python bench.py > $OUT/bench_default.log 2>&1 < /dev/null
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.log 2>&1 < /dev/null
 timeout 300 python bench.py --workload sarl --no-cpu-baseline > $OUT/bench_sarl.log 2>&1 < /dev/null
 timeout 300 python bench.py --workload om-sarl --no-cpu-baseline > $OUT/bench_om_sarl.log 2>&1 < /dev/null
 timeout 300 python bench.py --no-cpu-baseline --envs 32768 --steps 4000 > $OUT/bench_32k.log 2>&1 < /dev/null
 timeout 300 python bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 2000 --warmup 500 --chunk 500 > $OUT/bench_h20_r12.log 2>&1 < /dev/null
-timeout 300 python bench.py --no-cpu-baseline --humans 20 --circle-radius 4 --steps 400 --warmup 100 --chunk 100 --preroll 100 --seed-base 1000 --seed-mod 1024 > $OUT/bench_h20_r4.log 2>&1 < /dev/null
+timeout 120 python bench.py --no-cpu-baseline --humans 20 --circle-radius 4 --steps 400 --warmup 100 --chunk 100 --preroll 100 --seed-base 1000 --seed-mod 1024 > $OUT/bench_h20_r4.log 2>&1 < /dev/null
+timeout 120 python bench.py --no-cpu-baseline --humans 20 --circle-radius 4 --steps 8000 --warmup 400 --chunk 1000 --preroll 100 --seed-base 1000 --seed-mod 1024 --async-fill > $OUT/bench_h20_r4_async.log 2>&1 < /dev/null
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 cd /tmp
 A="--no-cpu-baseline"; D="--no-cpu-baseline --steps 20 --warmup 5"
