@@ -28,6 +28,7 @@
 #include "rollout_fused.h"
 #include "records_kernels.h"
 #include "sarl_kernels.h"
+#include "sarl_reg_kernel.h"
 
 // ------------------------------------------------------------------------------------------------ C ABI
 

@@ -1,0 +1,382 @@
+// sarl.ValueNetwork.forward (crowd_nav/policy/sarl.py:28-65) with the ACTIVATIONS IN REGISTERS: the shipped widths
+// (mlp1 150-100, mlp2 100-50, attention 100-100-1 with the global state, mlp3 150-100-100-1) and 5 humans.
+//
+// The LDS kernels (sarl_kernels.h) compute Y = X W^T with the activations as the MFMA A operand: a layer's output has to
+// travel through LDS to become the next layer's input, every layer ends in a workgroup barrier, and 7 column tiles on 16
+// waves leave the MFMA pipes 54 % busy.  Here a wave computes Y^T = W X^T for ITS OWN 16 (env, action) groups x 5 humans
+// (5 "N tiles" of 16 rows) through the whole network:
+//
+//   * A operand = weights (16 output features x 4 inputs), B operand = activations (4 inputs x 16 rows).  The accumulator
+//     of v_mfma_f32_16x16x4_f32 holds, in lane l, rows 4*(l>>4) .. +3 of column l&15 — four OUTPUT FEATURES of one ROW —
+//     and the B operand of a k-step wants, in lane l, input feature 4*ks + (l>>4) of row l&15.  With the output features of
+//     a 16-feature tile dealt to the accumulator rows as  slot m = 4*lg + s  <->  feature 16*t + 4*s + lg  (a 4 x 4
+//     transpose, done once in the weight packing), register s of output tile t IS the B operand of k-step 4*t + s of the
+//     next layer.  No LDS, no barrier, no data movement between layers: bias is the accumulator's initial value, ReLU one
+//     v_max per register.
+//   * The reductions over a group's humans (mean for the global state, masked softmax, weighted feature sum) combine the
+//     same register of the wave's 5 N tiles: lane-local.
+//   * Weights stream from L2 (L1-shared by the 4 waves of a workgroup, which run the same sequence) in the exact order of
+//     use as ONE linear array of 1-KiB "quads" (lane l: 4 consecutive k-steps of one output tile, or the bias of a tile),
+//     kRegDepth quads ahead, across layer and tile boundaries — a wave never waits for a layer to start.
+//   * One wave per SIMD (up to 512 registers: at most 310 activations live — the 80 registers of per-human features wait in
+//     wave-private LDS while the attention layers run), 20 independent MFMAs per weight quad.
+//
+// Arithmetic: each output is the fma chain  bias, then inputs in ascending k  (the MFMA's own order) — the same products as
+// the LDS kernels, which add the bias last; both within 1e-6 of torch (tests/test_sarl.py).
+#pragma once
+
+namespace cn {
+
+constexpr int kRegDepth = 4;   // weight quads in flight per wave
+constexpr int kRegHumans = 5;  // N tiles per wave
+constexpr int kRegWaves = 4;   // waves per workgroup = SIMDs per CU
+
+enum {
+    kR_mlp1_0, kR_mlp1_2, kR_mlp2_0, kR_mlp2_2, kR_att0_global, kR_att0_local, kR_att_2, kR_att_4,
+    kR_mlp3_0, kR_mlp3_2, kR_mlp3_4, kR_mlp3_6, kRegLayers
+};
+
+struct RegShape {
+    int ks;      // k-steps (inputs / 4, rounded up)
+    int mt;      // output tiles of 16 features
+    int bias;    // 1: a bias quad opens every output tile (0: the accumulator starts from another layer's result)
+    int paired;  // 1: one N tile only — two output tiles advance together so that consecutive MFMAs are independent
+};
+
+__host__ __device__ constexpr int reg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// xks = k-steps of the network input: 4 (13 features) or 16 (13 + 48 occupancy-map features)
+__host__ __device__ constexpr RegShape reg_shape(int l, int xks) {
+    switch (l) {
+        case kR_mlp1_0: return {xks, 10, 1, 0};
+        case kR_mlp1_2: return {38, 7, 1, 0};
+        case kR_mlp2_0: return {25, 7, 1, 0};
+        case kR_mlp2_2: return {25, 4, 1, 0};
+        case kR_att0_global: return {25, 7, 1, 1};
+        case kR_att0_local: return {25, 7, 0, 0};
+        case kR_att_2: return {25, 7, 1, 0};
+        case kR_att_4: return {25, 1, 1, 0};
+        case kR_mlp3_0: return {15, 10, 1, 1};  // 12.5 k-steps of weighted feature + the self state from the X registers
+        case kR_mlp3_2: return {38, 7, 1, 1};
+        case kR_mlp3_4: return {25, 7, 1, 1};
+        default: return {25, 1, 1, 1};          // kR_mlp3_6
+    }
+}
+__host__ __device__ constexpr int reg_tile_quads(int l, int xks) { return reg_shape(l, xks).bias + reg_cdiv(reg_shape(l, xks).ks, 4); }
+__host__ __device__ constexpr int reg_layer_quads(int l, int xks) { return reg_shape(l, xks).mt * reg_tile_quads(l, xks); }
+__host__ __device__ constexpr int reg_qbase(int l, int xks) {
+    int q = 0;
+    for (int i = 0; i < l; ++i) q += reg_layer_quads(i, xks);
+    return q;
+}
+// the stream is padded to a multiple of kRegDepth so that quad I always lives in register slot I % kRegDepth
+__host__ __device__ constexpr int reg_total_quads(int xks) { return reg_cdiv(reg_qbase(kRegLayers, xks), kRegDepth) * kRegDepth; }
+// position of item j (0 = bias if the layer has one, then the weight quads) of output tile mt inside its layer
+__host__ __device__ constexpr int reg_qpos(int l, int xks, int mt, int j) {
+    const RegShape s = reg_shape(l, xks);
+    const int S = reg_tile_quads(l, xks);
+    if (!s.paired || mt >= (s.mt / 2) * 2) return mt * S + j;
+    return (mt / 2) * 2 * S + 2 * j + (mt & 1);
+}
+// input column of W that k-step ks, lane group lg multiplies (-1: none).  mlp3.0 reads joint = [self (6) | weighted feature]
+// (sarl.py:61): k-steps 0..11 and lanes 0..31 of k-step 12 are the weighted feature's registers; lanes 32..63 of k-step 12
+// take self features 2, 3 from X k-step 0, k-step 13 takes 4, 5 from X k-step 1 and k-step 14 takes 0, 1 from X k-step 0 —
+// the registers that already hold them in those lanes.
+__host__ __device__ constexpr int reg_kcol(int l, int K, int k_off, int ks, int lg) {
+    if (l != kR_mlp3_0) return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
+    if (ks < 12) return 6 + 4 * ks + lg;
+    if (ks == 12) return lg < 2 ? 6 + 48 + lg : lg;
+    if (ks == 13) return lg < 2 ? 4 + lg : -1;
+    return lg < 2 ? lg : -1;
+}
+
+struct RegPackLayer {
+    const float* W;     // torch.nn.Linear weight [N][ldw]
+    const float* b;     // bias or nullptr
+    int N, ldw, K, k_off, replicate;  // replicate: the single output feature fills all 16 slots (attention score: every lane gets it)
+};
+struct RegPackPlan {
+    RegPackLayer L[kRegLayers];
+    int xks;
+};
+
+__global__ void sarl_reg_pack_kernel(RegPackPlan plan, float* stream) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int xks = plan.xks;
+    const int total = reg_total_quads(xks);
+    if (idx >= total * 256) return;
+    const int quad = idx >> 8, lane = (idx >> 2) & 63, kk = idx & 3;
+    const int lg = lane >> 4, m = lane & 15;
+    float v = 0.0f;
+    int l = 0, base = 0;
+    while (l < kRegLayers && quad >= base + reg_layer_quads(l, xks)) base += reg_layer_quads(l++, xks);
+    if (l < kRegLayers) {
+        const RegShape s = reg_shape(l, xks);
+        const int S = reg_tile_quads(l, xks);
+        const RegPackLayer& L = plan.L[l];
+        const int r = quad - base;
+        int mt, j;
+        const int pairs = s.paired ? s.mt / 2 : 0;
+        if (r < pairs * 2 * S) {
+            const int rr = r % (2 * S);
+            mt = 2 * (r / (2 * S)) + (rr & 1), j = rr >> 1;
+        } else {
+            const int r2 = r - pairs * 2 * S;
+            mt = 2 * pairs + r2 / S, j = r2 % S;
+        }
+        if (s.bias && j == 0) {  // accumulator register kk of lane group lg = feature 16 mt + 4 kk + lg
+            const int f = L.replicate ? 0 : 16 * mt + 4 * kk + lg;
+            v = (L.b && f < L.N) ? L.b[f] : 0.0f;
+        } else {
+            const int ks = 4 * (j - s.bias) + kk;
+            const int n = L.replicate ? 0 : 16 * mt + 4 * (m & 3) + (m >> 2);
+            const int col = ks < s.ks ? reg_kcol(l, L.K, L.k_off, ks, lg) : -1;
+            v = (n < L.N && col >= 0) ? L.W[(size_t)n * L.ldw + col] : 0.0f;
+        }
+    }
+    stream[idx] = v;
+}
+
+typedef const f32x4 __attribute__((address_space(1))) * gf32x4_p;
+
+// Quad J is read as  global_load_dwordx4 v, voff, s[base + J KiB]  (scalar base + 32-bit lane offset): the 546 addresses of a
+// tile are scalar adds, not VGPR pairs.  `base` is laundered once per tile so that they are not hoisted out of the tile loop
+// (546 loop-invariant addresses in registers: the first build spilled 474 of them to scratch in the prologue).
+struct RegStream {
+    const char* base;      // the stream (wave-uniform)
+    uint32_t voff;         // lane * 16
+    f32x4 q[kRegDepth];    // quads I .. I + kRegDepth - 1 of the running position (quad J in slot J % kRegDepth)
+};
+__device__ __forceinline__ f32x4 reg_quad(const RegStream& s, int J) {
+    return *(gf32x4_p)(s.base + (size_t)J * 1024 + s.voff);
+}
+template <int QT>
+__device__ __forceinline__ f32x4 reg_take(RegStream& s, int I) {
+    const f32x4 v = s.q[I % kRegDepth];
+    s.q[I % kRegDepth] = reg_quad(s, (I + kRegDepth) % QT);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 reg_relu(f32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_max_f32 %0, 0, %1" : "=v"(v[i]) : "v"(v[i]));  // fmaxf canonicalises first: 2 instructions
+    return v;
+}
+
+// emit(nt, mt, act(W x + b)) for NT N tiles and every output tile mt; in(nt, ks) = the B operand of k-step ks; init(mt) =
+// accumulator start when the layer has no bias quad
+template <int XKS, int L, int NT, bool RELU, class In, class Init, class Emit>
+__device__ __forceinline__ void reg_dense(RegStream& ws, In in, Init init, Emit emit) {
+    constexpr RegShape S = reg_shape(L, XKS);
+    constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
+    static_assert(!S.paired, "use reg_dense1");
+#pragma unroll
+    for (int mt = 0; mt < S.mt; ++mt) {
+        f32x4 c0, acc[NT];
+        if constexpr (S.bias != 0) c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 0));
+        else c0 = init(mt);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 a = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, S.bias + q));
+            __builtin_amdgcn_sched_barrier(0);  // the request for quad I + kRegDepth is issued HERE, not sunk to its use
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ks = 4 * q + kk;
+                if (ks < S.ks) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(nt, ks), ks == 0 ? c0 : acc[nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) emit(nt, mt, RELU ? reg_relu(acc[nt]) : acc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one N tile: output tiles two at a time (their MFMAs alternate: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles,
+// an independent one after 32)
+template <int XKS, int L, bool RELU, class In, int MT = reg_shape(L, XKS).mt>
+__device__ __forceinline__ void reg_dense1(RegStream& ws, In in, f32x4 (&out)[MT]) {
+    constexpr RegShape S = reg_shape(L, XKS);
+    constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
+    static_assert(S.paired && S.bias && MT == S.mt, "use reg_dense");
+#pragma unroll
+    for (int p = 0; p < MT / 2; ++p) {
+        const f32x4 c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, 2 * p, 0));
+        const f32x4 c1 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, 2 * p + 1, 0));
+        f32x4 acc0, acc1;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 a0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, 2 * p, 1 + q));
+            const f32x4 a1 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, 2 * p + 1, 1 + q));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ks = 4 * q + kk;
+                if (ks < S.ks) {
+                    const float x = in(ks);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kk], x, ks == 0 ? c0 : acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk], x, ks == 0 ? c1 : acc1, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        out[2 * p] = RELU ? reg_relu(acc0) : acc0, out[2 * p + 1] = RELU ? reg_relu(acc1) : acc1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MT & 1) {
+        constexpr int mt = MT - 1;
+        const f32x4 c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 0));
+        f32x4 acc;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 a = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 1 + q));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ks = 4 * q + kk;
+                if (ks < S.ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(ks), ks == 0 ? c0 : acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        out[mt] = RELU ? reg_relu(acc) : acc;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// X: the feature kernel's fragment order, X[((tile * 5 + h) * ks_x + ks) * 64 + lane] = feature 4 ks + (lane >> 4) of human h
+// of group lane & 15 — exactly the B operand of k-step ks.  V[group] out.  Persistent: wave w of the grid takes tiles
+// w, w + waves, ...; the next tile's X is requested while the value head of the current one runs.
+template <int XKS>
+__global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* stream, const float* X, float* V, int n_groups,
+                                                                  int n_tiles, int ks_x, const int* hcount) {
+    constexpr int NT = kRegHumans;
+    constexpr int QT = reg_total_quads(XKS);
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
+    RegStream ws;
+    ws.base = reinterpret_cast<const char*>(stream), ws.voff = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < kRegDepth; ++i) ws.q[i] = reg_quad(ws, i);
+    if (wid >= n_tiles) return;
+    const gfloat_p Xg = as_global(X) + lane;
+    float x[NT][XKS];
+    int cnt;
+    {
+        const gfloat_p xt = Xg + (size_t)wid * NT * ks_x * 64;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) x[nt][ks] = xt[(nt * ks_x + ks) * 64];
+        cnt = hcount[(size_t)wid * kSarlGroups + (lane & 15)];
+    }
+    // per-human features (mlp2 output, 80 registers) wait in LDS while the attention layers run: wave-private, no barrier
+    __shared__ f32x4 park[kRegWaves][NT * 4][64];
+    f32x4(*const mypark)[64] = park[threadIdx.x >> 6];
+    const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+    for (int tile = wid; tile < n_tiles; tile += nw) {
+        asm volatile("" : "+s"(ws.base));
+        const float self0 = x[0][0], self1 = x[0][1];  // features 0..3 / 4..7 of human 0's row: the self state lives in 0..5
+        f32x4 att[NT][7];
+        {
+            f32x4 h2[NT][7];
+            {
+                f32x4 h1[NT][10];
+                reg_dense<XKS, kR_mlp1_0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none,
+                                                    [&](int nt, int mt, f32x4 v) { h1[nt][mt] = v; });
+                reg_dense<XKS, kR_mlp1_2, NT, true>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none,
+                                                    [&](int nt, int mt, f32x4 v) { h2[nt][mt] = v; });
+            }
+            {
+                f32x4 t1[NT][7];
+                reg_dense<XKS, kR_mlp2_0, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none,
+                                                    [&](int nt, int mt, f32x4 v) { t1[nt][mt] = v; });
+                reg_dense<XKS, kR_mlp2_2, NT, false>(ws, [&](int nt, int ks) { return t1[nt][ks >> 2][ks & 3]; }, none,
+                                                     [&](int nt, int mt, f32x4 v) { mypark[nt * 4 + mt][lane] = v; });
+            }
+            // global state: mean over the humans present (sarl.py:42), elementwise over the 5 N tiles
+            f32x4 gterm[7];
+            {
+                f32x4 gm[7];
+                const float fc = (float)cnt;
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                    f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum[i] += nt < cnt ? h2[nt][t][i] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gm[t][i] = sum[i] / fc;
+                }
+                // attention.0 on [h2 | mean]: the global half (+ the layer's bias) is one N tile, shared by the 5 humans
+                reg_dense1<XKS, kR_att0_global, false>(ws, [&](int ks) { return gm[ks >> 2][ks & 3]; }, gterm);
+            }
+            f32x4 a0[NT][7];
+            reg_dense<XKS, kR_att0_local, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; },
+                                                    [&](int mt) { return gterm[mt]; },
+                                                    [&](int nt, int mt, f32x4 v) { a0[nt][mt] = v; });
+            reg_dense<XKS, kR_att_2, NT, true>(ws, [&](int nt, int ks) { return a0[nt][ks >> 2][ks & 3]; }, none,
+                                               [&](int nt, int mt, f32x4 v) { att[nt][mt] = v; });
+        }
+        f32x4 wf[4];
+        {
+            float sc[NT];  // attention.4: the score of (human, group) in every register of the group's lanes
+            reg_dense<XKS, kR_att_4, NT, false>(ws, [&](int nt, int ks) { return att[nt][ks >> 2][ks & 3]; }, none,
+                                                [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
+            // masked softmax without max subtraction (sarl.py:52-53); an absent human carries no weight
+            float e[NT], total = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float s = sc[nt];
+                e[nt] = nt < cnt ? expf(s) * (s != 0.0f ? 1.0f : 0.0f) : 0.0f;
+                total += e[nt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) e[nt] = e[nt] / total;
+            // weighted feature sum (sarl.py:60)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 f = mypark[nt * 4 + t][lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum[i] += e[nt] * f[i];
+                }
+                wf[t] = sum;
+            }
+        }
+        // the next tile's input (and this tile's last use of x is behind us)
+        const int next = tile + nw < n_tiles ? tile + nw : tile;
+        {
+            const gfloat_p xt = Xg + (size_t)next * NT * ks_x * 64;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < XKS; ++ks) x[nt][ks] = xt[(nt * ks_x + ks) * 64];
+        }
+        const int cnt_next = hcount[(size_t)next * kSarlGroups + (lane & 15)];
+        // value head on joint = [self | weighted feature] (sarl.py:61-62)
+        f32x4 j1[10], j2[7], j3[7], val[1];
+        const float mix = lane < 32 ? wf[3][0] : self0;
+        reg_dense1<XKS, kR_mlp3_0, true>(
+            ws, [&](int ks) { return ks < 12 ? wf[ks >> 2][ks & 3] : ks == 12 ? mix : ks == 13 ? self1 : self0; }, j1);
+        reg_dense1<XKS, kR_mlp3_2, true>(ws, [&](int ks) { return j1[ks >> 2][ks & 3]; }, j2);
+        reg_dense1<XKS, kR_mlp3_4, true>(ws, [&](int ks) { return j2[ks >> 2][ks & 3]; }, j3);
+        reg_dense1<XKS, kR_mlp3_6, false>(ws, [&](int ks) { return j3[ks >> 2][ks & 3]; }, val);
+        if (lane < kSarlGroups) {
+            const size_t G = (size_t)tile * kSarlGroups + lane;
+            if (G < (size_t)n_groups) V[G] = val[0][0];
+        }
+        cnt = cnt_next;
+        // the stream position wraps to quad 0 here: the padding quads are consumed so that slot I % kRegDepth stays aligned
+#pragma unroll
+        for (int i = reg_qbase(kRegLayers, XKS); i < QT; ++i) (void)reg_take<QT>(ws, i);
+    }
+}
+
+}  // namespace cn
