@@ -139,16 +139,20 @@ __global__ void sarl_reg_pack_kernel(RegPackPlan plan, float* stream) {
 
 typedef const f32x4 __attribute__((address_space(1))) * gf32x4_p;
 
-// Quad J is read as  global_load_dwordx4 v, voff, s[base + J KiB]  (scalar base + 32-bit lane offset): the 546 addresses of a
-// tile are scalar adds, not VGPR pairs.  `base` is laundered once per tile so that they are not hoisted out of the tile loop
-// (546 loop-invariant addresses in registers: the first build spilled 474 of them to scratch in the prologue).
+// Quad J is read as  buffer_load_dwordx4 v, voff, s[rsrc], soffset = J KiB offen : a buffer resource (4 SGPRs) over the
+// stream, the lane offset in ONE VGPR that never changes, the quad's offset a scalar constant.  No per-quad address in
+// vector registers: with global_load the 546 addresses were either hoisted out of the tile loop (474 of them spilled to
+// scratch in the first build) or rebuilt as 64-bit vector adds whose destination the register allocator, out of VGPRs, put
+// on top of loads still in flight (s_waitcnt vmcnt(0): the whole prefetch queue drained, several times per tile).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct RegStream {
-    const char* base;      // the stream (wave-uniform)
+    __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff;         // lane * 16
     f32x4 q[kRegDepth];    // quads I .. I + kRegDepth - 1 of the running position (quad J in slot J % kRegDepth)
 };
 __device__ __forceinline__ f32x4 reg_quad(const RegStream& s, int J) {
-    return *(gf32x4_p)(s.base + (size_t)J * 1024 + s.voff);
+    // 4 quads share one scalar offset (the other 2 address bits go into the instruction's 12-bit immediate)
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff + (J & 3) * 1024, (J >> 2) * 4096, 0));
 }
 template <int QT>
 __device__ __forceinline__ f32x4 reg_take(RegStream& s, int I) {
@@ -159,7 +163,11 @@ __device__ __forceinline__ f32x4 reg_take(RegStream& s, int I) {
 
 __device__ __forceinline__ f32x4 reg_relu(f32x4 v) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) asm("v_max_f32 %0, 0, %1" : "=v"(v[i]) : "v"(v[i]));  // fmaxf canonicalises first: 2 instructions
+    for (int i = 0; i < 4; ++i) {  // max(x, 0) on the bit pattern: negative floats are negative integers (-0.0 too) — ONE
+        const float f = v[i];                      // v_max_i32; fmaxf would quiet signalling NaNs first (a second v_max_f32)
+        const int b = __float_as_int(f);           // (bit_cast straight on the vector element reads element 0 for every i)
+        v[i] = __int_as_float(b > 0 ? b : 0);
+    }
     return v;
 }
 
@@ -170,9 +178,12 @@ __device__ __forceinline__ void reg_dense(RegStream& ws, In in, Init init, Emit 
     constexpr RegShape S = reg_shape(L, XKS);
     constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
     static_assert(!S.paired, "use reg_dense1");
+    // Output tile mt - 1 leaves the accumulators (AGPR -> VGPR, ReLU, or the LDS store) while the first 20 MFMAs of tile mt
+    // issue — two vector instructions in the shadow of every MFMA — instead of between the tiles with the matrix pipe idle.
+    f32x4 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < S.mt; ++mt) {
-        f32x4 c0, acc[NT];
+        f32x4 c0;
         if constexpr (S.bias != 0) c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 0));
         else c0 = init(mt);
 #pragma unroll
@@ -185,15 +196,89 @@ __device__ __forceinline__ void reg_dense(RegStream& ws, In in, Init init, Emit 
                 if (ks < S.ks) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(nt, ks), ks == 0 ? c0 : acc[nt], 0, 0, 0);
+                        acc[mt & 1][nt] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(nt, ks), ks == 0 ? c0 : acc[mt & 1][nt], 0, 0, 0);
+                }
+            }
+            if (q == 0 && mt > 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) emit(nt, mt - 1, RELU ? reg_relu(acc[(mt - 1) & 1][nt]) : acc[(mt - 1) & 1][nt]);
+#pragma unroll
+                for (int i = 0; i < 4 * NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) emit(nt, mt, RELU ? reg_relu(acc[nt]) : acc[nt]);
-        __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        emit(nt, S.mt - 1, RELU ? reg_relu(acc[(S.mt - 1) & 1][nt]) : acc[(S.mt - 1) & 1][nt]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ReLU of one value; AG: the result goes to an AGPR (the asm's "=a" operand is what keeps the array in the accumulator half
+// of the register file, where the next layer's MFMAs read it as their B operand directly — arrays the compiler moves there
+// on its own are copied back with v_accvgpr_read before every use).
+template <bool AG>
+__device__ __forceinline__ float reg_relu1(float x) {
+    const int b = __float_as_int(x);
+    x = __int_as_float(b > 0 ? b : 0);  // v_max_i32: negative floats are negative integers
+    if constexpr (AG) {
+        float r;
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(x));
+        return r;
+    }
+    return x;
+}
+
+// out[nt][mt] = relu(W x + b).  Every instruction a wave issues between two MFMAs delays the second one by ~5 cycles (one wave
+// per SIMD: nothing else hides it; measured: tile time = 32 cycles x MFMAs + 5.4 x everything else), so the layer is written
+// for instruction count: a VGPR array (AG = false) is accumulated in place and rectified with one v_max_i32 per value; an
+// AGPR array is accumulated in VGPRs, rectified there and moved with one v_accvgpr_write (2 per value; read - max - write on
+// an AGPR accumulator would be 3).  The ReLU of tile mt - 1 follows the first MFMAs of tile mt, so that it never waits for
+// the matrix pipe to drain.
+template <int XKS, int L, int NT, bool AG, class In, class Init, int MT = reg_shape(L, XKS).mt>
+__device__ __forceinline__ void reg_dense_arr(RegStream& ws, In in, Init init, f32x4 (&out)[NT][MT]) {
+    constexpr RegShape S = reg_shape(L, XKS);
+    constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
+    static_assert(!S.paired && MT == S.mt && S.ks >= 4, "use reg_dense1");
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 c0;
+        if constexpr (S.bias != 0) c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 0));
+        else c0 = init(mt);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 a = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, S.bias + q));
+            __builtin_amdgcn_sched_barrier(0);  // the request for quad I + kRegDepth is issued HERE, not sunk to its use
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ks = 4 * q + kk;
+                if (ks < S.ks) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt & 1][nt] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(nt, ks), ks == 0 ? c0 : acc[mt & 1][nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0 && mt > 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[nt][mt - 1][i] = reg_relu1<AG>(acc[(mt - 1) & 1][nt][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[nt][MT - 1][i] = reg_relu1<AG>(acc[(MT - 1) & 1][nt][i]);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // one N tile: output tiles two at a time (their MFMAs alternate: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles,
@@ -258,7 +343,8 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
     RegStream ws;
-    ws.base = reinterpret_cast<const char*>(stream), ws.voff = (uint32_t)lane * 16u;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, QT * 1024, 0x00020000);  // raw, 32-bit elements
+    ws.voff = (uint32_t)lane * 16u;
 #pragma unroll
     for (int i = 0; i < kRegDepth; ++i) ws.q[i] = reg_quad(ws, i);
     if (wid >= n_tiles) return;
@@ -277,25 +363,26 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
     __shared__ f32x4 park[kRegWaves][NT * 4][64];
     f32x4(*const mypark)[64] = park[threadIdx.x >> 6];
     const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+    CN_SARL_CLOCK_BEGIN();
     for (int tile = wid; tile < n_tiles; tile += nw) {
-        asm volatile("" : "+s"(ws.base));
         const float self0 = x[0][0], self1 = x[0][1];  // features 0..3 / 4..7 of human 0's row: the self state lives in 0..5
         f32x4 att[NT][7];
         {
             f32x4 h2[NT][7];
             {
                 f32x4 h1[NT][10];
-                reg_dense<XKS, kR_mlp1_0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none,
-                                                    [&](int nt, int mt, f32x4 v) { h1[nt][mt] = v; });
-                reg_dense<XKS, kR_mlp1_2, NT, true>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none,
-                                                    [&](int nt, int mt, f32x4 v) { h2[nt][mt] = v; });
+                reg_dense_arr<XKS, kR_mlp1_0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
+                CN_SARL_TICK(1);
+                reg_dense_arr<XKS, kR_mlp1_2, NT, false>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
+                CN_SARL_TICK(2);
             }
             {
                 f32x4 t1[NT][7];
-                reg_dense<XKS, kR_mlp2_0, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none,
-                                                    [&](int nt, int mt, f32x4 v) { t1[nt][mt] = v; });
+                reg_dense_arr<XKS, kR_mlp2_0, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, t1);
+                CN_SARL_TICK(3);
                 reg_dense<XKS, kR_mlp2_2, NT, false>(ws, [&](int nt, int ks) { return t1[nt][ks >> 2][ks & 3]; }, none,
                                                      [&](int nt, int mt, f32x4 v) { mypark[nt * 4 + mt][lane] = v; });
+                CN_SARL_TICK(4);
             }
             // global state: mean over the humans present (sarl.py:42), elementwise over the 5 N tiles
             f32x4 gterm[7];
@@ -314,19 +401,21 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
                 }
                 // attention.0 on [h2 | mean]: the global half (+ the layer's bias) is one N tile, shared by the 5 humans
                 reg_dense1<XKS, kR_att0_global, false>(ws, [&](int ks) { return gm[ks >> 2][ks & 3]; }, gterm);
+                CN_SARL_TICK(5);
             }
             f32x4 a0[NT][7];
-            reg_dense<XKS, kR_att0_local, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; },
-                                                    [&](int mt) { return gterm[mt]; },
-                                                    [&](int nt, int mt, f32x4 v) { a0[nt][mt] = v; });
-            reg_dense<XKS, kR_att_2, NT, true>(ws, [&](int nt, int ks) { return a0[nt][ks >> 2][ks & 3]; }, none,
-                                               [&](int nt, int mt, f32x4 v) { att[nt][mt] = v; });
+            reg_dense_arr<XKS, kR_att0_local, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; },
+                                                        [&](int mt) { return gterm[mt]; }, a0);
+            CN_SARL_TICK(6);
+            reg_dense_arr<XKS, kR_att_2, NT, false>(ws, [&](int nt, int ks) { return a0[nt][ks >> 2][ks & 3]; }, none, att);
+            CN_SARL_TICK(7);
         }
         f32x4 wf[4];
         {
             float sc[NT];  // attention.4: the score of (human, group) in every register of the group's lanes
             reg_dense<XKS, kR_att_4, NT, false>(ws, [&](int nt, int ks) { return att[nt][ks >> 2][ks & 3]; }, none,
                                                 [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
+            CN_SARL_TICK(8);
             // masked softmax without max subtraction (sarl.py:52-53); an absent human carries no weight
             float e[NT], total = 0.0f;
 #pragma unroll
@@ -350,6 +439,7 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
                 wf[t] = sum;
             }
         }
+        CN_SARL_TICK(9);
         // the next tile's input (and this tile's last use of x is behind us)
         const int next = tile + nw < n_tiles ? tile + nw : tile;
         {
@@ -365,8 +455,11 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         const float mix = lane < 32 ? wf[3][0] : self0;
         reg_dense1<XKS, kR_mlp3_0, true>(
             ws, [&](int ks) { return ks < 12 ? wf[ks >> 2][ks & 3] : ks == 12 ? mix : ks == 13 ? self1 : self0; }, j1);
+        CN_SARL_TICK(10);
         reg_dense1<XKS, kR_mlp3_2, true>(ws, [&](int ks) { return j1[ks >> 2][ks & 3]; }, j2);
+        CN_SARL_TICK(11);
         reg_dense1<XKS, kR_mlp3_4, true>(ws, [&](int ks) { return j2[ks >> 2][ks & 3]; }, j3);
+        CN_SARL_TICK(12);
         reg_dense1<XKS, kR_mlp3_6, false>(ws, [&](int ks) { return j3[ks >> 2][ks & 3]; }, val);
         if (lane < kSarlGroups) {
             const size_t G = (size_t)tile * kSarlGroups + lane;
@@ -376,7 +469,9 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         // the stream position wraps to quad 0 here: the padding quads are consumed so that slot I % kRegDepth stays aligned
 #pragma unroll
         for (int i = reg_qbase(kRegLayers, XKS); i < QT; ++i) (void)reg_take<QT>(ws, i);
+        CN_SARL_TICK(13);
     }
+    CN_SARL_CLOCK_END_N((n_tiles - wid + nw - 1) / nw);
 }
 
 }  // namespace cn
