@@ -265,6 +265,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
+        (rc = dev_alloc(e, &S.launch_trans, (size_t)P.B)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1)) ||
         (rc = dev_alloc(e, &e->S_dev, (size_t)1))) {
         cn_destroy(e);
@@ -612,6 +613,8 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     } else {
         CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, action);
     }
+    hipLaunchKernelGGL(cn::rollout_finish_kernel, dim3(1), dim3(1024), 0, e->stream, P.B, (const uint32_t*)e->S.launch_trans,
+                       (const cn_rollout_io*)e->io_dev);
 }
 
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {

@@ -373,9 +373,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
         io.cur_return[L.env] = cur_return;
         if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
-#ifndef CN_EXP_NO_TRANS_ATOMIC
-        if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, (unsigned long long)transitions);
-#endif
+        S.launch_trans[L.env] = transitions;  // summed by rollout_finish_kernel (no same-address atomics here)
     }
 }
 

@@ -66,6 +66,7 @@ struct StateView {
     int* ring_filled_out;   // [B] (written by the fill kernel; the host swaps the two)
     int* ring_ready;        // [B*D] async fill: ordinal + 1 of the scenario a slot holds, stored with release once it is complete
     int* ring_claim;        // [B*D] async fill: ordinal + 1 some fill launch is generating (or has generated) for the slot
+    uint32_t* launch_trans; // [B] transitions each env executed in the last rollout launch (summed by rollout_finish_kernel)
 };
 
 struct StepIo {
@@ -1064,9 +1065,26 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         io.cur_return[L.env] = cur_return;
         if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
-#ifndef CN_EXP_NO_TRANS_ATOMIC
-        if (io.transitions && transitions) atomicAdd((unsigned long long*)io.transitions, (unsigned long long)transitions);
-#endif
+        S.launch_trans[L.env] = transitions;  // no atomic here: see rollout_finish_kernel
+    }
+}
+
+// cn_rollout_io.transitions += the transitions of the launch before it on the stream.  One same-address atomic per env at
+// the end of the rollout kernel cost ~10 ns each, serialised: 45 of a 1-step launch's 59 us, 12-15 us of a 20-step launch
+// (4096 envs; profiles/r02_launch_probe_transitions_atomic.txt).  Plain per-env stores + this one-workgroup sum: ~3 us.
+__global__ __launch_bounds__(1024) void rollout_finish_kernel(int B, const uint32_t* launch_trans, const cn_rollout_io* iop) {
+    __shared__ unsigned long long part[16];
+    unsigned long long sum = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) sum += launch_trans[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += part[w];
+        uint64_t* dst = iop->transitions;
+        if (dst && total) *dst += total;
     }
 }
 
