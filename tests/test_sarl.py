@@ -107,6 +107,37 @@ def test_sarl_mlp_vs_torch_fp32_random_inputs(humans, with_om):
     assert np.all(out['best'].cpu().numpy() >= 0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_om', [False, True])
+def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
+    """5 humans at the shipped widths run sarl_reg_kernel (activations in registers); CROWDNAV_AMD_SARL_REG=0 keeps the LDS
+    pipe kernel on the same engine configuration.  Same inputs, same weights: both within 2e-5 of torch and within 1e-6 of
+    each other (they add the bias at opposite ends of the same fma chain), including a last tile of padding groups."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(5)
+    d = 61 if with_om else 13
+    net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    B = 203  # 16 443 groups = 1027 full tiles + 11 groups: more tiles than the 1024 persistent waves, and a ragged last one
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for reg in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+        eng.reset(3000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[reg] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), eng.sarl_export('X').cpu())
+    with torch.no_grad():
+        want = net(got['1'][2].reshape(B * 81, 5, d)).reshape(B, 81).numpy()
+    assert torch.equal(got['1'][2], got['0'][2])
+    assert np.abs(got['1'][0] - want).max() <= 2e-5 and np.abs(got['0'][0] - want).max() <= 2e-5
+    assert np.abs(got['1'][0] - got['0'][0]).max() <= 1e-6
+    assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
 def _joint_rows(g, d, a):
     """float32 joint rows [propagate(self, action a) | next human h] of decision d, as MultiHumanRL.predict builds them."""
     s, act = g['states'][d], g['action_space'][a]
