@@ -266,6 +266,48 @@ __device__ __forceinline__ void lp3_scan(const float4* lines, const float4* proj
     }
 }
 
+// The same for any MAXL (the 10-half-plane kernels): 45 (i, j) projections and 45 (i, k) candidates per infeasible agent.
+//   slot of (i, k) = i (i - 1) / 2 + k;  lp3_program_of_n: the i of a slot
+template <int MAXL>
+__device__ __forceinline__ int lp3_program_of_n(int m) {
+    int i = 1;
+#pragma unroll
+    for (int t = 2; t < MAXL; ++t) i += (m >= t * (t - 1) / 2) ? 1 : 0;  // thresholds 1, 3, 6, 10, ...
+    return i;
+}
+template <int MAXL>
+__device__ __forceinline__ void lp3_scan_n(const float4* lines, const float4* proj, const float4* cand, int n, int begin,
+                                           float radius, float& rx, float& ry) {
+    float distance = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+        const float4 li = lines[i];
+        float4 pk[MAXL - 1], ck[MAXL - 1];  // program i's projected half-planes and their candidates: requested together
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            pk[k] = proj[i * (i - 1) / 2 + k];
+            ck[k] = cand[i * (i - 1) / 2 + k];
+        }
+        const float viol_i = li.z * (li.y - ry) - li.w * (li.x - rx);
+        const bool active = (i >= begin) & (i < n) & (viol_i > distance);
+        float r2x = -li.w * radius, r2y = li.z * radius;  // linearProgram2, directionOpt: start at opt * radius
+        bool failed = false;
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float det = pk[k].z * (pk[k].y - r2y) - pk[k].w * (pk[k].x - r2x);
+            const bool viol = !failed & (det > 0.0f);
+            const bool feasible = ck[k].z != 0.0f;
+            r2x = (viol & feasible) ? ck[k].x : r2x;
+            r2y = (viol & feasible) ? ck[k].y : r2y;
+            failed = failed | (viol & !feasible);
+        }
+        rx = (active & !failed) ? r2x : rx;
+        ry = (active & !failed) ? r2y : ry;
+        const float pen = li.z * (li.y - ry) - li.w * (li.x - rx);
+        distance = active ? pen : distance;
+    }
+}
+
 // ------------------------------------------------------------------ lane-cooperative 2-D program
 // The same program with one lane per (agent, half-plane): a wave holds kWave / MAXL agents (12 at MAXL = 5), lane
 // g * MAXL + l owns half-plane l of the g-th agent of the chunk.  Per round every agent advances to its next violated

@@ -105,12 +105,28 @@ struct Smem {
 };
 
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
+// CN_CAND_LP3_10 (compile time, default off): the 10-half-plane kernels run the 3-D fallback in candidate form like the
+// 5-half-plane ones (lp3_project / lp_line_candidate on (agent, i, j) lanes, then lp3_scan_n per agent) instead of
+// lp_relaxed_coop's rounds.  Built, bit-identical on the whole GPU suite, and REJECTED on speed at 20 humans: 45 projections
+// + 45 candidates per infeasible agent (each candidate a loop over up to 8 earlier lines) cost as much as the cooperative
+// rounds (27.1 k vs 25.8 k ticks per wave-step) and the 8.6 KB of chunk buffers take a resident workgroup per CU
+// (67.7 -> 51.6 M env-steps/s).
+#ifndef CN_CAND_LP3_10
+#define CN_CAND_LP3_10 0
+#endif
+// its chunk: agents per pass (45 projections + 45 candidates each, in `proj`)
+constexpr int kLp3Agents = 6;
+constexpr int kLp3Pairs10 = 45;
+__host__ __device__ inline size_t proj_bytes(int nA, int maxl) {
+    const size_t rows = (size_t)16 * kLineStride * nA, lp3 = (size_t)16 * 2 * kLp3Pairs10 * kLp3Agents;
+    return (CN_CAND_LP3_10 != 0 && maxl == 10 && lp3 > rows) ? lp3 : rows;
+}
 
 // maxl: the candidate-form buffers (cand2, cand3) exist for the 5-half-plane kernels only — at 21 agents per env they
 // would cost the 10-half-plane kernels a resident workgroup per CU
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl) {
-    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 4 : 2) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + (size_t)pairs * 8 + 64 + 8 + 16 +
-           sizeof(double) * kMaxDiscount;
+    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 3 : 1) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + proj_bytes(nA, maxl) +
+           (size_t)pairs * 8 + 64 + 8 + 16 + 16 + sizeof(double) * kMaxDiscount;
 }
 
 template <int MAXL>
@@ -123,7 +139,7 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.posd = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
     s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
-    s.proj = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    s.proj = reinterpret_cast<float4*>(p), p += proj_bytes(nA, MAXL);
     s.cand2 = s.cand3 = nullptr;
     if (MAXL == 5) {
         s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
@@ -138,6 +154,7 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.count = reinterpret_cast<int*>(p), p += 4 * nA;
     s.flag = reinterpret_cast<int*>(p), p += 4 * nA;
     s.todo = reinterpret_cast<int*>(p), p += 4 * (nA + 1);
+    p += (16 - (reinterpret_cast<size_t>(p) & 15)) & 15;  // rows of d2 are read as float4 when NC is a multiple of 4
     s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
     s.pinfo = reinterpret_cast<int*>(p), p += 4 * P.pairs;
     s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
@@ -279,7 +296,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                                             PhaseClock* clk = nullptr) {
     (void)clk;
     constexpr bool kCoop = (MAXL == 5) ? (CN_COOP_LP5 != 0) : (CN_COOP_LP10 != 0);
-    constexpr bool kCoop3 = (MAXL == 5) ? (CN_COOP_LP3_5 != 0) : (CN_COOP_LP3_10 != 0);
+    constexpr bool kCand3 = (MAXL == 10) && (CN_CAND_LP3_10 != 0);  // candidate-form fallback, chunks of kLp3Agents agents
+    constexpr bool kCoop3 = !kCand3 && ((MAXL == 5) ? (CN_COOP_LP3_5 != 0) : (CN_COOP_LP3_10 != 0));
     constexpr bool kPar = (MAXL == 5) && (CN_PAR_LP5 != 0) && !kCoop;
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
@@ -289,6 +307,10 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
         pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
     };
+    if (MAXL == 10 && P.NC == 20 && P.orca.max_neighbors == 10) {  // two-sweep pair phase: no neighbour in any slot yet
+        int4* kept4 = reinterpret_cast<int4*>(s.proj);
+        for (int i = threadIdx.x; i * 4 < P.nA * 10; i += blockDim.x) kept4[i] = make_int4(-1, -1, -1, -1);
+    }
     if (L.lane < P.nA) {
         s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
         s.posd[L.lane] = make_double2(r.px, r.py);
@@ -298,7 +320,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             float pref_x, pref_y;
             preferred(pref_x, pref_y);
             s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
-        } else if (kCoop3) {
+        } else if (kCoop3 || kCand3) {
             s.sol[L.lane] = make_float4(0.0f, 0.0f, max_speed, solve ? 1.0f : 0.0f);
         }
     }
@@ -319,6 +341,56 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     // pairs-2: neighbour slot = stable rank by (distSq, visit order) among the in-range candidates, which
     // is what RVO2's sorted insertion with strict '<' produces; slots >= maxNeighbors fall off the list.
     const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
+    // BASELINE configs[3]'s crowd (20 candidates per agent, 10 kept): the candidate row comes in as five 16-byte reads
+    // issued together (the scalar loop waited for LDS once per two candidates: ten round trips per pass of 64 pairs), and
+    // the half-plane is computed in a second sweep over the (agent, kept slot) lanes only — 210 of the 420 ordered pairs,
+    // four passes of a wave instead of seven.  Same comparisons and the same half-plane arithmetic: bit-identical.
+    const bool two_sweeps = MAXL == 10 && P.NC == 20 && P.orca.max_neighbors == 10;
+    if (two_sweeps) {
+        // kept [nA][10]: candidate lane | robot's-sim bit << 8 of the pair that ranks there, -1 = no such neighbour (cleared in
+        // the stage phase; proj is free until the solve).  A pair inside the range ranks by (v < mine) | (v == mine & k < c)
+        // alone: every candidate that precedes it is inside the range too — 4 vector instructions per candidate instead of 7;
+        // the ranks of an agent's in-range candidates are a permutation of 0 .. within - 1, so the neighbours kept are
+        // exactly the filled slots and their number falls out of the second sweep's ballot.
+        int* kept = reinterpret_cast<int*>(s.proj);
+        for (int p = L.lane; p < P.pairs; p += blockDim.x) {
+            const int info = s.pinfo[p];
+            const int c = (info >> 16) & 0xff;
+            const float mine = s.d2[p];
+            const float4* row4 = reinterpret_cast<const float4*>(s.d2 + (p - c));
+            float v[20];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float4 t = row4[j];
+                v[4 * j] = t.x, v[4 * j + 1] = t.y, v[4 * j + 2] = t.z, v[4 * j + 3] = t.w;
+            }
+            int rank = 0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) rank += ((v[k] < mine) | ((v[k] == mine) & (k < c))) ? 1 : 0;
+            if (mine < range_sq && rank < 10) kept[(info & 0xff) * 10 + rank] = ((info >> 8) & 0xff) | (((info >> 25) & 1) << 8);
+        }
+        __syncthreads();
+        // second sweep: lane = (agent, slot), 6 agents per pass of a wave (lanes 60..63 idle)
+        const int wl = threadIdx.x & (kWave - 1), g = wl / 10, slot = wl - g * 10;
+        const int waves = (blockDim.x + kWave - 1) / kWave;
+        for (int q0 = (threadIdx.x / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
+            const int q = q0 + g;
+            const bool lane_ok = wl < 60 && q < P.nA;
+            const int e = lane_ok ? kept[q * 10 + slot] : -1;
+            const bool valid = e >= 0;
+            const unsigned long long vm = __ballot(valid);
+            const int qq = lane_ok ? q : 0;
+            const int ol = valid ? (e & 0xff) : qq;  // unused slots: a finite dummy (the agent against itself), not stored
+            const bool robot_sim = (e >> 8) & 1;
+            const float4 me = s.kin[qq];
+            const float4 ot = s.kin[ol];
+            const float rq_r = s.rview[qq], ro_r = s.rview[ol], rq_h = s.hview[qq], ro_h = s.hview[ol];
+            const float rsum = (valid && robot_sim) ? rq_r + ro_r : rq_h + ro_h;
+            if (lane_ok && slot == 0) s.count[q] = __popcll((vm >> (10 * g)) & 0x3ffull);
+            if (valid)
+                s.lines[q * kLineStride + slot] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
+        }
+    } else
     for (int p = L.lane; p < P.pairs; p += blockDim.x) {
         const int info = s.pinfo[p];
         const int q = info & 0xff, c = (info >> 16) & 0xff;
@@ -434,7 +506,47 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 #ifdef CN_PHASE_TIMING
         if (clk) clk->acc[9] += __popcll(__ballot(need));  // agents in the fallback
 #endif
-        if (kCoop3) {
+        if (kCand3) {
+            if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+                int my_t = 0;
+                if (L.lane < kWave) {
+                    const unsigned long long nm = __ballot(need);
+                    my_t = __popcll(nm & ((1ull << L.lane) - 1ull));
+                    if (need) s.todo[my_t] = L.lane;
+                    if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
+                }
+                __syncthreads();
+                constexpr int kPairs = MAXL * (MAXL - 1) / 2;
+                static_assert(MAXL != 10 || kPairs == kLp3Pairs10, "proj_bytes() sizes the chunk buffers");
+                float4* const projc = s.proj;                          // [kLp3Agents][kPairs] projected half-planes
+                float4* const candc = s.proj + kLp3Agents * kPairs;    // ... and their candidates
+                const int n_todo = s.todo[P.nA];
+                for (int t0 = 0; t0 < n_todo; t0 += kLp3Agents) {
+                    const int nt = n_todo - t0 < kLp3Agents ? n_todo - t0 : kLp3Agents;
+                    const int items = nt * kPairs;
+                    for (int p = threadIdx.x; p < items; p += blockDim.x) {  // projections: lane = (agent, i, j)
+                        const int t = p / kPairs, m = p - t * kPairs;
+                        const int a = s.todo[t0 + t];
+                        const int i = lp3_program_of_n<MAXL>(m), j = m - i * (i - 1) / 2;
+                        const float4* la = s.lines + a * kLineStride;
+                        projc[p] = lp3_project(la[i], la[j]);
+                    }
+                    __syncthreads();
+                    for (int p = threadIdx.x; p < items; p += blockDim.x) {  // their candidates: lane = (agent, i, k)
+                        const int t = p / kPairs, m = p - t * kPairs;
+                        const int a = s.todo[t0 + t];
+                        const int i = lp3_program_of_n<MAXL>(m), base = i * (i - 1) / 2;
+                        const float4 li = s.lines[a * kLineStride + i];
+                        const float4* pa = projc + t * kPairs + base;
+                        candc[p] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
+                    }
+                    __syncthreads();
+                    if (need && my_t >= t0 && my_t < t0 + nt)
+                        lp3_scan_n<MAXL>(mine, projc + (my_t - t0) * kPairs, candc + (my_t - t0) * kPairs, n, fail, max_speed, rx, ry);
+                    __syncthreads();  // the next chunk overwrites the buffers
+                }
+            }
+        } else if (kCoop3) {
             if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible
                 if (L.lane < kWave) {  // agent lanes live in wave 0: compact the infeasible ones
                     const unsigned long long nm = __ballot(need);
