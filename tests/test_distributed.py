@@ -87,4 +87,5 @@ def test_bench_self_launches_its_ranks_without_a_launcher():
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1'],
                        env=env, capture_output=True, text=True, timeout=150)
     assert p.returncode != 0
-    assert p.stderr.count('needs GPU') == 2 and 'rank 1 needs GPU 1' in p.stderr
+    # the first rank to fail makes the parent terminate the other one, which may not have reached its own message yet
+    assert 1 <= p.stderr.count('needs GPU') <= 2 and 'rendezvous' not in p.stderr.lower()

@@ -121,7 +121,7 @@ def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
     B = 203  # 16 443 groups = 1027 full tiles + 11 groups: more tiles than the 1024 persistent waves, and a ragged last one
     space, _, _ = build_action_space(1.0)
     got = {}
-    for reg in ('1', '0'):
+    for reg in ('1', '0'):  # 1 = by size: 1028 tiles are more than the 512 up to which the LDS kernel finishes first
         monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
         eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
         eng.reset(3000 + np.arange(B))
@@ -136,6 +136,45 @@ def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
     assert np.abs(got['1'][0] - want).max() <= 2e-5 and np.abs(got['0'][0] - want).max() <= 2e-5
     assert np.abs(got['1'][0] - got['0'][0]).max() <= 1e-6
     assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
+@pytest.mark.gpu
+def test_register_resident_value_network_on_the_reference_fixtures_and_under_the_mixed_rule(monkeypatch):
+    """Small batches run the LDS kernel by default; forced (CROWDNAV_AMD_SARL_REG=2) the register-resident kernel reproduces the
+    reference fixture's network outputs, and masks an episode's absent humans under the `mixed` rule exactly like the LDS
+    kernel does (attention mean and softmax over the humans present)."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', '2')
+    for name in ('sarl_plain.npz', 'sarl_om.npz'):
+        g = load_golden(name)
+        n = len(g['states'])
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                           robot_visible=int(g['robot_visible']))
+        eng.set_state(g['states'], g['gtime'])
+        eng.sarl_configure(actions=g['action_space'], gamma=0.9, with_om=bool(int(g['with_om'])))
+        eng.sarl_set_weights(_mirror(g).state_dict())
+        out = eng.sarl_select()
+        assert np.abs(eng.sarl_export('V').cpu().numpy() - g['net_out']).max() <= 1e-6
+        assert np.abs(out['values'].cpu().numpy() - g['values']).max() <= 1e-6
+    # mixed rule: 1..5 humans per episode, the absent ones parked and masked
+    torch.manual_seed(11)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    space, _, _ = build_action_space(1.0)
+    B, got = 64, {}
+    for reg in ('2', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        e2 = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1,
+                                          scenario_rule=crowdnav_amd.MIXED)
+        e2.reset(1000 + np.arange(B))
+        e2.step(np.zeros((B, 2)), update=True)
+        e2.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+        e2.sarl_set_weights(net.state_dict())
+        e2.sarl_select()
+        got[reg] = e2.sarl_export('V').cpu().numpy()
+        counts = e2.human_count().cpu().numpy()
+    assert len(set(counts.tolist())) >= 3 and counts.min() < 5
+    assert np.abs(got['2'] - got['0']).max() <= 1e-6
 
 
 def _joint_rows(g, d, a):
