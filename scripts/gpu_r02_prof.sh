@@ -29,6 +29,10 @@ done
 prof trace_sarl --kernel-trace --stats --output-format csv -d $OUT/trace_sarl -o trace -- python $REPO/scripts/sarl_bench.py
 prof pmc_sarl --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sarl -o p -- python $REPO/scripts/sarl_bench.py --iters 3
 cd $REPO
+( CROWDNAV_AMD_LIB=$REPO/crowdnav_amd/lib/exp/lib_timing.so timeout 100 python scripts/sarl_reg_probe.py ) 2>&1 | grep -v amdgpu > $OUT/sarl_reg_probe.txt
+( CROWDNAV_AMD_LIB=$REPO/crowdnav_amd/lib/exp/lib_timing.so timeout 100 python scripts/phase_probe.py ) 2>&1 | grep -v amdgpu | tail -n 14 > $OUT/phase_probe_h5.txt
+( CROWDNAV_AMD_LIB=$REPO/crowdnav_amd/lib/exp/lib_timing.so timeout 100 python scripts/phase_probe.py --humans 20 --circle-radius 12 --steps 1000 ) 2>&1 | grep -v amdgpu | tail -n 14 > $OUT/phase_probe_h20.txt
+timeout 150 python scripts/launch_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/launch_probe.txt
 rm -f $OUT/r02_traffic.json
 python scripts/pmc_to_traffic.py $OUT/r02_traffic.json 4096 5 1000 rollout_fused_kernel tail $OUT/pmc_default_fetch $OUT/pmc_default_write $OUT/pmc_default_sq1 $OUT/pmc_default_sq2 > /dev/null
 python scripts/pmc_to_traffic.py $OUT/r02_traffic.json 4096 5 20 rollout_fused_kernel 2 $OUT/pmc_driver_fetch $OUT/pmc_driver_write $OUT/pmc_driver_sq1 $OUT/pmc_driver_sq2 > /dev/null
