@@ -17,6 +17,7 @@ namespace cn {
 
 struct WaveRng {
     uint32_t* key;   // [624] generator state (LDS)
+    uint32_t* prev;  // [2][624] the states one and two blocks earlier, or NULL (kept only when the stream is handed on)
     uint32_t* out;   // [kWindow] tempered outputs, ring indexed by stream position % kWindow (LDS)
     uint32_t produced;  // stream words generated so far (wave-uniform)
     uint32_t cursor;    // next unread stream word (wave-uniform)
@@ -49,6 +50,13 @@ struct WaveRng {
     // Regenerate the 624-word block in place, in the three dependency-free ranges of the recurrence
     // new[i] = new_or_old[i + 397 mod 624] ^ twist(old[i], old[i + 1]), and append its tempered words to the window.
     __device__ void next_block(int lane) {
+        if (prev) {
+            for (int i = lane; i < 624; i += 64) {
+                prev[624 + i] = prev[i];
+                prev[i] = key[i];
+            }
+            __syncthreads();
+        }
         for (int ph = 0; ph < 3; ++ph) {
             const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454);
             const int hi = ph == 0 ? 227 : (ph == 1 ? 454 : 623);
@@ -86,11 +94,27 @@ struct WaveRng {
         const uint32_t a = word(stream_index) >> 5, b = word(stream_index + 1) >> 6;
         return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     }
+    // The generator after `cursor` words in the form Mt19937 (scenario_device.h) continues from: it regenerates one word at
+    // a time in place, so at position p of block kb its array holds words [0, p) of block kb and words [p, 624) of block
+    // kb - 1 (the seeded state for kb = 0).  The window runs up to a block ahead of the cursor: block kb is the latest one
+    // or the one before it — hence the two kept generations; everything consumed = the latest block at position 0.
+    __device__ void persist(uint32_t* dst, int stride, int* pos_out, int lane) const {
+        const uint32_t latest = produced / 624u;  // blocks generated
+        const uint32_t kb = cursor / 624u;
+        const bool drained = cursor == produced;  // also the freshly seeded generator (0 == 0)
+        const int pos = drained ? 0 : (int)(cursor - kb * 624u);
+        const bool in_latest = kb + 1u == latest;
+        const uint32_t* newer = in_latest ? key : prev;
+        const uint32_t* older = drained ? key : (in_latest ? prev : prev + 624);
+        for (int i = lane; i < 624; i += 64) dst[(size_t)i * stride] = i < pos ? newer[i] : older[i];
+        if (lane == 0) *pos_out = pos;
+    }
 };
 
 // Shared scratch of one generator wave
 struct WaveScratch {
     uint32_t key[624];
+    uint32_t prev[2 * 624];
     uint32_t out[WaveRng::kWindow];
     double2 ppos[64];
     double2 pgoal[64];
@@ -99,11 +123,14 @@ struct WaveScratch {
 
 // Builds agents [0, A) at pos/vel/goal/rv[base + agent] (vel may be NULL); returns np.random.random() calls consumed.
 // Must be called by all 64 lanes of a one-wave workgroup.
+// mt_key_out / mt_stride / mt_pos_out (optional): where the env's own generator continues (cn_reset: epsilon-greedy draws).
 __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScratch& s, uint32_t seed, size_t base,
-                                                  double2* pos, double2* vel, double2* goal, double2* rv) {
+                                                  double2* pos, double2* vel, double2* goal, double2* rv,
+                                                  uint32_t* mt_key_out = nullptr, int mt_stride = 0,
+                                                  int* mt_pos_out = nullptr) {
     const double kPi = 3.141592653589793;
     const int lane = threadIdx.x & 63;
-    WaveRng rng{s.key, s.out, 0, 0};
+    WaveRng rng{s.key, mt_key_out ? s.prev : nullptr, s.out, 0, 0};
     rng.seed(seed, lane);
     const int A = c.num_agents;
     const double R = c.circle_radius;
@@ -216,6 +243,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
         }
     }
     __syncthreads();
+    if (mt_key_out) rng.persist(mt_key_out, mt_stride, mt_pos_out, lane);
     return (uint64_t)(rng.cursor / 2);
 }
 

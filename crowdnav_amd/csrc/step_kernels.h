@@ -930,9 +930,10 @@ __global__ __launch_bounds__(kWave) void reset_wave_kernel(Params P, ScenarioCfg
     __shared__ WaveScratch scratch;
     const int b = blockIdx.x;
     if (mask && !mask[b]) return;
-    const uint64_t n = generate_scenario_wave(C, scratch, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv);
+    // the env's own numpy stream continues where the scenario left it (cn_sarl_explore): mt_key [624][B], mt_pos [B]
+    const uint64_t n = generate_scenario_wave(C, scratch, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv, S.mt_key + b,
+                                              P.B, &S.mt_pos[b]);
     if (threadIdx.x == 0) {
-        S.mt_pos[b] = -1;  // the env's own generator state is not kept by this path
         S.gtime[b] = 0.0;
         S.theta[b] = 1.5707963267948966;
         if (draws) draws[b] = n;

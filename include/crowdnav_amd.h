@@ -255,9 +255,8 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action);
  *   probability = np.random.random(); if probability < epsilon: action_space[np.random.choice(n_actions)]
  * drawn from the env's OWN numpy stream — the one cn_reset seeded (np.random.seed, crowd_sim.py:272-276) continued
  * after the scenario draws, exactly as the sequential reference consumes it.  Needs episodes started by cn_reset
- * (otherwise the next cn_sync fails) and at most 8 humans: larger crowds are generated one wave per scenario, which does
- * not keep the env's generator state (CN_ERR_UNSUPPORTED).  explored (optional) uint8 [B]: 1 where the random action was
- * taken. */
+ * (otherwise the next cn_sync fails); both scenario generators (one lane / one wave per scenario) leave the env's
+ * generator where the scenario's last draw left it.  explored (optional) uint8 [B]: 1 where the random action was taken. */
 int cn_sarl_explore(cn_engine* e, double epsilon, const uint8_t* mask, int32_t* best, double* action,
                     uint8_t* explored);
 /* replaces MultiHumanRL.transform (multi_human_rl.py:90-104; CADRL.transform cadrl.py:171-185 for one human) for the

@@ -94,13 +94,16 @@ def _setup(g):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('randomize', [False, True])
-def test_explore_continues_each_envs_numpy_stream(randomize):
-    """cn_sarl_explore draws from the stream np.random.seed(seed) + the scenario's random() calls left behind."""
+@pytest.mark.parametrize('randomize,humans', [(False, 5), (True, 5), (False, 12), (True, 14)])
+def test_explore_continues_each_envs_numpy_stream(randomize, humans):
+    """cn_sarl_explore draws from the stream np.random.seed(seed) + the scenario's random() calls left behind — with the
+    lane-per-scenario generator (up to 8 humans) and with the wave-per-scenario one, whose window of tempered words runs up
+    to a block ahead of the read position (it keeps the previous block's state for exactly this)."""
     import crowdnav_amd
     B, K = 48, 81
-    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
-                                       robot_visible=1, randomize_attributes=int(randomize))
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                       robot_visible=1, randomize_attributes=int(randomize),
+                                       circle_radius=4.0 if humans == 5 else (5.0 if not randomize else 8.0))
     acts = np.stack([np.arange(K), -np.arange(K)], axis=1).astype(np.float64)
     eng.sarl_configure(actions=acts)
     seeds = 2000 + 17 * np.arange(B)
