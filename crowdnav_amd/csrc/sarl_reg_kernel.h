@@ -178,8 +178,8 @@ __device__ __forceinline__ void reg_dense(RegStream& ws, In in, Init init, Emit 
     constexpr RegShape S = reg_shape(L, XKS);
     constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
     static_assert(!S.paired, "use reg_dense1");
-    // Output tile mt - 1 leaves the accumulators (AGPR -> VGPR, ReLU, or the LDS store) while the first 20 MFMAs of tile mt
-    // issue — two vector instructions in the shadow of every MFMA — instead of between the tiles with the matrix pipe idle.
+    // Output tile mt - 1 leaves the accumulators (AGPR -> VGPR, ReLU, or the LDS store) after the first MFMAs of tile mt have
+    // issued, so that it never waits for the matrix pipe to drain (two accumulator sets).
     f32x4 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < S.mt; ++mt) {
@@ -200,16 +200,12 @@ __device__ __forceinline__ void reg_dense(RegStream& ws, In in, Init init, Emit 
                             __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(nt, ks), ks == 0 ? c0 : acc[mt & 1][nt], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             if (q == 0 && mt > 0) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) emit(nt, mt - 1, RELU ? reg_relu(acc[(mt - 1) & 1][nt]) : acc[(mt - 1) & 1][nt]);
-#pragma unroll
-                for (int i = 0; i < 4 * NT; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
