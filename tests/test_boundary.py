@@ -91,20 +91,22 @@ def test_record_block_kernel_equals_host_pack(amd):
     assert set(np.unique(_np(rec[:, 0, 0])).tolist()) <= {0.0, 2.0, 3.0, 4.0}
 
 
-def test_summary_kernel_is_the_explorer_statistics_and_bitwise_reproducible(amd):
+@pytest.mark.parametrize('n_envs', [1000, 2500])
+def test_summary_kernel_is_the_explorer_statistics_and_bitwise_reproducible(amd, n_envs):
+    """8 000 (env, record) items run the one-workgroup kernel, 20 000 the multi-workgroup one (ticketed last-block sum)."""
     import torch
     from crowdnav_amd import distributed as cd
-    eng, bufs = _rollout(amd, 1000, [200], K=8)
+    eng, bufs = _rollout(amd, n_envs, [200], K=8)
     blocks = eng.rollout_records()
     s = _np(eng.records_summary(blocks))
     assert np.array_equal(s, _np(eng.records_summary(blocks.clone())))  # fixed summation order
     rec, cnt = (_np(t) for t in cd.split_blocks(blocks))
-    held = [rec[b, j] for b in range(1000) for j in range(cnt[b])]
+    held = [rec[b, j] for b in range(n_envs) for j in range(cnt[b])]
     out = np.array([r[0] for r in held])
     assert s[0] == _np(bufs['ep_count']).sum() and s[1] == len(held)
     assert (s[2], s[3], s[4]) == ((out == 2).sum(), (out == 3).sum(), (out == 4).sum())
     assert abs(s[5] - sum(r[3] for r in held if r[0] == 2)) < 1e-6
-    assert abs(s[6] - sum(r[2] for r in held)) < 1e-9
+    assert abs(s[6] - sum(r[2] for r in held)) < 1e-9 + 1e-12 * len(held)  # another summation order
     assert s[7] == sum(r[4] for r in held)
     # explorer.py:74-80 from these eight numbers
     success_rate, collision_rate = s[2] / s[1], s[3] / s[1]
