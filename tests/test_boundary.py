@@ -93,7 +93,7 @@ def test_record_block_kernel_equals_host_pack(amd):
 
 @pytest.mark.parametrize('n_envs', [1000, 2500])
 def test_summary_kernel_is_the_explorer_statistics_and_bitwise_reproducible(amd, n_envs):
-    """8 000 (env, record) items run the one-workgroup kernel, 20 000 the multi-workgroup one (ticketed last-block sum)."""
+    """8 000 and 20 000 (env, record) items: inside one grid stride of the 64 x 256-thread kernel, and beyond it."""
     import torch
     from crowdnav_amd import distributed as cd
     eng, bufs = _rollout(amd, n_envs, [200], K=8)
