@@ -139,6 +139,35 @@ def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('with_om', [False, True])
+def test_value_network_at_the_full_benchmark_size_vs_torch(with_om):
+    """BASELINE configs[2] at full size: 4096 envs x 81 actions x 5 humans = 20 736 tiles through the register-resident kernel
+    (20 full rounds of the 1024 persistent waves + a quarter round) — every one of the 331 776 network outputs against the
+    torch fp32 module on the same device, and the decision's arg-max against the combined values."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(7)
+    d = 61 if with_om else 13
+    net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    B = 4096
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.reset(2000 + np.arange(B))
+    eng.step(np.zeros((B, 2)), update=True)
+    space, _, _ = build_action_space(1.0)
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
+    eng.sarl_set_weights(net.state_dict())
+    out = eng.sarl_select()
+    X, V = eng.sarl_export('X'), eng.sarl_export('V')
+    dev_net = net.to(X.device)
+    with torch.no_grad():
+        want = torch.cat([dev_net(X.reshape(B * 81, 5, d)[i:i + 65536]) for i in range(0, B * 81, 65536)]).reshape(B, 81)
+    assert float((V.reshape(B, 81) - want).abs().max()) <= 2e-5
+    values = out['values']
+    assert torch.equal(out['best'].long(), values.argmax(dim=1)) or \
+        float((values.gather(1, out['best'].long()[:, None])[:, 0] - values.max(dim=1).values).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_register_resident_value_network_on_the_reference_fixtures_and_under_the_mixed_rule(monkeypatch):
     """Small batches run the LDS kernel by default; forced (CROWDNAV_AMD_SARL_REG=2) the register-resident kernel reproduces the
     reference fixture's network outputs, and masks an episode's absent humans under the `mixed` rule exactly like the LDS
