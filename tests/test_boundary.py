@@ -77,6 +77,18 @@ def test_ring_redo_pool_regenerates_long_rejection_chains_exactly(amd, oracle_mo
     _same_as_oracle(eng, bufs, o, total, rec, cur, B, steps)
 
 
+@pytest.mark.parametrize('B,H,R,steps', [(3, 2, 4.0, 150), (5, 7, 5.0, 150), (7, 3, 4.0, 151), (4, 12, 8.0, 120)])
+def test_fused_rollout_with_auto_reset_at_edge_sizes(amd, oracle_mod, B, H, R, steps):
+    """Odd batch sizes (the last wave is padded), crowds on either side of every kernel boundary (the four-barrier fused
+    kernel up to 5 humans, the general 5- and 10-half-plane kernels, lane- and wave-per-scenario generators): episodes,
+    auto-resets and end states of cn_rollout equal the oracle's, whatever the launch lengths."""
+    cfg = dict(num_humans=H, circle_radius=R)
+    o, total, rec, cur = _oracle_rollout(oracle_mod, B, steps, **cfg)
+    assert rec['count'].sum() >= B  # every env went through at least one auto-reset on average
+    eng, bufs = _rollout(amd, B, [steps // 3, steps - steps // 3 - 7, 7], **cfg)
+    _same_as_oracle(eng, bufs, o, total, rec, cur, B, steps)
+
+
 def test_record_block_kernel_equals_host_pack(amd):
     import torch
     from crowdnav_amd import distributed as cd
