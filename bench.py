@@ -14,12 +14,16 @@ start their first episode in lock step, so without it a short run would time a s
 ends; after it the episodes are spread over all phases and the timed steps contain their share of episode ends and
 auto-resets (`episodes_finished`).
 
-Multi-GPU: the env axis is sharded (weak scaling: 4096 envs per GPU, global env ids offset by rank, no collective on the
-step path); the only exchange is one all-gather (RCCL) of the per-env episode-record blocks at the end, inside the timed
-region, followed by the job-wide summary kernel.  The JSON line also carries `roofline` (algorithmic bytes of the
-dominant kernel over its HIP-event duration), `issue_roofline` (the bound that actually limits this kernel, only when the
-committed PMC profile is of the same launch shape) and, at N=1, `cpu_baseline` (the CPU oracle timed on this host's
-cores on a bounded sample of the same workload).
+The timed region is the step path: the K batched steps, whose rollout launches also leave the shard's episode statistics
+(explorer.py:74-90) and record blocks behind (their last workgroup; no boundary kernel).  Multi-GPU: the env axis is sharded
+(weak scaling: 4096 envs per GPU, global env ids offset by rank, no collective on the step path); every rank times its own K
+steps between a barrier + synchronize on both sides, value = all ranks' transitions / the slowest rank's time; the one
+exchange of a job — the all-gather (RCCL) of the per-env record blocks + the job-wide summary kernel at the END of a run —
+is timed separately as `boundary_ms` (and `value_incl_boundary` charges it to these K steps).  The JSON line also carries
+`roofline` (algorithmic bytes of the dominant kernel over its HIP-event duration), `issue_roofline` (the bound that
+actually limits this kernel, only when the committed PMC profile is of the same launch shape) and, at N=1, `cpu_baseline`
+(the CPU oracle timed on this host's cores on a bounded sample of the same workload; + the unmodified reference Python
+loop as timed in the build container) and `secondary` (BASELINE configs[2] and configs[3] measured in the same run).
 """
 import argparse
 import json
@@ -35,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
-PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
 
 
 def algorithmic_bytes_per_env_step(H):
@@ -79,10 +83,16 @@ def pmc_issue(rec, envs, steps_per_launch, launch_seconds):
     return out
 
 
-def bench_sarl(args, world, rank, local_rank):
-    """BASELINE configs[2]: 4096 envs x 5 humans, SARL value-network rollout (random-init weights), greedy phase.
+def sarl_flop(B, H, om):
+    """algorithmic flops of one batched value-network decision: per (env, action) tile of H humans"""
+    return 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B
+
+
+def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
+    """BASELINE configs[2]: B envs x H humans, SARL value-network rollout (random-init weights), greedy phase.
     A step = cn_sarl_select (81 lookaheads + value network per env) + cn_rollout_step (transition, bookkeeping, seeded
-    auto-reset)."""
+    auto-reset).  HIP events bracket every cn_sarl_select (the MFMA roofline is the value network's flops over THAT time)
+    and every whole step."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -90,8 +100,6 @@ def bench_sarl(args, world, rank, local_rank):
     from crowdnav_amd import distributed as cd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
     from crowdnav_amd.sarl_rollout import SarlRollout
-    B, H = args.envs, args.humans
-    om = args.workload == 'om-sarl'
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
                                        robot_visible=1, device=local_rank)
     torch.manual_seed(0)
@@ -101,46 +109,128 @@ def bench_sarl(args, world, rank, local_rank):
     eng.sarl_set_weights(net.state_dict())
     off, stride = cd.shard(rank, world, B)
     ro = SarlRollout(eng, 0.9, seed_base=2000, seed_mod=2 ** 32 - 2000, env_offset=off, env_stride=stride)
-    steps, warm = min(args.steps, 200), min(args.warmup, 20)
-    ro.run(min(args.preroll, 60))
+    ro.run(preroll)
     ro.run(warm)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    for e3 in ev:
+        for e in e3:
+            e.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize()
     before = int(ro.transitions.item())
-    sel_ms = []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for e0, e1, e2 in ev:
         e0.record()
-        ro.step()
+        sel = eng.sarl_select(want_values=False)
         e1.record()
-        sel_ms.append((e0, e1))
+        eng.rollout_step(sel['action'])
+        e2.record()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
     transitions = int(ro.transitions.item()) - before
     tot = torch.tensor([float(transitions)], dtype=torch.float64, device='cuda')
     tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if world > 1:  # real per-rank counts over the slowest rank's time
         dist.all_reduce(tot)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    flop = 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B
-    step_s = sum(a.elapsed_time(b) for a, b in sel_ms) / 1e3 / steps
+    flop = sarl_flop(B, H, om)
+    select_s = sum(a.elapsed_time(b) for a, b, _ in ev) / 1e3 / steps
+    step_s = sum(a.elapsed_time(c) for a, _, c in ev) / 1e3 / steps
+    name = 'om-sarl' if om else 'sarl'
     out = {
-        'metric': 'env-steps/sec, %d envs x %d humans, %s value-net rollout (BASELINE configs[2])' % (B, H, args.workload),
+        'metric': 'env-steps/sec, %d envs x %d humans, %s value-net rollout (BASELINE configs[2])' % (B, H, name),
         'value': float(tot.item()) / float(tmax.item()), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps,
         'warmup': warm, 'ms_per_step': float(tmax.item()) * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32 (FP32 MFMA value network, f64 lookahead rewards)', 'data': 'synthetic',
-        'config': {'workload': '%d envs x %d humans, 81 actions, %s, random-init weights' % (B, H, args.workload),
-                   'preroll_steps': min(args.preroll, 60)},
-        'roofline': {'bound': 'mfma', 'achieved': flop / step_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
-                     'frac': flop / step_s / 1e12 / 157.3, 'traffic': None,
-                     'note': 'flops of the value network / whole batched step (select + step + reset + bookkeeping)'},
+        'config': {'workload': '%d envs x %d humans, 81 actions, %s, random-init weights' % (B, H, name),
+                   'preroll_steps': preroll},
+        'roofline': {'bound': 'mfma', 'achieved': flop / select_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                     'frac': flop / select_s / 1e12 / 157.3, 'traffic': None,
+                     'kernel': 'cn_sarl_select (orca + lookahead + reward + feature + value-network + select kernels; the '
+                               'value network is cn::sarl_reg_kernel)',
+                     'select_ms': select_s * 1e3, 'step_ms': step_s * 1e3,
+                     'frac_of_whole_step': flop / step_s / 1e12 / 157.3,
+                     'note': 'algorithmic flops of the value network over the HIP-event time of cn_sarl_select; '
+                             'frac_of_whole_step: over select + transition + reset + bookkeeping'},
     }
+    del ro, eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_sarl(args, world, rank, local_rank):
+    out = measure_sarl(args.envs, args.humans, args.workload == 'om-sarl', min(args.steps, 200), min(args.warmup, 20),
+                       min(args.preroll, 60), world, rank, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def measure_h20(B, local_rank):
+    """BASELINE configs[3]'s shard on one GPU: 4096 envs x 20 humans (rollout_kernel<10>, one env per wave).  Three figures:
+    the reference geometry (4 m circle, where the reference's rejection sampling makes RESETS the bound) with the
+    asynchronous scenario fill, resets included; the same geometry with resets excluded (47-step launches inside the
+    48-episode ring budget, the fill launch before each of them untimed); and the 12 m circle, where resets are cheap."""
+    import torch
+    import crowdnav_amd
+    H = 20
+
+    def one(radius, flags, seed_base, seed_mod, warm, lengths, refill_before_each=False):
+        sim = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA, robot_visible=1,
+                                           device=local_rank, circle_radius=radius, flags=flags)
+        bufs = sim.rollout_begin(seed_base=seed_base, seed_mod=seed_mod, episode_limit=-1, record_capacity=4)
+        for n in warm:
+            sim.rollout(n)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in lengths]
+        torch.cuda.synchronize()
+        done = 0
+        for (e0, e1), n in zip(evs, lengths):
+            if refill_before_each:  # a 1-step launch spends the ring budget's last step: it carries the (untimed) fill
+                sim.rollout(1)
+                torch.cuda.synchronize()
+            n0 = int(bufs['transitions'].item())
+            e0.record()
+            sim.rollout(n)
+            e1.record()
+            torch.cuda.synchronize()
+            done += int(bufs['transitions'].item()) - n0
+        secs = sum(a.elapsed_time(b) for a, b in evs) / 1e3
+        res = {'value': done / secs, 'unit': 'env-steps/s', 'launches': lengths, 'seconds': secs,
+               'paused_env_steps': B * sum(lengths) - done,
+               'roofline_frac_hbm': algorithmic_bytes_per_env_step(H) * done / secs / 1e9 / HBM_PEAK_GBS}
+        sim.sync()
+        del sim, bufs
+        torch.cuda.empty_cache()
+        return res
+
+    seeds = (1000, 1024)  # the 'test' phase seeds, on which the reference's own rejection sampling terminates
+    return {
+        'workload': '%d envs x %d humans per GPU, ORCA humans + ORCA robot, cn::rollout_kernel<10>' % (B, H),
+        'r4_async_fill': one(4.0, crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL, seeds[0], seeds[1], [500], [1000, 1000]),
+        'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47, 47, 47], refill_before_each=True),
+        'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [200, 500], [500, 500, 500]),
+        'episode_seeds_r4': '%d + c %% %d' % seeds,
+        'note': 'r4_async_fill: resets included (envs whose next scenario is not ready pause: paused_env_steps); '
+                'r4_resets_excluded: HIP events around 47-step launches that stay inside the ring budget, so the timed launch '
+                'is the transition kernel alone (the synchronous fill runs in the untimed 1-step launch before it); r12: '
+                'resets included, cheap at that radius',
+    }
+
+
+def secondary(B, local_rank):
+    """BASELINE configs[2] (SARL / OM-SARL value-network rollouts) and configs[3] (20 humans) measured in the SAME run as
+    the headline, after its timed region, so that the driver's record carries them."""
+    out = {}
+    for om in (False, True):
+        r = measure_sarl(B, 5, om, 50, 10, 30, 1, 0, local_rank)
+        key = 'om_sarl' if om else 'sarl'
+        out[key] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'roofline')}
+        out[key]['workload'] = r['config']['workload']
+    out['h20'] = measure_h20(B, local_rank)
+    return out
 
 
 def cpu_baseline(envs, humans, target_seconds=8.0):
@@ -171,7 +261,17 @@ def cpu_baseline(envs, humans, target_seconds=8.0):
     steps1 = max(20, int(0.4 * target_seconds * n / dt / envs))
     n_one, dt_one = run(1, steps1)
     crowd_oracle.CrowdOracle.set_threads(cores)
+    # north_star: "next to the reference Python-RVO2 CPU path": the unmodified reference loop cannot run on the GPU box
+    # (/root/reference does not travel); its timing in the build container is committed by oracle/time_reference_python.py
+    ref_py = None
+    ref_path = os.path.join(ROOT, 'profiles', 'r03_reference_python.json')
+    if os.path.exists(ref_path):
+        r = json.load(open(ref_path))
+        ref_py = {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'],
+                  'host': r['host_cpu'] + ' (build container, NOT this host)',
+                  'note': r['what'] + '; on the float32 rvo2 restatement; profiles/r03_reference_python.json'}
     return {
+        'reference_python': ref_py,
         'value': n_all / dt_all, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
         'sample': '%d envs x %d humans x %d steps, auto-reset, OpenMP over envs (oracle/crowd_oracle.cpp, '
                   'float32 RVO2 restatement; upstream Python-RVO2 is not installable offline), %.1f s of wall time on '
@@ -229,6 +329,8 @@ def main():
     ap.add_argument('--async-fill', action='store_true',
                     help='CN_FLAG_ASYNC_SCENARIO_FILL: scenario generation on side streams (crowds of more than 8 humans)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the configs[2] / configs[3] measurements that follow the headline at N=1')
     ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
                     help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
     args = ap.parse_args()
@@ -264,9 +366,12 @@ def main():
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
                                        robot_visible=1, device=local_rank, circle_radius=args.circle_radius,
                                        flags=crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL if args.async_fill else 0)
-    # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply
+    # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply.
+    # boundary_records=1: every rollout launch leaves the shard's explorer.py:74-90 sums (bufs['summary']) and one record
+    # block per env (bufs['blocks'], 56 B per env: the all-gather's input) behind — its own last workgroup, no extra kernel
     bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=4,
-                             env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1])
+                             env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1],
+                             boundary_records=1)
 
     # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
     # inside the timed region costs more host time than a 20-step launch's enqueue
@@ -287,48 +392,57 @@ def main():
                 events.append((e0, e1, n))
             left -= n
 
-    def fence():
+    def drain():
         pool[-1].record()
         while not pool[-1].query():  # spin until the stream has drained: a blocking synchronize alone wakes up late
             pass
         torch.cuda.synchronize()
+
+    def fence():
+        drain()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
     def shard_boundary():
-        """episode records of this shard (one pack kernel) -> every rank (one RCCL all-gather) -> the job-wide summary
-        of explorer.py:74-90 (one kernel): float64 [8] on the device"""
-        blocks = eng.rollout_records(max_records=1)  # one (the env's latest-slot) episode per env: 56 B per env to exchange
-        if world > 1:
-            blocks = cd.gather_blocks(blocks)
-        return eng.records_summary(blocks)
+        """What a run does ONCE, when it ends (explorer.py:74): single GPU - nothing, the last launch has written the
+        statistics; sharded - the record blocks of every rank (one RCCL all-gather of 56 B per env) and the job-wide
+        summary of explorer.py:74-90 (one kernel): float64 [8] on the device"""
+        if world == 1:
+            return bufs['summary']
+        return eng.records_summary(cd.gather_blocks(bufs['blocks']), record_capacity=4)
 
     run(args.preroll)
     run(args.warmup)
     shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
     fence()
     before = int(bufs['transitions'].item())
-    ep_before = float(shard_boundary()[0].item())
+    ep_before = float(bufs['summary'][0].item())
     events = []
-    fence()
+    fence()  # barrier + synchronize
     t0 = time.perf_counter()
     run(args.steps, events)
-    summary = shard_boundary()
-    fence()
+    drain()  # this rank's K steps are done (synchronize) ...
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()  # ... and every rank's, before anything else is launched
+    tb = time.perf_counter()
+    summary = shard_boundary()
+    drain()
+    boundary = time.perf_counter() - tb if world > 1 else 0.0
+    own_episodes = float(bufs['summary'][0].item()) - ep_before
 
     transitions = int(bufs['transitions'].item()) - before
     # an env whose 48-deep scenario ring ran dry inside one launch pauses until the next launch; count what ran
     paused_env_steps = B * args.steps - transitions
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    t = torch.tensor([elapsed, boundary], dtype=torch.float64, device='cuda')
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    n = torch.tensor([transitions], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's K steps; the slowest rank's boundary
+    elapsed, boundary = float(t[0].item()), float(t[1].item())
+    n = torch.tensor([transitions, own_episodes], dtype=torch.float64, device='cuda')
     if world > 1:
         dist.all_reduce(n)  # transitions of every shard (they differ by the few ring-dry pauses)
-    total = int(n.item())
+    total, episodes = int(n[0].item()), int(n[1].item())
 
     kernel_s = sum(e0.elapsed_time(e1) for e0, e1, _ in events) / 1e3
     launches = len(events)
@@ -343,28 +457,38 @@ def main():
         'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 ORCA solve + f64 env step', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[%d]: %d batched envs x %d humans per GPU, ORCA humans + holonomic '
-                               'ORCA robot (visible), circle_crossing radius %g, in-kernel auto-reset'
-                               % (1 if (B, H) == (4096, 5) else 3 if H == 20 else 1, B, H, args.circle_radius),
+        'config': {'workload': '%s%d batched envs x %d humans per GPU, ORCA humans + holonomic ORCA robot (visible), '
+                               'circle_crossing radius %g, in-kernel auto-reset'
+                               % ('BASELINE configs[1]: ' if (B, H) == (4096, 5) else "BASELINE configs[3]'s shard: " if
+                                  (B, H) == (4096, 20) else '', B, H, args.circle_radius),
                    'envs_per_gpu': B, 'humans': H, 'steps_per_launch': steps_per_launch, 'launches': launches,
                    'episode_seeds': '%d + c %% %d' % (args.seed_base, args.seed_mod),
                    'scenario_fill': 'asynchronous (side streams, per-slot ready flags)' if args.async_fill else 'before each launch',
                    'preroll_steps': args.preroll,
-                   'parallelism': 'env-axis shards x%d, all-gather of episode records at the end' % world},
+                   'parallelism': 'env-axis shards x%d, no collective on the step path; one all-gather of episode records '
+                                  'when a run ends (boundary_ms)' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof),
-                     'kernel': 'cn::rollout_fused_kernel (one cn_rollout call; + cn::ring_fill_kernel when the scenario '
-                               'ring needs topping up)' if H <= 5 else 'cn::rollout_kernel<10> (+ cn::ring_fill_wave_kernel)',
+                     'kernel': 'cn::rollout_fused_kernel (one cn_rollout call incl. its in-kernel statistics epilogue; + '
+                               'cn::ring_fill_kernel when the scenario ring needs topping up)' if H <= 5 else
+                               'cn::rollout_kernel<10> (+ cn::ring_fill_wave_kernel)',
                      'avg_launch_ms': avg_launch_s * 1e3,
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
         'issue_roofline': pmc_issue(prof, B, steps_per_launch, avg_launch_s),
+        'boundary_ms': boundary * 1e3,
+        'value_incl_boundary': total / (elapsed + boundary),
         'paused_env_steps': paused_env_steps,
-        'episodes_finished': int(s[0] - ep_before),
+        'episodes_finished': episodes,
         'mean_recorded_return': s[6] / max(s[1], 1.0),
         'recorded_success_rate': s[2] / max(s[1], 1.0),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(B, H)
+    if rank == 0 and world == 1 and not args.no_secondary and (B, H) == (4096, 5):
+        eng.sync()
+        del eng, bufs
+        torch.cuda.empty_cache()
+        out['secondary'] = secondary(B, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CROWDNAV_AMD_LIB: another build of the same library (kernel A/B experiments, scripts/gpu_ab.sh); default in-tree
 LIB_PATH = os.environ.get('CROWDNAV_AMD_LIB') or os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
@@ -59,6 +59,7 @@ class CnRolloutIo(C.Structure):
         ('ep_count', C.c_void_p), ('cur_steps', C.c_void_p), ('cur_return', C.c_void_p),
         ('cur_danger', C.c_void_p), ('cur_danger_dmin_sum', C.c_void_p),
         ('active', C.c_void_p), ('transitions', C.c_void_p),
+        ('summary', C.c_void_p), ('blocks', C.c_void_p), ('blocks_records', C.c_int32),
     ]
 
 
@@ -88,6 +89,7 @@ SYMBOLS = {
     'cn_get_theta': (C.c_int, [_P, _P]),
     'cn_get_human_count': (C.c_int, [_P, _P]),
     'cn_drop_robot_sim': (C.c_int, [_P]),
+    'cn_drop_sims': (C.c_int, [_P]),
     'cn_set_robot_sim': (C.c_int, [_P, _P, C.c_float]),
     'cn_reset': (C.c_int, [_P, _P, _P, _P]),
     'cn_orca': (C.c_int, [_P, _P]),

@@ -138,7 +138,7 @@ inline int grid_lanes(const cn_engine* e) { return (e->P.B + cn::kWave - 1) / cn
 extern "C" {
 
 const char* cn_last_error(void) { return g_err; }
-int cn_abi_version(void) { return 4; }
+int cn_abi_version(void) { return 5; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
     if (!c || !out) return fail(CN_ERR_INVALID, "cn_create: NULL argument");
@@ -265,7 +265,11 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
-        (rc = dev_alloc(e, &S.launch_trans, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &S.trans_shard, (size_t)cn::kTransShards)) ||
+        (rc = dev_alloc(e, &S.wg_partial, (size_t)P.B * CN_SUMMARY_FIELDS)) ||
+        (rc = dev_alloc(e, &S.group_partial, (size_t)cn::kEpilogueGroups * CN_SUMMARY_FIELDS)) ||
+        (rc = dev_alloc(e, &S.tickets, (size_t)cn::kEpilogueGroups + 1)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1)) ||
         (rc = dev_alloc(e, &e->S_dev, (size_t)1))) {
         cn_destroy(e);
@@ -454,6 +458,12 @@ int cn_drop_robot_sim(cn_engine* e) {
     return CN_OK;
 }
 
+int cn_drop_sims(cn_engine* e) {
+    int rc = cn_drop_robot_sim(e);
+    if (rc) return rc;
+    return CN_OK;
+}
+
 int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t* draws) {
     int rc = bind(e);
     if (rc) return rc;
@@ -513,9 +523,22 @@ int cn_set_gamma(cn_engine* e, double gamma) {
     return CN_OK;
 }
 
+// CN_FLAG_ASYNC_SCENARIO_FILL: fill kernels still in flight on the side streams read the device copy of the io block, the
+// caller's buffers behind it and the claim / ready flags.  Before any of those change hands (a new io block, a restart of the
+// bookkeeping) the host waits for them: a straggler of the previous rollout must not publish a scenario of the old seed
+// numbering into the new one's ring, nor read buffers the caller is about to free.
+static int drain_fill_streams(cn_engine* e) {
+    if (!e->async_fill) return CN_OK;
+    for (int i = 0; i < cn_engine::kFillStreams; ++i)
+        if (e->fill_streams[i]) CN_HIP(hipStreamSynchronize(e->fill_streams[i]));
+    return CN_OK;
+}
+
 // Upload the caller's io struct (ordered on the engine's stream) if it differs from the device copy.
 static int upload_io(cn_engine* e, const cn_rollout_io* io) {
     if (e->io_valid && std::memcmp(&e->io_host, io, sizeof(*io)) == 0) return CN_OK;
+    int rc = drain_fill_streams(e);
+    if (rc) return rc;
     e->io_host = *io;
     CN_HIP(hipMemcpyAsync(e->io_dev, &e->io_host, sizeof(*io), hipMemcpyHostToDevice, e->stream));
     e->io_valid = true;
@@ -529,6 +552,7 @@ static int check_io(const cn_engine* e, const cn_rollout_io* io) {
     if (!io->ep_count || !io->cur_steps || !io->cur_return || !io->active)
         return fail(CN_ERR_INVALID, "rollout io: ep_count, cur_steps, cur_return and active are required");
     if (io->record_capacity < 0) return fail(CN_ERR_INVALID, "record_capacity must be >= 0");
+    if (io->blocks && io->blocks_records < 1) return fail(CN_ERR_INVALID, "rollout io: blocks needs blocks_records >= 1");
     if (io->env_offset < 0 || io->env_stride < io->env_offset + e->P.B)
         return fail(CN_ERR_INVALID, "rollout io: need env_offset >= 0 and env_stride >= env_offset + num_envs");
     return CN_OK;
@@ -537,7 +561,7 @@ static int check_io(const cn_engine* e, const cn_rollout_io* io) {
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     int rc = bind(e);
     if (rc) return rc;
-    if ((rc = check_io(e, io)) || (rc = upload_io(e, io))) return rc;
+    if ((rc = check_io(e, io)) || (rc = drain_fill_streams(e)) || (rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     if (e->gen_wave)
         hipLaunchKernelGGL(cn::rollout_begin_wave_kernel, dim3(e->P.B), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
@@ -599,7 +623,9 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     const cn::Params& P = e->P;
     static const bool use_fused = env_int("CROWDNAV_AMD_FUSED", 1) != 0;
     const bool headline = P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 && P.threads == 64;
-    if (use_fused && e->maxl == 5 && !P.robot_unicycle && P.NC <= cn::kFusedMaxNC && P.pairs <= cn::kWave &&
+    // (the fused kernel reads the launch-time fill level only: never with the asynchronous fill, whose slots are published
+    // one by one — CROWDNAV_AMD_WAVE_SCENARIOS=1 can switch that on for a small crowd)
+    if (use_fused && !e->async_fill && e->maxl == 5 && !P.robot_unicycle && P.NC <= cn::kFusedMaxNC && P.pairs <= cn::kWave &&
         P.nA * 5 <= cn::kWave && P.threads == cn::kWave) {
         if (headline)
             hipLaunchKernelGGL((cn::rollout_fused_kernel<true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
@@ -613,8 +639,6 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     } else {
         CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, action);
     }
-    hipLaunchKernelGGL(cn::rollout_finish_kernel, dim3(1), dim3(1024), 0, e->stream, P.B, (const uint32_t*)e->S.launch_trans,
-                       (const cn_rollout_io*)e->io_dev);
 }
 
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {

@@ -17,8 +17,11 @@ constexpr int kRecordFields = CN_RECORD_FIELDS;  // outcome, steps, discounted r
 
 __host__ __device__ inline size_t record_block_doubles(int K) { return 1 + (size_t)K * kRecordFields; }
 
-// blocks [B][1 + K * 6] f64: block b = { episodes env b has FINISHED (unclamped), then K records }; record j is the
-// env's j-th episode and is valid while j < min(count, record_capacity, K), zeros otherwise.
+// blocks [B][1 + K * 6] f64: block b = { episodes env b has FINISHED (unclamped), then K records }; record j is slot j of
+// the env's record RING (the rollout kernels write episode e to slot e % record_capacity): the env's j-th episode while
+// count <= record_capacity, afterwards its most recent episode with ordinal = j mod record_capacity; valid while
+// j < min(count, record_capacity, K), zeros otherwise.  (The rollout kernels' own epilogue writes the same blocks when
+// cn_rollout_io.blocks is set: step_kernels.h, rollout_epilogue.)
 __global__ void records_pack_kernel(int B, int K, const cn_rollout_io* io_dev, double* blocks) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * K) return;

@@ -362,8 +362,8 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
         S.goal[L.gi] = make_double2(r.gx, r.gy);
         S.rv[L.gi] = make_double2(r.rad, r.vpref);
     }
+    const cn_rollout_io io = *iop;
     if (robot) {
-        const cn_rollout_io io = *iop;
         S.gtime[L.env] = ep.gtime;
         S.theta[L.env] = theta;
         if (P.robot_orca) S.rsim_valid[L.env] = 1;
@@ -373,8 +373,10 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
         io.cur_return[L.env] = cur_return;
         if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
-        S.launch_trans[L.env] = transitions;  // summed by rollout_finish_kernel (no same-address atomics here)
+        S.ep_word[L.env] = (ep.ep_count << 2) | ep.state;
     }
+    // transitions counter, record blocks, explorer.py:74-90 sums: the launch's own tail (step_kernels.h: rollout_epilogue)
+    rollout_epilogue(P, S, io, L, robot, transitions, ep.ep_count, reinterpret_cast<double*>(s.lines));
 }
 
 }  // namespace cn

@@ -66,8 +66,17 @@ struct StateView {
     int* ring_filled_out;   // [B] (written by the fill kernel; the host swaps the two)
     int* ring_ready;        // [B*D] async fill: ordinal + 1 of the scenario a slot holds, stored with release once it is complete
     int* ring_claim;        // [B*D] async fill: ordinal + 1 some fill launch is generating (or has generated) for the slot
-    uint32_t* launch_trans; // [B] transitions each env executed in the last rollout launch (summed by rollout_finish_kernel)
+    int* ep_word;           // [B] (episodes finished << 2) | io.active state, ONE word stored by the rollout kernels next to the
+                            // two io arrays: the asynchronous fill reads it for a consistent (state, ep_count) snapshot
+    // launch epilogue of the rollout kernels (rollout_epilogue): arrival tickets and partial sums
+    unsigned long long* trans_shard;  // [kTransShards] transitions of the running launch, sharded by workgroup index
+    double* wg_partial;     // [workgroups][CN_SUMMARY_FIELDS] per-workgroup sums over its envs' record rings
+    double* group_partial;  // [kEpilogueGroups][CN_SUMMARY_FIELDS]
+    unsigned* tickets;      // [kEpilogueGroups + 1] arrivals per group, then of the group leaders; zero between launches
 };
+
+constexpr int kTransShards = 64;
+constexpr int kEpilogueGroups = 8;  // workgroup b arrives at counter b % 8 (= its XCD under the observed placement)
 
 struct StepIo {
     const double* action;
@@ -865,6 +874,7 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, Scenario
     const int64_t c0 = episode_id(io, b, 0);
     const bool on = io.episode_limit < 0 || c0 < io.episode_limit;
     io.active[b] = on ? kRunning : kRetired;
+    S.ep_word[b] = on ? kRunning : kRetired;
     io.ep_count[b] = 0;
     io.cur_steps[b] = 0;
     io.cur_return[b] = 0.0;
@@ -948,6 +958,7 @@ __global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, Sce
     const bool on = io.episode_limit < 0 || c0 < io.episode_limit;
     if (threadIdx.x == 0) {
         io.active[b] = on ? kRunning : kRetired;
+        S.ep_word[b] = on ? kRunning : kRetired;
         io.ep_count[b] = 0;
         io.cur_steps[b] = 0;
         io.cur_return[b] = 0.0;
@@ -996,9 +1007,13 @@ __global__ __launch_bounds__(kWave) void ring_fill_wave_async_kernel(Params P, S
     const int D = P.ring_depth;
     const int b = idx / D, slot = idx - b * D;
     const cn_rollout_io* io = R.io;
-    const int state = io->active[b];
+    // (state, episodes finished) of the env as ONE word: the transition kernel running beside this launch stores it once
+    // when it ends — two separate loads of io->active / io->ep_count could pair an old state with a new count and claim a
+    // slot whose scenario has not been consumed yet
+    const int word = __hip_atomic_load(&S.ep_word[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int state = word & 3;
     if (state == kRetired) return;
-    const int next = io->ep_count[b] + (state == kWaitingScenario ? 0 : 1);
+    const int next = (word >> 2) + (state == kWaitingScenario ? 0 : 1);
     const int ordinal = next + ((slot - next % D) + D) % D;
     const int64_t c = episode_id(*io, b, ordinal);
     if (io->episode_limit >= 0 && c >= io->episode_limit) return;
@@ -1055,6 +1070,133 @@ __device__ __forceinline__ int finish_episode(const Params& P, const StateView& 
     if (scenario_ready(P, S, env, ep_count, ring_filled)) return 2 + ep_count % ring_depth;
     state = kWaitingScenario;  // ring ran dry (or this scenario is still being generated): pause until a later launch
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- launch epilogue
+// Behind every rollout launch there used to be three more kernels on the stream: rollout_finish_kernel (the transitions
+// counter), records_pack_kernel (the shard's record blocks) and records_summary_kernel (explorer.py:74-90) — 18 us of
+// kernels plus their boundaries behind a 106 us launch in the driver's 20-step shape.  They are the tail of the rollout
+// kernel now: every workgroup leaves its share (transitions into a sharded counter, its envs' record blocks, the sums over
+// its envs' record rings), takes an arrival ticket of its group (workgroup b -> counter b % 8: 256 arrivals per counter at
+// 2048 workgroups, ~12 ns each, spread over the time the workgroups finish), the last arrival of a group adds the group's
+// partial sums in workgroup order and arrives at the top counter, and the last of those writes the results.  The summation
+// order is a function of the workgroup indices only, never of the arrival order: the same bits on every run.
+// Hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility): payload as 8-byte agent-scope atomic
+// stores (write-through), s_waitcnt vmcnt(0), then the ticket (agent-scope RMW); the reader loads the payload with
+// agent-scope atomic loads after its own ticket came back.  No L2 write-back / L1 invalidate fences.
+__device__ __forceinline__ void agent_store(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double agent_load(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// scratch: LDS, at least (E * CN_SUMMARY_FIELDS + 1) doubles, free after the last barrier of the step loop.
+// Called by every thread of the workgroup (contains barriers); `transitions` / `ep_count` are read on the robot lanes.
+__device__ __forceinline__ void rollout_epilogue(const Params& P, const StateView& S, const cn_rollout_io& io, const Lane& L,
+                                                 bool robot, unsigned int transitions, int ep_count, double* scratch) {
+    constexpr int F = CN_SUMMARY_FIELDS;
+    const int tid = threadIdx.x;
+    if (robot && transitions)
+        atomicAdd(&S.trans_shard[blockIdx.x & (kTransShards - 1)], (unsigned long long)transitions);  // no return value
+    const int cap = io.record_capacity;
+    const int held = ep_count < cap ? ep_count : cap;
+    if (robot && io.blocks) {  // cn_rollout_records' block of this env
+        const int K = io.blocks_records;
+        double* blk = io.blocks + (size_t)L.env * (1 + (size_t)K * CN_RECORD_FIELDS);
+        blk[0] = (double)ep_count;
+        for (int j = 0; j < K; ++j) {
+            double* rec = blk + 1 + (size_t)j * CN_RECORD_FIELDS;
+            const bool have = j < held;
+            const size_t k = (size_t)L.env * cap + j;
+            rec[0] = (have && io.ep_outcome) ? (double)io.ep_outcome[k] : 0.0;
+            rec[1] = (have && io.ep_steps) ? (double)io.ep_steps[k] : 0.0;
+            rec[2] = (have && io.ep_return) ? io.ep_return[k] : 0.0;
+            rec[3] = (have && io.ep_time) ? io.ep_time[k] : 0.0;
+            rec[4] = (have && io.ep_danger) ? (double)io.ep_danger[k] : 0.0;
+            rec[5] = (have && io.ep_danger_dmin_sum) ? io.ep_danger_dmin_sum[k] : 0.0;
+        }
+    }
+    const bool want = io.summary != nullptr;  // uniform over the launch
+    if (want) {
+        if (robot) {  // this env's sums over its record ring (cn_records_summary's fields)
+            double acc[F] = {};
+            acc[0] = (double)ep_count;
+            acc[1] = (double)held;
+            for (int j = 0; j < held; ++j) {
+                const size_t k = (size_t)L.env * cap + j;
+                const int outcome = io.ep_outcome ? (int)io.ep_outcome[k] : 0;
+                acc[2] += outcome == CN_REACH_GOAL ? 1.0 : 0.0;
+                acc[3] += outcome == CN_COLLISION ? 1.0 : 0.0;
+                acc[4] += outcome == CN_TIMEOUT ? 1.0 : 0.0;
+                acc[5] += (outcome == CN_REACH_GOAL && io.ep_time) ? io.ep_time[k] : 0.0;
+                acc[6] += io.ep_return ? io.ep_return[k] : 0.0;
+                acc[7] += io.ep_danger ? (double)io.ep_danger[k] : 0.0;
+            }
+            const int el = L.ebase / P.A;
+#pragma unroll
+            for (int f = 0; f < F; ++f) scratch[el * F + f] = acc[f];
+        }
+        __syncthreads();
+        if (tid < F) {  // the workgroup's envs in env order
+            double t = 0.0;
+            for (int el = 0; el < P.E; ++el)
+                if ((int)blockIdx.x * P.E + el < P.B) t += scratch[el * F + tid];
+            agent_store(S.wg_partial + (size_t)blockIdx.x * F + tid, t);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's payload has left before the ticket is taken
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(scratch + P.E * F);
+    const int g = blockIdx.x & (kEpilogueGroups - 1);
+    const int members = ((int)gridDim.x - g + kEpilogueGroups - 1) / kEpilogueGroups;  // workgroups b with b % 8 == g
+    if (tid == 0)
+        flag[0] = __hip_atomic_fetch_add(&S.tickets[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(members - 1);
+    __syncthreads();
+    if (!flag[0]) return;
+    // last arrival of group g: the group's sums, members in index order (lane l: members l, l + 64, ..; lanes by a fixed tree)
+    if (want && tid < kWave) {
+        double acc[F] = {};
+        for (int m = tid; m < members; m += kWave) {
+            const double* p = S.wg_partial + (size_t)(g + kEpilogueGroups * m) * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += agent_load(p + f);
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            double v = acc[f];
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (tid == 0) agent_store(S.group_partial + g * F + f, v);
+        }
+    }
+    const int groups = (int)gridDim.x < kEpilogueGroups ? (int)gridDim.x : kEpilogueGroups;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flag[1] = __hip_atomic_fetch_add(&S.tickets[kEpilogueGroups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                  (unsigned)(groups - 1);
+    }
+    __syncthreads();
+    if (!flag[1]) return;
+    // last arrival of all: results out, counters back to zero for the next launch (ordered by the kernel boundary)
+    if (tid < kWave) {
+        unsigned long long t = 0ull;
+        if (tid < kTransShards) {
+            t = __hip_atomic_load(&S.trans_shard[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.trans_shard[tid] = 0ull;
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (tid == 0 && io.transitions && t) *io.transitions += t;
+        if (want && tid < F) {
+            double v = 0.0;
+            for (int gg = 0; gg < groups; ++gg) v += agent_load(S.group_partial + gg * F + tid);
+            io.summary[tid] = v;
+        }
+        if (tid <= kEpilogueGroups) S.tickets[tid] = 0u;
+    }
 }
 
 // Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs
@@ -1178,27 +1320,9 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         io.cur_return[L.env] = cur_return;
         if (io.cur_danger) io.cur_danger[L.env] = cur_danger;
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
-        S.launch_trans[L.env] = transitions;  // no atomic here: see rollout_finish_kernel
+        S.ep_word[L.env] = (ep_count << 2) | state;
     }
-}
-
-// cn_rollout_io.transitions += the transitions of the launch before it on the stream.  One same-address atomic per env at
-// the end of the rollout kernel cost ~10 ns each, serialised: 45 of a 1-step launch's 59 us, 12-15 us of a 20-step launch
-// (4096 envs; profiles/r02_launch_probe_transitions_atomic.txt).  Plain per-env stores + this one-workgroup sum: ~3 us.
-__global__ __launch_bounds__(1024) void rollout_finish_kernel(int B, const uint32_t* launch_trans, const cn_rollout_io* iop) {
-    __shared__ unsigned long long part[16];
-    unsigned long long sum = 0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) sum += launch_trans[b];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long total = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += part[w];
-        uint64_t* dst = iop->transitions;
-        if (dst && total) *dst += total;
-    }
+    rollout_epilogue(P, S, *R.io, L, robot, transitions, ep_count, reinterpret_cast<double*>(s.lines));
 }
 
 }  // namespace cn

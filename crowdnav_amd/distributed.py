@@ -5,8 +5,10 @@ independent of the number of ranks.  The only exchange is ONE all-gather of fixe
 shard boundary (end of Explorer.run_k_episodes, crowd_nav/utils/explorer.py:74-90 needs them on one rank).
 
 A record block is what cn_rollout_records packs per env (include/crowdnav_amd.h): float64 [1 + 6 K] =
-(episodes finished, K x RECORD_FIELDS).  pack_blocks is its host-side restatement (CPU tests, and the reference for the
-GPU test of the kernel)."""
+(episodes finished, K x RECORD_FIELDS).  Record j is RING SLOT j of the env's record ring: its j-th finished episode while
+the env has finished at most record_capacity episodes; once the ring has wrapped, the most recent episode whose ordinal
+is congruent to j.  episodes_in_global_order therefore refuses wrapped blocks (size the rings for the run).
+pack_blocks is its host-side restatement (CPU tests, and the reference for the GPU test of the kernel)."""
 import torch
 import torch.distributed as dist
 
@@ -57,9 +59,14 @@ def gather_blocks(blocks, group=None):
     return out
 
 
-def episodes_in_global_order(records, counts, total_envs):
-    """Flatten gathered records to a list ordered by global episode id c = g + j * total_envs."""
+def episodes_in_global_order(records, counts, total_envs, finished=None):
+    """Flatten gathered records to a list ordered by global episode id c = g + j * total_envs.  finished (optional): the
+    unclamped episode counts, blocks[:, 0]; an env that finished more episodes than its ring holds has overwritten slots,
+    and slot j is then not episode j (include/crowdnav_amd.h: record_capacity) — refused."""
     K = records.shape[1]
+    if finished is not None and bool((finished.to(torch.int64) > counts).any()):
+        raise ValueError('record rings have wrapped (an env finished more episodes than its %d record slots): slot j is no '
+                         'longer episode j; use a larger record_capacity' % int(counts.max()))
     rows = []
     for j in range(K):
         have = counts > j

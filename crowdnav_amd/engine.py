@@ -123,6 +123,11 @@ class BatchedCrowdSim(object):
     def drop_robot_sim(self):
         check(self._lib.cn_drop_robot_sim(self._h))
 
+    def drop_sims(self):
+        """Fresh rvo2 simulators for every agent (cn_drop_sims): the robot's captured radii and every simulator's kd-tree
+        order are forgotten — after teleporting the agents with set_state, when freshly built policies are meant."""
+        check(self._lib.cn_drop_sims(self._h))
+
     def reset(self, seeds, mask=None):
         """np.random.seed(seeds[b]) + scenario generation per env; returns the np.random.random() call counts."""
         host = seeds.cpu().numpy() if torch.is_tensor(seeds) else np.asarray(seeds)
@@ -165,10 +170,13 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_set_gamma(self._h, float(gamma)))
 
     def rollout_begin(self, seed_base, seed_mod, episode_limit=-1, record_capacity=8, env_offset=0,
-                      env_stride=None):
+                      env_stride=None, boundary_records=0):
         """Start Explorer-style episode bookkeeping: env b runs global episodes b, b+B, b+2B, ... (< limit),
         episode c seeded with seed_base + c % seed_mod.  A shard of a larger job passes its first global env
-        id as env_offset and the global env count as env_stride."""
+        id as env_offset and the global env count as env_stride.
+        boundary_records = K > 0: every rollout launch also leaves the shard-boundary outputs itself (its last workgroup):
+        bufs['summary'] float64 [8] (what records_summary() returns for this engine) and bufs['blocks'] float64
+        [B, 1 + 6 K] (what rollout_records(K) returns) — no boundary kernels on a single GPU, only the all-gather on many."""
         B, K = self.B, int(record_capacity)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
         bufs = dict(
@@ -178,11 +186,19 @@ class BatchedCrowdSim(object):
             ep_count=z((B,), torch.int32), cur_steps=z((B,), torch.int32), cur_return=z((B,), torch.float64),
             cur_danger=z((B,), torch.int32), cur_danger_dmin_sum=z((B,), torch.float64),
             active=z((B,), torch.uint8), transitions=z((1,), torch.int64))
+        Kb = int(boundary_records)
+        if Kb > 0:
+            bufs['summary'] = z((_lib.SUMMARY_FIELDS,), torch.float64)
+            bufs['blocks'] = z((B, 1 + Kb * _lib.RECORD_FIELDS), torch.float64)
         io = CnRolloutIo(seed_base=int(seed_base), seed_mod=int(seed_mod), episode_limit=int(episode_limit),
                          env_offset=int(env_offset), env_stride=int(B if env_stride is None else env_stride),
-                         record_capacity=K, **{k: v.data_ptr() for k, v in bufs.items()})
-        self._rollout = (io, bufs)
+                         record_capacity=K, blocks_records=Kb, **{k: v.data_ptr() for k, v in bufs.items()})
+        # the previous rollout's buffers stay referenced until cn_rollout_begin has returned: with the asynchronous scenario
+        # fill, kernels of the old rollout may still be reading them on the engine's side streams (the call waits for them)
+        previous = self._rollout
         check(self._lib.cn_rollout_begin(self._h, C.byref(io)))
+        self._rollout = (io, bufs)
+        del previous
         return bufs
 
     def rollout(self, n_steps):

@@ -118,8 +118,16 @@ int cn_get_theta(cn_engine* e, double* theta);
  * humans: two circle-crossing, the rest square-crossing).  The engine keeps num_humans slots per env; absent humans are
  * parked at rest at x >= 1e6, out of every neighbour range, and sit AFTER the present ones in cn_get_state / obs. */
 int cn_get_human_count(cn_engine* e, int32_t* count);
-/* forget the robot ORCA policy's captured radii (a new policy object; orca.py:95-104) */
+/* forget the robot ORCA policy's captured radii and its rvo2 simulator's kd-tree order (a new policy object;
+ * orca.py:95-104) */
 int cn_drop_robot_sim(cn_engine* e);
+/* (ABI v5) forget EVERY agent's rvo2 simulator — the robot's as above and each human's (a human's ORCA policy object and
+ * its simulator are rebuilt with the Human at every CrowdSim.reset, crowd_sim.py:155-207; cn_reset and the rollout's
+ * auto-reset do this themselves).  What a simulator carries from step to step besides the radii is the permutation its
+ * kd-tree partitions in place (RVO2 KdTree::buildAgentTree; only simulators of more than 10 agents ever split): it decides
+ * the visiting order of candidates at EXACTLY equal squared distance.  For a caller that teleports the agents with
+ * cn_set_state and wants the behaviour of freshly built simulators. */
+int cn_drop_sims(cn_engine* e);
 /* The opposite: give every env the SAME captured simulator — radii host float32 [num_humans + 1] (robot, humans) as
  * the robot's rvo2 simulator holds them (radius + 0.01 + safety_space), max_speed its maxSpeed.  This is what one
  * persistent ORCA policy object means for a batch: the reference builds the simulator at the policy's first predict and
@@ -160,7 +168,9 @@ typedef struct cn_rollout_io {
     int64_t episode_limit; /* <0: unbounded */
     int64_t env_offset;
     int64_t env_stride;    /* >= env_offset + B */
-    int32_t record_capacity; /* records kept per env (ring; older ones are overwritten) */
+    int32_t record_capacity; /* records kept per env: a RING — episode j of the env lands in slot j % record_capacity, so
+                                once an env has finished more than record_capacity episodes slot j holds its most recent
+                                episode with ordinal congruent to j (older ones are overwritten) */
     /* per-episode records, [B][record_capacity]; all optional */
     uint8_t* ep_outcome;   /* CN_REACH_GOAL / CN_COLLISION / CN_TIMEOUT */
     int32_t* ep_steps;
@@ -176,6 +186,12 @@ typedef struct cn_rollout_io {
     double* cur_danger_dmin_sum;
     uint8_t* active;       /* 0 once env b ran out of episodes (c >= episode_limit) */
     uint64_t* transitions; /* [1] device counter: += number of step() transitions executed */
+    /* (ABI v5) shard-boundary outputs produced by the LAST workgroup of every cn_rollout / cn_rollout_step launch itself
+     * (arrival tickets, fixed summation order: bitwise reproducible), so that a single-GPU run needs no boundary kernel
+     * and a sharded run only its all-gather.  Both optional (NULL = off): */
+    double* summary;       /* [CN_SUMMARY_FIELDS] the numbers of cn_records_summary over THIS engine's record rings */
+    double* blocks;        /* [B][CN_RECORD_BLOCK_DOUBLES(blocks_records)] what cn_rollout_records(blocks_records) packs */
+    int32_t blocks_records; /* >= 1 when blocks != NULL */
 } cn_rollout_io;
 
 /* discount table used for ep_return: gamma^(t * time_step * robot_v_pref), computed on the host with libm
@@ -289,7 +305,9 @@ int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action)
 #define CN_RECORD_BLOCK_DOUBLES(K) (1 + (K) * CN_RECORD_FIELDS)
 /* pack the record rings of io into ONE self-contained float64 block per env: blocks double
  * [B][CN_RECORD_BLOCK_DOUBLES(max_records)]; block b = { number of episodes env b has finished (unclamped), then record j
- * = its j-th finished episode for j < min(count, record_capacity, max_records), zeros beyond }.  One kernel. */
+ * = ring slot j for j < min(count, record_capacity, max_records), zeros beyond }.  Slot j is the env's j-th finished episode
+ * while count <= record_capacity; after the ring has wrapped it is the most recent episode with ordinal = j mod
+ * record_capacity (size the rings for the episodes a run can finish when per-episode identities matter).  One kernel. */
 int cn_rollout_records(cn_engine* e, const cn_rollout_io* io, int max_records, double* blocks);
 /* all-gather such blocks over the ranks of an RCCL communicator (rccl_comm = the caller's ncclComm_t, one rank per GPU;
  * librccl.so.1 is bound at first use): blocks_all double [n_ranks * B][CN_RECORD_BLOCK_DOUBLES(max_records)], rank-major

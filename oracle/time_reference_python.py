@@ -1,0 +1,65 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Times the UNMODIFIED reference's own CPU path — the loop of crowd_nav/test.py:86-92 / explorer.py:41-48
+(`ob = env.reset('test', i); while not done: action = robot.act(ob); ob, _, done, info = env.step(action)`) with the ORCA
+robot policy, Python CrowdSim + the `rvo2` module (here: the float32 restatement, oracle/rvo2_pymodule.cpp — upstream
+Python-RVO2 is not installable offline) — on ONE core of the machine this runs on, and writes the result to
+profiles/r03_reference_python.json.  /root/reference does not exist on the GPU box, so this number cannot be re-timed
+there: bench.py embeds the committed file in `cpu_baseline.reference_python`, labelled with the host it was measured on.
+
+    make -C oracle && PYTHONDONTWRITEBYTECODE=1 python oracle/time_reference_python.py
+"""
+import json
+import os
+import platform
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or 'unknown'
+
+
+def run(robot_visible, cases, human_num=5):
+    env, robot, _ = ref_harness.make_env(robot_visible=robot_visible, human_num=human_num)
+    steps = 0
+    t0 = time.perf_counter()
+    for i in range(cases):
+        ob = env.reset('test', i)
+        done = False
+        while not done:
+            action = robot.act(ob)
+            ob, _, done, info = env.step(action)
+            steps += 1
+    return steps, time.perf_counter() - t0
+
+
+def main():
+    assert ref_harness.available(), 'needs /root/reference and `make -C oracle`'
+    out = {'what': "unmodified reference loop (env.reset('test', i); robot.act; env.step), ORCA robot, 5 humans, "
+                   "circle_crossing, one process, one core",
+           'host_cpu': cpu_model(), 'cores': 1, 'unit': 'env-steps/s', 'runs': []}
+    for visible in (False, True):
+        run(visible, 3)  # imports, first-call costs
+        steps, dt = run(visible, 60)
+        out['runs'].append({'robot_visible': visible, 'test_cases': 60, 'env_steps': steps, 'seconds': dt,
+                            'env_steps_per_s': steps / dt})
+    out['value'] = min(r['env_steps_per_s'] for r in out['runs'])
+    out['value_visible_robot'] = out['runs'][1]['env_steps_per_s']
+    path = os.path.join(os.path.dirname(HERE), 'profiles', 'r03_reference_python.json')
+    json.dump(out, open(path, 'w'), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
