@@ -266,10 +266,9 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) ||
-        (rc = dev_alloc(e, &S.trans_shard, (size_t)cn::kTransShards)) ||
-        (rc = dev_alloc(e, &S.wg_partial, (size_t)P.B * CN_SUMMARY_FIELDS)) ||
-        (rc = dev_alloc(e, &S.group_partial, (size_t)cn::kEpilogueGroups * CN_SUMMARY_FIELDS)) ||
-        (rc = dev_alloc(e, &S.tickets, (size_t)cn::kEpilogueGroups + 1)) ||
+        (rc = dev_alloc(e, &S.wg_partial, (size_t)P.B * (CN_SUMMARY_FIELDS + 1))) ||
+        (rc = dev_alloc(e, &S.group_partial, (size_t)cn::kEpilogueGroups * (CN_SUMMARY_FIELDS + 1))) ||
+        (rc = dev_alloc(e, &S.tickets, (size_t)(cn::kEpilogueGroups + 1) * cn::kTicketStride)) ||
         (rc = dev_alloc(e, &e->io_dev, (size_t)1)) || (rc = dev_alloc(e, &e->C.error, (size_t)1)) ||
         (rc = dev_alloc(e, &e->S_dev, (size_t)1))) {
         cn_destroy(e);

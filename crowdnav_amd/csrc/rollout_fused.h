@@ -28,8 +28,22 @@ struct EpisodeRegs {  // replicated on every agent lane of the env
     int state, ep_count, ring_filled;
 };
 
+// A wave-uniform value pinned in vector registers.  The eight float64 parameters of the step (dt, time limit, rewards,
+// discomfort distance / factor, safety space) arrive as kernel arguments in SGPRs; with ~100 SGPRs live in the step loop the
+// register allocator spilled that 16-dword block into VGPR lanes and re-read it with v_readlane five times per step (107
+// v_readlane of the loop's ~1 450 instructions: every one a VALU issue slot).  As VALU operands they are needed in VGPRs
+// anyway; the empty asm makes the copy explicit and opaque, so the values stay there (16 VGPRs; the kernel has room up to 168).
+// (CN_EXP_SGPR_PARAMS: the A/B build that leaves them where the compiler puts them.)
+template <typename T>
+__device__ __forceinline__ T in_vgpr(T x) {
+#ifndef CN_EXP_SGPR_PARAMS
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
 __device__ __forceinline__ void stage_agent(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
-                                            float robot_max_speed, bool solve) {
+                                            float robot_max_speed, bool solve, double human_safety) {
     if (L.lane >= P.nA) return;
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     const double gdx = r.gx - r.px, gdy = r.gy - r.py;
@@ -40,7 +54,7 @@ __device__ __forceinline__ void stage_agent(const Params& P, const Smem& s, cons
     s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
     s.posd[L.lane] = make_double2(r.px, r.py);
     s.rad[L.lane] = r.rad;
-    s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
+    s.hview[L.lane] = (float)(r.rad + 0.01 + human_safety);
     s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
     float sx, sy;  // linearProgram2's start point (Appendix A.4): a function of the preferred velocity only
     lp_start_point(max_speed, pref_x, pref_y, sx, sy);
@@ -120,7 +134,11 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
         }
         my_slot = (int)((row_slots >> (8 * c)) & 0xffull);
     }
-    stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca));
+    const double c_dt = in_vgpr(P.dt), c_limit = in_vgpr(P.time_limit), c_limit1 = in_vgpr(P.time_limit - 1.0);
+    const double c_success = in_vgpr(P.success_reward), c_collision = in_vgpr(P.collision_penalty);
+    const double c_ddist = in_vgpr(P.discomfort_dist), c_dfactor = in_vgpr(P.discomfort_factor);
+    const double c_hsafety = in_vgpr(P.human_safety);
+    stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca), c_hsafety);
     __syncthreads();
 
 #ifdef CN_PHASE_TIMING
@@ -266,14 +284,14 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             const double2 rp = s.posd[L.ebase];
             const double x1 = r.px - rp.x, y1 = r.py - rp.y;
             const double wx = r.vx - act_x, wy = r.vy - act_y;
-            const double x2 = x1 + wx * P.dt, y2 = y1 + wy * P.dt;
+            const double x2 = x1 + wx * c_dt, y2 = y1 + wy * c_dt;
             const double sx = x2 - x1, sy = y2 - y1;
             double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
             u = (u > 1.0) ? 1.0 : ((u < 0.0) ? 0.0 : u);
             const bool degenerate = (sx == 0.0 && sy == 0.0);  // utils.py:11-13
             const double cx = degenerate ? 0.0 - x1 : (x1 + u * sx) - 0.0;
             const double cy = degenerate ? 0.0 - y1 : (y1 + u * sy) - 0.0;
-            const double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+            const double endx = r.px + new_vx * c_dt, endy = r.py + new_vy * c_dt;
             const double d = norm2(human ? cx : endx - r.gx, human ? cy : endy - r.gy);
             s.closest[L.lane] = human ? d - r.rad - s.rad[L.ebase] : d;
         }
@@ -297,18 +315,18 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             }
             // crowd_sim.py:364-389 as a priority chain of selects (timeout > collision > goal > danger > nothing): the
             // same values as the if / elif ladder without its nested branches
-            const bool timeout = ep.gtime >= P.time_limit - 1.0;
+            const bool timeout = ep.gtime >= c_limit1;
             const bool reaching = goal_dist < robot_rad;
-            const bool danger = dmin < P.discomfort_dist;
-            double reward = danger ? (dmin - P.discomfort_dist) * P.discomfort_factor * P.dt : 0.0;
+            const bool danger = dmin < c_ddist;
+            double reward = danger ? (dmin - c_ddist) * c_dfactor * c_dt : 0.0;
             int info = danger ? CN_DANGER : CN_NOTHING;
-            reward = reaching ? P.success_reward : reward, info = reaching ? CN_REACH_GOAL : info;
-            reward = collision ? P.collision_penalty : reward, info = collision ? CN_COLLISION : info;
+            reward = reaching ? c_success : reward, info = reaching ? CN_REACH_GOAL : info;
+            reward = collision ? c_collision : reward, info = collision ? CN_COLLISION : info;
             reward = timeout ? 0.0 : reward, info = timeout ? CN_TIMEOUT : info;
             const bool done = timeout | collision | reaching;
-            ep.gtime += P.dt;
-            r.px = r.px + new_vx * P.dt;  // Agent.step (agent.py:127-135)
-            r.py = r.py + new_vy * P.dt;
+            ep.gtime += c_dt;
+            r.px = r.px + new_vx * c_dt;  // Agent.step (agent.py:127-135)
+            r.py = r.py + new_vy * c_dt;
             r.vx = new_vx;
             r.vy = new_vy;
             // return / danger accumulators: every lane of the env carries them (only the robot lane's copy is written out)
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                         if (io.ep_outcome) io.ep_outcome[k] = (uint8_t)info;
                         if (io.ep_steps) io.ep_steps[k] = cur_steps;
                         if (io.ep_return) io.ep_return[k] = cur_return;
-                        if (io.ep_time) io.ep_time[k] = (info == CN_TIMEOUT) ? P.time_limit : ep.gtime;
+                        if (io.ep_time) io.ep_time[k] = (info == CN_TIMEOUT) ? c_limit : ep.gtime;
                         if (io.ep_danger) io.ep_danger[k] = cur_danger;
                         if (io.ep_danger_dmin_sum) io.ep_danger_dmin_sum[k] = cur_dsum;
                     }
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 }
             }
         }
-        stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca));
+        stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca), c_hsafety);
         __syncthreads();
         CN_TICK(clk, 7);
     }

@@ -69,14 +69,14 @@ struct StateView {
     int* ep_word;           // [B] (episodes finished << 2) | io.active state, ONE word stored by the rollout kernels next to the
                             // two io arrays: the asynchronous fill reads it for a consistent (state, ep_count) snapshot
     // launch epilogue of the rollout kernels (rollout_epilogue): arrival tickets and partial sums
-    unsigned long long* trans_shard;  // [kTransShards] transitions of the running launch, sharded by workgroup index
-    double* wg_partial;     // [workgroups][CN_SUMMARY_FIELDS] per-workgroup sums over its envs' record rings
-    double* group_partial;  // [kEpilogueGroups][CN_SUMMARY_FIELDS]
-    unsigned* tickets;      // [kEpilogueGroups + 1] arrivals per group, then of the group leaders; zero between launches
+    double* wg_partial;     // [workgroups][CN_SUMMARY_FIELDS + 1] per-workgroup sums over its envs' record rings, its transitions
+    double* group_partial;  // [kEpilogueGroups][CN_SUMMARY_FIELDS + 1]
+    unsigned* tickets;      // [(kEpilogueGroups + 1) * kTicketStride] arrivals per group, then of the group leaders, one
+                            // counter per 256-byte line; zero between launches
 };
 
-constexpr int kTransShards = 64;
-constexpr int kEpilogueGroups = 8;  // workgroup b arrives at counter b % 8 (= its XCD under the observed placement)
+constexpr int kEpilogueGroups = 32;  // workgroup b arrives at counter b % 32: 64 arrivals per counter at 2048 workgroups
+constexpr int kTicketStride = 64;    // counters 256 bytes apart: same-line atomics serialise at ~10 ns each
 
 struct StepIo {
     const double* action;
@@ -1076,10 +1076,11 @@ __device__ __forceinline__ int finish_episode(const Params& P, const StateView& 
 // Behind every rollout launch there used to be three more kernels on the stream: rollout_finish_kernel (the transitions
 // counter), records_pack_kernel (the shard's record blocks) and records_summary_kernel (explorer.py:74-90) — 18 us of
 // kernels plus their boundaries behind a 106 us launch in the driver's 20-step shape.  They are the tail of the rollout
-// kernel now: every workgroup leaves its share (transitions into a sharded counter, its envs' record blocks, the sums over
-// its envs' record rings), takes an arrival ticket of its group (workgroup b -> counter b % 8: 256 arrivals per counter at
-// 2048 workgroups, ~12 ns each, spread over the time the workgroups finish), the last arrival of a group adds the group's
-// partial sums in workgroup order and arrives at the top counter, and the last of those writes the results.  The summation
+// kernel now: every workgroup leaves its share (its envs' record blocks; the sums over its envs' record rings and its
+// transitions as one partial record), takes an arrival ticket of its group (workgroup b -> counter b % 32: 64 arrivals per counter at
+// 2048 workgroups; every counter on its own 256-byte line — nine counters in ONE line serialised all 2048 arrivals of a
+// 1-step launch: 35 us instead of 17), the last arrival of a group adds the group's partial sums in workgroup order and
+// arrives at the top counter, and the last of those writes the results.  The summation
 // order is a function of the workgroup indices only, never of the arrival order: the same bits on every run.
 // Hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility): payload as 8-byte agent-scope atomic
 // stores (write-through), s_waitcnt vmcnt(0), then the ticket (agent-scope RMW); the reader loads the payload with
@@ -1093,14 +1094,12 @@ __device__ __forceinline__ double agent_load(const double* p) {
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// scratch: LDS, at least (E * CN_SUMMARY_FIELDS + 1) doubles, free after the last barrier of the step loop.
+// scratch: LDS, at least (E * (CN_SUMMARY_FIELDS + 1) + 1) doubles, free after the last barrier of the step loop.
 // Called by every thread of the workgroup (contains barriers); `transitions` / `ep_count` are read on the robot lanes.
 __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateView& S, const cn_rollout_io& io, const Lane& L,
                                                  bool robot, unsigned int transitions, int ep_count, double* scratch) {
-    constexpr int F = CN_SUMMARY_FIELDS;
+    constexpr int F = CN_SUMMARY_FIELDS + 1;  // the eight sums + this launch's transitions (exact in a double)
     const int tid = threadIdx.x;
-    if (robot && transitions)
-        atomicAdd(&S.trans_shard[blockIdx.x & (kTransShards - 1)], (unsigned long long)transitions);  // no return value
     const int cap = io.record_capacity;
     const int held = ep_count < cap ? ep_count : cap;
     if (robot && io.blocks) {  // cn_rollout_records' block of this env
@@ -1120,9 +1119,10 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
         }
     }
     const bool want = io.summary != nullptr;  // uniform over the launch
-    if (want) {
-        if (robot) {  // this env's sums over its record ring (cn_records_summary's fields)
-            double acc[F] = {};
+    if (robot) {  // this env's sums over its record ring (cn_records_summary's fields) + its transitions
+        double acc[F] = {};
+        acc[F - 1] = (double)transitions;
+        if (want) {
             acc[0] = (double)ep_count;
             acc[1] = (double)held;
             for (int j = 0; j < held; ++j) {
@@ -1135,68 +1135,67 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
                 acc[6] += io.ep_return ? io.ep_return[k] : 0.0;
                 acc[7] += io.ep_danger ? (double)io.ep_danger[k] : 0.0;
             }
-            const int el = L.ebase / P.A;
+        }
+        const int el = L.ebase / P.A;
 #pragma unroll
-            for (int f = 0; f < F; ++f) scratch[el * F + f] = acc[f];
-        }
-        __syncthreads();
-        if (tid < F) {  // the workgroup's envs in env order
-            double t = 0.0;
-            for (int el = 0; el < P.E; ++el)
-                if ((int)blockIdx.x * P.E + el < P.B) t += scratch[el * F + tid];
-            agent_store(S.wg_partial + (size_t)blockIdx.x * F + tid, t);
-        }
+        for (int f = 0; f < F; ++f) scratch[el * F + f] = acc[f];
+    }
+    __syncthreads();
+    const int f0 = want ? 0 : F - 1;  // without a summary only the transitions travel
+    if (tid >= f0 && tid < F) {  // the workgroup's envs in env order
+        double t = 0.0;
+        for (int el = 0; el < P.E; ++el)
+            if ((int)blockIdx.x * P.E + el < P.B) t += scratch[el * F + tid];
+        agent_store(S.wg_partial + (size_t)blockIdx.x * F + tid, t);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's payload has left before the ticket is taken
     __syncthreads();
     int* const flag = reinterpret_cast<int*>(scratch + P.E * F);
-    const int g = blockIdx.x & (kEpilogueGroups - 1);
-    const int members = ((int)gridDim.x - g + kEpilogueGroups - 1) / kEpilogueGroups;  // workgroups b with b % 8 == g
+    const int n_wg = (int)gridDim.x;
+    const int g = blockIdx.x % kEpilogueGroups;
+    const int members = (n_wg - g + kEpilogueGroups - 1) / kEpilogueGroups;  // workgroups b with b % groups == g
     if (tid == 0)
-        flag[0] = __hip_atomic_fetch_add(&S.tickets[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(members - 1);
+        flag[0] = __hip_atomic_fetch_add(&S.tickets[g * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                  (unsigned)(members - 1);
     __syncthreads();
     if (!flag[0]) return;
     // last arrival of group g: the group's sums, members in index order (lane l: members l, l + 64, ..; lanes by a fixed tree)
-    if (want && tid < kWave) {
+    if (tid < kWave) {
         double acc[F] = {};
         for (int m = tid; m < members; m += kWave) {
             const double* p = S.wg_partial + (size_t)(g + kEpilogueGroups * m) * F;
 #pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] += agent_load(p + f);
+            for (int f = 0; f < F; ++f)
+                if (f >= f0) acc[f] += agent_load(p + f);
         }
 #pragma unroll
         for (int f = 0; f < F; ++f) {
+            if (f < f0) continue;
             double v = acc[f];
 #pragma unroll
             for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (tid == 0) agent_store(S.group_partial + g * F + f, v);
         }
     }
-    const int groups = (int)gridDim.x < kEpilogueGroups ? (int)gridDim.x : kEpilogueGroups;
+    const int groups = n_wg < kEpilogueGroups ? n_wg : kEpilogueGroups;
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        flag[1] = __hip_atomic_fetch_add(&S.tickets[kEpilogueGroups], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                  (unsigned)(groups - 1);
+        flag[1] = __hip_atomic_fetch_add(&S.tickets[kEpilogueGroups * kTicketStride], 1u, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(groups - 1);
     }
     __syncthreads();
     if (!flag[1]) return;
     // last arrival of all: results out, counters back to zero for the next launch (ordered by the kernel boundary)
-    if (tid < kWave) {
-        unsigned long long t = 0ull;
-        if (tid < kTransShards) {
-            t = __hip_atomic_load(&S.trans_shard[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            S.trans_shard[tid] = 0ull;
-        }
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_down(t, off);
-        if (tid == 0 && io.transitions && t) *io.transitions += t;
-        if (want && tid < F) {
-            double v = 0.0;
-            for (int gg = 0; gg < groups; ++gg) v += agent_load(S.group_partial + gg * F + tid);
+    if (tid >= f0 && tid < F) {
+        double v = 0.0;
+        for (int gg = 0; gg < groups; ++gg) v += agent_load(S.group_partial + gg * F + tid);
+        if (tid < F - 1) {
             io.summary[tid] = v;
+        } else if (io.transitions && v != 0.0) {
+            *io.transitions += (uint64_t)v;
         }
-        if (tid <= kEpilogueGroups) S.tickets[tid] = 0u;
     }
+    if (tid <= kEpilogueGroups) S.tickets[tid * kTicketStride] = 0u;
 }
 
 // Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs

@@ -1,7 +1,7 @@
 """Per-phase shader-clock breakdown of the fused rollout (profiling build only).
 
-    hipcc ... -DCN_PHASE_TIMING crowdnav_amd.hip -o crowdnav_amd/lib/exp/lib_timing.so
-    CROWDNAV_AMD_LIB=crowdnav_amd/lib/exp/lib_timing.so python scripts/phase_probe.py [--humans 5] [--envs 4096]
+    make -C crowdnav_amd/csrc exp NAME=timing DEFS=-DCN_PHASE_TIMING
+    CROWDNAV_AMD_LIB=build/exp/lib_timing.so python scripts/phase_probe.py [--humans 5] [--envs 4096]
 """
 import argparse
 import ctypes as C

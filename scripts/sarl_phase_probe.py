@@ -1,6 +1,6 @@
 """Per-layer shader-clock breakdown of sarl_mlp_kernel (profiling build, -DCN_PHASE_TIMING).
 
-    CROWDNAV_AMD_LIB=crowdnav_amd/lib/exp/lib_timing.so python scripts/sarl_phase_probe.py
+    CROWDNAV_AMD_LIB=build/exp/lib_timing.so python scripts/sarl_phase_probe.py
 """
 import ctypes as C
 import os

@@ -1,7 +1,7 @@
 """Per-layer shader-clock breakdown of sarl_reg_kernel (profiling build, -DCN_PHASE_TIMING): ticks per tile as wave 0 of every
 workgroup sees them, against the issue time of the layer's MFMAs (32 cycles each, one wave per SIMD).
 
-    CROWDNAV_AMD_LIB=crowdnav_amd/lib/exp/lib_timing.so python scripts/sarl_reg_probe.py
+    CROWDNAV_AMD_LIB=build/exp/lib_timing.so python scripts/sarl_reg_probe.py
 """
 import ctypes as C
 import os
