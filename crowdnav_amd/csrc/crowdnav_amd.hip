@@ -210,7 +210,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
     P.ring_depth = env_int("CROWDNAV_AMD_RING_DEPTH", 48);
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
-    e->smem = cn::smem_bytes(P.nA, P.pairs, e->maxl);
+    P.kd = P.A > cn::kKdLeaf ? 1 : 0;  // a simulator of more than 10 agents splits its kd-tree: visiting order matters at ties
+    e->smem = cn::smem_bytes(P.nA, P.pairs, e->maxl, P.A, P.E);
     e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", 0) != 0;
     e->gen_wave = env_int("CROWDNAV_AMD_WAVE_SCENARIOS", c->num_humans > 8 ? 1 : 0) != 0;
     P.robot_visible = c->robot_visible ? 1 : 0;
@@ -266,6 +267,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &S.kd_order, P.kd ? n * cn::kd_row_bytes(P.A) : (size_t)4)) ||
+        (rc = dev_alloc(e, &S.kd_valid, P.kd ? n : (size_t)4)) ||
         (rc = dev_alloc(e, &S.wg_partial, (size_t)P.B * (CN_SUMMARY_FIELDS + 1))) ||
         (rc = dev_alloc(e, &S.group_partial, (size_t)cn::kEpilogueGroups * (CN_SUMMARY_FIELDS + 1))) ||
         (rc = dev_alloc(e, &S.tickets, (size_t)(cn::kEpilogueGroups + 1) * cn::kTicketStride)) ||
@@ -454,12 +457,15 @@ int cn_drop_robot_sim(cn_engine* e) {
     int rc = bind(e);
     if (rc) return rc;
     CN_HIP(hipMemsetAsync(e->S.rsim_valid, 0, (size_t)e->P.B, e->stream));
+    if (e->P.kd)  // ... and its simulator's kd-tree order: byte 0 of every env's A flags
+        CN_HIP(hipMemset2DAsync(e->S.kd_valid, (size_t)e->P.A, 0, 1, (size_t)e->P.B, e->stream));
     return CN_OK;
 }
 
 int cn_drop_sims(cn_engine* e) {
     int rc = cn_drop_robot_sim(e);
     if (rc) return rc;
+    if (e->P.kd) CN_HIP(hipMemsetAsync(e->S.kd_valid, 0, (size_t)e->P.B * e->P.A, e->stream));
     return CN_OK;
 }
 

@@ -20,6 +20,7 @@
 
 #include "../../include/crowdnav_amd.h"
 #include "orca_device.h"
+#include "kd_order.h"
 #include "scenario_device.h"
 #include "scenario_wave.h"
 
@@ -38,6 +39,7 @@ struct Params {
     int robot_visible, robot_orca;
     int robot_unicycle;  // external robot actions are ActionRot(v, r) (agent.py:115-135)
     int async_fill;      // CN_FLAG_ASYNC_SCENARIO_FILL: ring slots are published one by one (StateView::ring_ready)
+    int kd;              // A > 10: some rvo2 simulator of an env holds more than 10 agents and splits its kd-tree (kd_order.h)
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double robot_safety, human_safety;
     OrcaParams orca;
@@ -66,6 +68,8 @@ struct StateView {
     int* ring_filled_out;   // [B] (written by the fill kernel; the host swaps the two)
     int* ring_ready;        // [B*D] async fill: ordinal + 1 of the scenario a slot holds, stored with release once it is complete
     int* ring_claim;        // [B*D] async fill: ordinal + 1 some fill launch is generating (or has generated) for the slot
+    uint8_t* kd_order;      // [B*A][kd_row_bytes(A)] the permutation each agent's rvo2 simulator partitions in place (kd_order.h)
+    uint8_t* kd_valid;      // [B*A] 0 = a freshly built simulator (identity order)
     int* ep_word;           // [B] (episodes finished << 2) | io.active state, ONE word stored by the rollout kernels next to the
                             // two io arrays: the asynchronous fill reads it for a consistent (state, ep_count) snapshot
     // launch epilogue of the rollout kernels (rollout_epilogue): arrival tickets and partial sums
@@ -111,6 +115,7 @@ struct Smem {
     float4* res;      // [nA] ... and output: (result.x, result.y, first infeasible line or n, -)
     int* todo;        // [nA + 1] agents that need the 3-D fallback, compacted; [nA] = how many
     double* disc;     // [kMaxDiscount] discount table gamma^(t dt v_pref) (rollout kernel only)
+    KdSmem kd;        // kd-tree visiting order of simulators with more than 10 agents (Params::kd)
 };
 
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
@@ -133,9 +138,9 @@ __host__ __device__ inline size_t proj_bytes(int nA, int maxl) {
 
 // maxl: the candidate-form buffers (cand2, cand3) exist for the 5-half-plane kernels only — at 21 agents per env they
 // would cost the 10-half-plane kernels a resident workgroup per CU
-__host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl) {
+__host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl, int A = 0, int E = 1) {
     return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 3 : 1) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + proj_bytes(nA, maxl) +
-           (size_t)pairs * 8 + 64 + 8 + 16 + 16 + sizeof(double) * kMaxDiscount;
+           (size_t)pairs * 8 + 64 + 8 + 16 + 16 + sizeof(double) * kMaxDiscount + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
 }
 
 template <int MAXL>
@@ -167,6 +172,12 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
     s.pinfo = reinterpret_cast<int*>(p), p += 4 * P.pairs;
     s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
+    s.kd = KdSmem{};
+    if (P.kd) {
+        char* q = reinterpret_cast<char*>(s.disc + kMaxDiscount);
+        q += (16 - (reinterpret_cast<size_t>(q) & 15)) & 15;
+        s.kd = kd_carve(q, nA, P.A, P.E);
+    }
     return s;
 }
 
@@ -244,6 +255,191 @@ __device__ __forceinline__ void load_robot_view(const Params& P, const StateView
         } else {
             robot_max_speed = (float)r.vpref;
             S.rsim_max_speed[L.env] = robot_max_speed;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- kd-tree order (kd_order.h)
+// A launch keeps the permutations of its envs' simulators in LDS: loaded here (or built fresh), stored by kd_store.
+__device__ __forceinline__ void kd_load(const Params& P, const StateView& S, const Smem& s, const Lane& L) {
+    if (!P.kd) return;
+    const KdSmem& k = s.kd;
+    if (L.lane < P.nA) {
+        uint8_t* row = k.ord + (size_t)L.lane * k.row;
+        if (L.valid && S.kd_valid[L.gi] != 0) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(S.kd_order + L.gi * k.row);
+            for (int w = 0; w < k.row / 4; ++w) reinterpret_cast<uint32_t*>(row)[w] = src[w];
+        } else {
+            kd_identity_row(row, k.row, P.A, L.a, P.robot_visible);
+        }
+    }
+    if (threadIdx.x == 0) *k.gen = 0;
+    for (int i = threadIdx.x; i < P.E * 2 * 2; i += blockDim.x) k.count[i] = 0;  // no "last step's tree" yet
+}
+
+__device__ __forceinline__ void kd_store(const Params& P, const StateView& S, const Smem& s, const Lane& L) {
+    if (!P.kd || !L.valid) return;
+    const KdSmem& k = s.kd;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(k.ord + (size_t)L.lane * k.row);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(S.kd_order + L.gi * k.row);
+    for (int w = 0; w < k.row / 4; ++w) dst[w] = row[w];
+    S.kd_valid[L.gi] = 1;
+}
+
+// A new episode: every Human is rebuilt and with it its ORCA policy and simulator (crowd_sim.py:155-207); the robot's
+// policy object, hence its simulator, lives on.  Called by the lanes of an env that has just loaded its next scenario.
+__device__ __forceinline__ void kd_new_episode(const Params& P, const Smem& s, const Lane& L) {
+    if (!P.kd) return;
+    const KdSmem& k = s.kd;
+    if (L.a > 0) kd_identity_row(k.ord + (size_t)L.lane * k.row, k.row, P.A, L.a, P.robot_visible);
+    if (L.a == 0) {  // nothing of this env's previous tree says anything about the fresh rows
+        const int prev = *k.gen ^ 1, el = L.ebase / P.A;
+        k.count[(prev * P.E + el) * 2 + 0] = 0;
+        k.count[(prev * P.E + el) * 2 + 1] = 0;
+    }
+}
+
+// The tree(s) of every env of the workgroup from this step's float32 positions (s.kin), breadth first on agent sets: the
+// nodes that split, in `generation` g of the node lists.  All threads (barriers inside).
+__device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, const Lane& L, int g) {
+    const KdSmem& k = s.kd;
+    const int tid = threadIdx.x;
+    const bool agent = L.lane < P.nA;
+    const int el = agent ? L.ebase / P.A : 0;
+    const float4 me = agent ? s.kin[L.lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t kx = kd_key(me.x), ky = kd_key(me.y);
+    const uint64_t amask = P.A >= 64 ? ~0ull : ((1ull << P.A) - 1ull);
+    for (int t = 0; t < 2; ++t) {
+        KdNode* list = k.nodes + ((size_t)(g * P.E + el) * 2 + t) * k.mn;
+        int* cnt = k.count + (g * P.E + el) * 2 + t;
+        if (!kd_tree_on(P.A, t, P.robot_visible)) {  // uniform
+            if (agent && L.a == 0) *cnt = 0;
+            continue;
+        }
+        for (int i = tid; i < P.E * k.mn; i += blockDim.x) {
+            k.bb[4 * i + 0] = 0xffffffffu, k.bb[4 * i + 1] = 0u, k.bb[4 * i + 2] = 0xffffffffu, k.bb[4 * i + 3] = 0u;
+        }
+        if (agent && L.a == 0) {  // the env's robot lane keeps the books (whether or not the robot is in this tree)
+            list[0].meta = (uint32_t)kd_tree_size(P.A, t) << 8;
+            list[0].left = t == 0 ? amask : (amask & ~1ull);
+            *cnt = 1;
+        }
+        __syncthreads();
+        for (int r = 0;; ++r) {
+            const int c = agent ? *cnt : 0;
+            const bool live = agent && r < c;
+            if (!__syncthreads_or(live ? 1 : 0)) break;
+            KdNode nd = KdNode{0u, 0u, 0ull};
+            bool member = false;
+            uint32_t* acc = k.bb + ((size_t)el * k.mn + r) * 4;
+            if (live) {
+                nd = list[r];
+                member = (t == 0 || L.a > 0) && ((nd.left >> L.a) & 1ull) != 0ull;
+                if (member) {
+                    atomicMin(acc + 0, kx), atomicMax(acc + 1, kx);
+                    atomicMin(acc + 2, ky), atomicMax(acc + 3, ky);
+                }
+            }
+            __syncthreads();
+            bool lower = false;
+            if (live) {
+                const float min_x = kd_unkey(acc[0]), max_x = kd_unkey(acc[1]), min_y = kd_unkey(acc[2]), max_y = kd_unkey(acc[3]);
+                const bool vertical = (max_x - min_x) > (max_y - min_y);
+                const float split = vertical ? 0.5f * (max_x + min_x) : 0.5f * (max_y + min_y);
+                lower = member && (vertical ? me.x : me.y) < split;
+            }
+            const unsigned long long ballot = __ballot(lower);
+            if (live && L.a == 0) {
+                const uint64_t lm = (ballot >> L.ebase) & amask;
+                const int begin = nd.meta & 0xff, end = (nd.meta >> 8) & 0xff, nl = __popcll(lm);
+                const bool degenerate = nl == 0;
+                list[r].meta = (uint32_t)begin | ((uint32_t)end << 8) | ((uint32_t)nl << 16) | (degenerate ? 1u << 24 : 0u);
+                list[r].left = lm;
+                int n = c;
+                if (!degenerate && nl > kKdLeaf && n < k.mn) {
+                    list[n].meta = (uint32_t)begin | ((uint32_t)(begin + nl) << 8);
+                    list[n].left = lm;
+                    ++n;
+                }
+                if (!degenerate && end - begin - nl > kKdLeaf && n < k.mn) {
+                    list[n].meta = (uint32_t)(begin + nl) | ((uint32_t)end << 8);
+                    list[n].left = nd.left & ~lm;
+                    ++n;
+                }
+                *cnt = n;
+            }
+        }
+    }
+}
+
+// Every simulator's permutation follows this step's tree (lane = the simulator's own agent).  A node whose record equals
+// last step's, under ancestors that did not move anything either, is partitioned already.
+__device__ __forceinline__ void kd_update_orders(const Params& P, const Smem& s, const Lane& L, int g) {
+    const KdSmem& k = s.kd;
+    if (L.lane >= P.nA) return;
+    const int el = L.ebase / P.A, t = kd_tree_of(L.a, P.robot_visible);
+    if (!kd_tree_on(P.A, t, P.robot_visible)) return;
+    const KdNode* cur = k.nodes + ((size_t)(g * P.E + el) * 2 + t) * k.mn;
+    const KdNode* old = k.nodes + ((size_t)((g ^ 1) * P.E + el) * 2 + t) * k.mn;
+    const int n_cur = k.count[(g * P.E + el) * 2 + t], n_old = k.count[((g ^ 1) * P.E + el) * 2 + t];
+    uint8_t* row = k.ord + (size_t)L.lane * k.row;
+    bool dirty = false;
+    for (int r = 0; r < n_cur; ++r) {
+        const KdNode c = cur[r];
+        if (!dirty) {
+            dirty = r >= n_old;
+            if (!dirty) {
+                const KdNode o = old[r];
+                dirty = o.meta != c.meta || o.left != c.left;
+            }
+        }
+        if (dirty && ((c.meta >> 24) & 1u) == 0u)
+            kd_partition(row, c.meta & 0xff, (c.meta >> 8) & 0xff, (c.meta >> 16) & 0xff, c.left);
+    }
+}
+
+// Position of every agent of this lane's simulator in RVO2's traversal of its tree (queryAgentTreeRecursive without the
+// pruning, which only drops candidates that would be rejected): nearer child first, a leaf in permutation order.  Serial on
+// the lane; runs only for simulators with an exact distance tie.
+__device__ __forceinline__ void kd_visit_order(const Params& P, const Smem& s, const Lane& L, int g) {
+    const KdSmem& k = s.kd;
+    const int el = L.ebase / P.A, t = kd_tree_of(L.a, P.robot_visible);
+    const KdNode* cur = k.nodes + ((size_t)(g * P.E + el) * 2 + t) * k.mn;
+    const int n_cur = kd_tree_on(P.A, t, P.robot_visible) ? k.count[(g * P.E + el) * 2 + t] : 0;
+    const uint8_t* row = k.ord + (size_t)L.lane * k.row;
+    uint8_t* vis = k.visit + (size_t)L.lane * k.row;
+    uint16_t* st = k.stack + (size_t)L.lane * (k.mn + 1);
+    const float4 me = s.kin[L.lane];
+    auto box_dist = [&](int b, int e) {
+        float4 q = s.kin[L.ebase + row[b]];
+        float min_x = q.x, max_x = q.x, min_y = q.y, max_y = q.y;
+        for (int p = b + 1; p < e; ++p) {
+            q = s.kin[L.ebase + row[p]];
+            max_x = fmaxf(max_x, q.x), min_x = fminf(min_x, q.x);
+            max_y = fmaxf(max_y, q.y), min_y = fminf(min_y, q.y);
+        }
+        const float a0 = fmaxf(0.0f, min_x - me.x), a1 = fmaxf(0.0f, me.x - max_x);
+        const float a2 = fmaxf(0.0f, min_y - me.y), a3 = fmaxf(0.0f, me.y - max_y);
+        return ((a0 * a0 + a1 * a1) + a2 * a2) + a3 * a3;
+    };
+    int sp = 0, next = 0;
+    st[sp++] = (uint16_t)(kd_tree_size(P.A, t) << 8);
+    while (sp > 0) {
+        const int e = st[--sp];
+        const int b = e & 0xff, en = e >> 8;
+        int nl = 0;
+        if (en - b > kKdLeaf)
+            for (int r = 0; r < n_cur; ++r) {
+                const uint32_t m = cur[r].meta;
+                if ((m & 0xffffu) == (uint32_t)e && ((m >> 24) & 1u) == 0u) nl = (m >> 16) & 0xff;
+            }
+        if (nl > 0) {
+            const float dl = box_dist(b, b + nl), dr = box_dist(b + nl, en);
+            const uint16_t lo = (uint16_t)(b | ((b + nl) << 8)), hi = (uint16_t)((b + nl) | (en << 8));
+            st[sp++] = dl < dr ? hi : lo;  // the farther child waits
+            st[sp++] = dl < dr ? lo : hi;
+        } else {
+            for (int p = b; p < en; ++p) vis[row[p]] = (uint8_t)next++;
         }
     }
 }
@@ -332,8 +528,21 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         } else if (kCoop3 || kCand3) {
             s.sol[L.lane] = make_float4(0.0f, 0.0f, max_speed, solve ? 1.0f : 0.0f);
         }
+        if (P.kd) {
+            s.kd.tie[L.lane] = 0;
+            s.kd.dnext[L.lane] = std::numeric_limits<float>::infinity();
+        }
     }
     __syncthreads();
+    // simulators of more than 10 agents: this step's kd-tree(s) and every simulator's permutation (kd_order.h); the visiting
+    // order itself is only worked out further down if a simulator turns out to have an exact distance tie
+    int kd_gen = 0;
+    if (P.kd) {
+        kd_gen = *s.kd.gen;
+        kd_build_trees(P, s, L, kd_gen);
+        kd_update_orders(P, s, L, kd_gen);
+        if (threadIdx.x == 0) *s.kd.gen = kd_gen ^ 1;  // this step's node lists are the next step's "last step"
+    }
     CN_TICK(clk, 0);
 
     // pairs-1: squared distances, self.pos - other.pos (Appendix A.2)
@@ -355,6 +564,38 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     // the half-plane is computed in a second sweep over the (agent, kept slot) lanes only — 210 of the 420 ordered pairs,
     // four passes of a wave instead of seven.  Same comparisons and the same half-plane arithmetic: bit-identical.
     const bool two_sweeps = MAXL == 10 && P.NC == 20 && P.orca.max_neighbors == 10;
+    // second sweep of that path: lane = (agent, slot), 6 agents per pass of a wave (lanes 60..63 idle).  detect_ties: a
+    // simulator has an exact distance tie that RVO2's visiting order decides if two of its kept neighbours are equally far
+    // (adjacent slots) or the last kept one is as far as the nearest dropped one.
+    auto sweep2 = [&](bool detect_ties) {
+        const int* kept = reinterpret_cast<const int*>(s.proj);
+        const int wl = threadIdx.x & (kWave - 1), g = wl / 10, slot = wl - g * 10;
+        const int waves = (blockDim.x + kWave - 1) / kWave;
+        for (int q0 = (threadIdx.x / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
+            const int q = q0 + g;
+            const bool lane_ok = wl < 60 && q < P.nA;
+            const int e = lane_ok ? kept[q * 10 + slot] : -1;
+            const bool valid = e >= 0;
+            const unsigned long long vm = __ballot(valid);
+            const int qq = lane_ok ? q : 0;
+            const int ol = valid ? (e & 0xff) : qq;  // unused slots: a finite dummy (the agent against itself), not stored
+            const bool robot_sim = (e >> 8) & 1;
+            const float4 me = s.kin[qq];
+            const float4 ot = s.kin[ol];
+            const float rq_r = s.rview[qq], ro_r = s.rview[ol], rq_h = s.hview[qq], ro_h = s.hview[ol];
+            const float rsum = (valid && robot_sim) ? rq_r + ro_r : rq_h + ro_h;
+            if (lane_ok && slot == 0) s.count[q] = __popcll((vm >> (10 * g)) & 0x3ffull);
+            if (valid)
+                s.lines[q * kLineStride + slot] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
+            if (P.kd && detect_ties) {
+                const float ddx = me.x - ot.x, ddy = me.y - ot.y;
+                const float dsq = ddx * ddx + ddy * ddy;  // = s.d2 of the pair (same operands, same operations)
+                const float before = __shfl_up(dsq, 1);
+                const bool tie = valid && ((slot > 0 && before == dsq) || (slot == 9 && dsq == s.kd.dnext[qq]));
+                if (tie) s.kd.tie[qq] = 1;
+            }
+        }
+    };
     if (two_sweeps) {
         // kept [nA][10]: candidate lane | robot's-sim bit << 8 of the pair that ranks there, -1 = no such neighbour (cleared in
         // the stage phase; proj is free until the solve).  A pair inside the range ranks by (v < mine) | (v == mine & k < c)
@@ -377,41 +618,25 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 #pragma unroll
             for (int k = 0; k < 20; ++k) rank += ((v[k] < mine) | ((v[k] == mine) & (k < c))) ? 1 : 0;
             if (mine < range_sq && rank < 10) kept[(info & 0xff) * 10 + rank] = ((info >> 8) & 0xff) | (((info >> 25) & 1) << 8);
+            if (P.kd && mine < range_sq && rank == 10) s.kd.dnext[info & 0xff] = mine;  // the nearest one that is dropped
         }
         __syncthreads();
-        // second sweep: lane = (agent, slot), 6 agents per pass of a wave (lanes 60..63 idle)
-        const int wl = threadIdx.x & (kWave - 1), g = wl / 10, slot = wl - g * 10;
-        const int waves = (blockDim.x + kWave - 1) / kWave;
-        for (int q0 = (threadIdx.x / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
-            const int q = q0 + g;
-            const bool lane_ok = wl < 60 && q < P.nA;
-            const int e = lane_ok ? kept[q * 10 + slot] : -1;
-            const bool valid = e >= 0;
-            const unsigned long long vm = __ballot(valid);
-            const int qq = lane_ok ? q : 0;
-            const int ol = valid ? (e & 0xff) : qq;  // unused slots: a finite dummy (the agent against itself), not stored
-            const bool robot_sim = (e >> 8) & 1;
-            const float4 me = s.kin[qq];
-            const float4 ot = s.kin[ol];
-            const float rq_r = s.rview[qq], ro_r = s.rview[ol], rq_h = s.hview[qq], ro_h = s.hview[ol];
-            const float rsum = (valid && robot_sim) ? rq_r + ro_r : rq_h + ro_h;
-            if (lane_ok && slot == 0) s.count[q] = __popcll((vm >> (10 * g)) & 0x3ffull);
-            if (valid)
-                s.lines[q * kLineStride + slot] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
-        }
+        sweep2(true);
     } else
     for (int p = L.lane; p < P.pairs; p += blockDim.x) {
         const int info = s.pinfo[p];
         const int q = info & 0xff, c = (info >> 16) & 0xff;
         const float mine = s.d2[p];
         const float* row = s.d2 + (p - c);
-        int rank = 0, within = 0;
+        int rank = 0, within = 0, same = 0;
         for (int k = 0; k < P.NC; ++k) {  // (bitwise, not short-circuit: no branch per candidate)
             const float v = row[k];
             const int in = v < range_sq ? 1 : 0;
             within += in;
+            same += v == mine ? 1 : 0;  // itself included
             rank += in & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (k < c ? 1 : 0)));
         }
+        if (P.kd && mine < range_sq && same > 1) s.kd.tie[q] = 1;  // an exact tie: RVO2's kd-tree visiting order decides
         if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
         if (mine < range_sq && rank < P.orca.max_neighbors) {
             const int ol = (info >> 8) & 0xff;
@@ -424,6 +649,47 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         }
     }
     __syncthreads();
+    if (P.kd) {
+        const bool my_tie = L.lane < P.nA && s.kd.tie[L.lane] != 0;
+        if (__syncthreads_or(my_tie ? 1 : 0)) {  // rare: rank the candidates of those simulators again, ties by visiting order
+            if (my_tie) kd_visit_order(P, s, L, kd_gen);
+            __syncthreads();
+            int* kept = reinterpret_cast<int*>(s.proj);
+            for (int p = L.lane; p < P.pairs; p += blockDim.x) {
+                const int info = s.pinfo[p];
+                const int q = info & 0xff, c = (info >> 16) & 0xff, ol = (info >> 8) & 0xff;
+                if (s.kd.tie[q] == 0) continue;
+                const int qb = q / P.A * P.A;
+                const uint8_t* vq = s.kd.visit + (size_t)q * s.kd.row;
+                const float mine = s.d2[p];
+                const float* row = s.d2 + (p - c);
+                const int my_visit = vq[ol - qb];
+                int rank = 0;
+                for (int k = 0; k < P.NC; ++k) {
+                    const float v = row[k];
+                    const int visit = vq[((s.pinfo[p - c + k] >> 8) & 0xff) - qb];
+                    rank += (v < range_sq ? 1 : 0) & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (visit < my_visit ? 1 : 0)));
+                }
+                if (mine < range_sq && rank < P.orca.max_neighbors) {
+                    const bool robot_sim = (info >> 25) & 1;
+                    if (two_sweeps) {
+                        kept[q * 10 + rank] = ol | ((robot_sim ? 1 : 0) << 8);
+                    } else {
+                        const float4 me = s.kin[q];
+                        const float4 ot = s.kin[ol];
+                        const float rsum = robot_sim ? s.rview[q] + s.rview[ol] : s.hview[q] + s.hview[ol];
+                        s.lines[q * kLineStride + rank] =
+                            make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
+                    }
+                }
+            }
+            __syncthreads();
+            if (two_sweeps) {
+                sweep2(false);
+                __syncthreads();
+            }
+        }
+    }
     CN_TICK(clk, 2);
 
     out_vx = 0.0f, out_vy = 0.0f;
@@ -719,8 +985,10 @@ __global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, 
     float robot_max_speed;
     load_robot_view(P, S, s, L, r, robot_max_speed);
     build_pairs(P, s);
+    kd_load(P, S, s, L);
     float vx, vy;
     orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid, vx, vy);
+    kd_store(P, S, s, L);
     if (L.valid) {
         out_vel[2 * L.gi] = vx;
         out_vel[2 * L.gi + 1] = vy;
@@ -737,6 +1005,7 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
     float robot_max_speed = 0.0f;
     if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
     build_pairs(P, s);
+    kd_load(P, S, s, L);
     double gtime = (L.valid && L.a == 0) ? S.gtime[L.env] : 0.0;
     const AgentRegs before = r;
 
@@ -744,6 +1013,7 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
     StepResult res;
     double nvx, nvy;
     step_core<MAXL, UNI>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta);
+    kd_store(P, S, s, L);  // (a lookahead rebuilds the humans' trees too: the reference's onestep_lookahead runs doStep)
     if (!L.valid) return;
 
     if (L.a == 0) {
@@ -837,6 +1107,8 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Params P, ScenarioCfg C, S
     S.gtime[b] = 0.0;
     S.theta[b] = 1.5707963267948966;  // robot.set(..., np.pi / 2)
     if (draws) draws[b] = n;
+    if (P.kd)  // new Human objects, new ORCA policies, new rvo2 simulators (the robot's persists)
+        for (int a = 1; a < P.A; ++a) S.kd_valid[(size_t)b * P.A + a] = 0;
 }
 
 __global__ void mt_probe_kernel(uint32_t* key, uint32_t seed, int n, double* out) {
@@ -882,6 +1154,8 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, Scenario
     if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[b] = 0.0;
     S.ring_filled_in[b] = 0;
     S.ring_filled_out[b] = 0;
+    if (P.kd)
+        for (int a = 1; a < P.A; ++a) S.kd_valid[(size_t)b * P.A + a] = 0;
     if (!on) return;
     generate_scenario_lane<IN_LDS>(C, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv, S.mt_key + b,
                                    P.B, false, nullptr);
@@ -948,6 +1222,8 @@ __global__ __launch_bounds__(kWave) void reset_wave_kernel(Params P, ScenarioCfg
         S.theta[b] = 1.5707963267948966;
         if (draws) draws[b] = n;
     }
+    if (P.kd)
+        for (int a = 1 + threadIdx.x; a < P.A; a += blockDim.x) S.kd_valid[(size_t)b * P.A + a] = 0;
 }
 
 __global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
@@ -969,6 +1245,8 @@ __global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, Sce
         S.gtime[b] = 0.0;
         S.mt_pos[b] = -1;
     }
+    if (P.kd)
+        for (int a = 1 + threadIdx.x; a < P.A; a += blockDim.x) S.kd_valid[(size_t)b * P.A + a] = 0;
     if (P.async_fill)
         for (int t = threadIdx.x; t < P.ring_depth; t += blockDim.x) {  // nothing resident, nothing claimed
             S.ring_ready[(size_t)b * P.ring_depth + t] = 0;
@@ -1223,6 +1501,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     float robot_max_speed = 0.0f;
     if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
     build_pairs(P, s);
+    kd_load(P, S, s, L);
 
     const bool robot = L.valid && L.a == 0;
     double theta = robot ? S.theta[L.env] : 0.0;  // heading of a unicycle robot (external actions only)
@@ -1249,6 +1528,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     __syncthreads();
     if (L.valid && s.flag[L.ebase] >= 2) {
         load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+        kd_new_episode(P, s, L);
         theta = 1.5707963267948966;
     }
     unsigned int transitions = 0;
@@ -1291,6 +1571,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         __syncthreads();
         if (L.valid && s.flag[L.ebase] >= 2) {
             load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
+            kd_new_episode(P, s, L);
             theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
         }
         CN_TICK(clk, 7);
@@ -1302,6 +1583,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     }
 #endif
 
+    kd_store(P, S, s, L);
     if (L.valid) {
         S.pos[L.gi] = make_double2(r.px, r.py);
         S.vel[L.gi] = make_double2(r.vx, r.vy);

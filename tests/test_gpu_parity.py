@@ -553,7 +553,7 @@ def test_free_running_soak_vs_oracle(amd, oracle_mod, humans, envs, rounds, radi
     for r in range(rounds):
         o = oracle_mod.CrowdOracle(num_envs=envs, robot_policy=1, **cfg)
         o.reset(50000 + 1000 * r + np.arange(envs))
-        eng.drop_robot_sim()
+        eng.drop_sims()  # a fresh oracle: fresh rvo2 simulators for every agent on this side too
         eng.set_state(o.get_state()[0], np.zeros(envs))
         for t in range(100):
             got = eng.step(None, update=True, want_obs=False)
