@@ -104,27 +104,53 @@ int bind(cn_engine* e) {
 
 inline int grid_envs(const cn_engine* e) { return (e->P.B + e->P.E - 1) / e->P.E; }
 
-// launch a kernel template instantiated for the engine's half-plane capacity
-#define CN_LAUNCH_MAXL(e, kernel, grid, ...)                                                              \
-    do {                                                                                                  \
-        if ((e)->maxl == 5)                                                                               \
-            hipLaunchKernelGGL(cn::kernel<5>, dim3(grid), dim3((e)->P.threads), (e)->smem, (e)->stream, __VA_ARGS__);  \
-        else                                                                                              \
-            hipLaunchKernelGGL(cn::kernel<10>, dim3(grid), dim3((e)->P.threads), (e)->smem, (e)->stream, __VA_ARGS__); \
+// launch a kernel template instantiated for the engine's half-plane capacity (and with / without the kd-tree bookkeeping of
+// simulators with more than 10 agents)
+#define CN_LAUNCH_MAXL(e, kernel, grid, ...)                                                                        \
+    do {                                                                                                            \
+        const dim3 g__(grid), b__((e)->P.threads);                                                                  \
+        if ((e)->maxl == 5 && !(e)->P.kd)                                                                           \
+            hipLaunchKernelGGL((cn::kernel<5, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);               \
+        else if ((e)->maxl == 5)                                                                                    \
+            hipLaunchKernelGGL((cn::kernel<5, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                \
+        else if (!(e)->P.kd)                                                                                        \
+            hipLaunchKernelGGL((cn::kernel<10, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);              \
+        else                                                                                                        \
+            hipLaunchKernelGGL((cn::kernel<10, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);               \
     } while (0)
 
-// ... and for the robot kinematics (the unicycle code only exists in the <.., true> instantiations)
-#define CN_LAUNCH_MAXL_UNI(e, kernel, grid, ...)                                                                        \
-    do {                                                                                                                \
-        const dim3 g__(grid), b__((e)->P.threads);                                                                      \
-        if ((e)->maxl == 5 && !(e)->P.robot_unicycle)                                                                   \
-            hipLaunchKernelGGL((cn::kernel<5, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                   \
-        else if ((e)->maxl == 5)                                                                                        \
-            hipLaunchKernelGGL((cn::kernel<5, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                    \
-        else if (!(e)->P.robot_unicycle)                                                                                \
-            hipLaunchKernelGGL((cn::kernel<10, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                  \
-        else                                                                                                            \
-            hipLaunchKernelGGL((cn::kernel<10, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                   \
+// ... and for the robot kinematics (the unicycle code only exists in the <.., true, ..> instantiations).  K: the kernel
+// template takes <MAXL, UNI, KD> (step_kernel) — rollout_kernel has HEADLINE in between, see CN_LAUNCH_ROLLOUT
+#define CN_LAUNCH_MAXL_UNI(e, kernel, grid, ...)                                                                    \
+    do {                                                                                                            \
+        const dim3 g__(grid), b__((e)->P.threads);                                                                  \
+        const int v__ = ((e)->maxl == 5 ? 0 : 4) | ((e)->P.robot_unicycle ? 2 : 0) | ((e)->P.kd ? 1 : 0);           \
+        switch (v__) {                                                                                              \
+            case 0: hipLaunchKernelGGL((cn::kernel<5, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+            case 1: hipLaunchKernelGGL((cn::kernel<5, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
+            case 2: hipLaunchKernelGGL((cn::kernel<5, true, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
+            case 3: hipLaunchKernelGGL((cn::kernel<5, true, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;    \
+            case 4: hipLaunchKernelGGL((cn::kernel<10, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break; \
+            case 5: hipLaunchKernelGGL((cn::kernel<10, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+            case 6: hipLaunchKernelGGL((cn::kernel<10, true, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+            default: hipLaunchKernelGGL((cn::kernel<10, true, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+        }                                                                                                           \
+    } while (0)
+
+#define CN_LAUNCH_ROLLOUT(e, grid, ...)                                                                             \
+    do {                                                                                                            \
+        const dim3 g__(grid), b__((e)->P.threads);                                                                  \
+        const int v__ = ((e)->maxl == 5 ? 0 : 4) | ((e)->P.robot_unicycle ? 2 : 0) | ((e)->P.kd ? 1 : 0);           \
+        switch (v__) {                                                                                              \
+            case 0: hipLaunchKernelGGL((cn::rollout_kernel<5, false, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+            case 1: hipLaunchKernelGGL((cn::rollout_kernel<5, false, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
+            case 2: hipLaunchKernelGGL((cn::rollout_kernel<5, true, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
+            case 3: hipLaunchKernelGGL((cn::rollout_kernel<5, true, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;    \
+            case 4: hipLaunchKernelGGL((cn::rollout_kernel<10, false, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break; \
+            case 5: hipLaunchKernelGGL((cn::rollout_kernel<10, false, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+            case 6: hipLaunchKernelGGL((cn::rollout_kernel<10, true, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+            default: hipLaunchKernelGGL((cn::rollout_kernel<10, true, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
+        }                                                                                                           \
     } while (0)
 
 int env_int(const char* name, int fallback) {
@@ -211,6 +237,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     P.kd = P.A > cn::kKdLeaf ? 1 : 0;  // a simulator of more than 10 agents splits its kd-tree: visiting order matters at ties
+    P.kdl = cn::kd_layout(P.nA, P.A, P.E);
     e->smem = cn::smem_bytes(P.nA, P.pairs, e->maxl, P.A, P.E);
     e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", 0) != 0;
     e->gen_wave = env_int("CROWDNAV_AMD_WAVE_SCENARIOS", c->num_humans > 8 ? 1 : 0) != 0;
@@ -639,10 +666,10 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
             hipLaunchKernelGGL((cn::rollout_fused_kernel<false>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
                                (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else if (e->maxl == 5 && !P.robot_unicycle && headline) {
-        hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P, e->S, R,
-                           n_steps, action);
+        hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
+                           (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else {
-        CN_LAUNCH_MAXL_UNI(e, rollout_kernel, grid_envs(e), e->P, e->S, R, n_steps, action);
+        CN_LAUNCH_ROLLOUT(e, grid_envs(e), e->P, (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     }
 }
 

@@ -327,7 +327,7 @@ __device__ __forceinline__ void lp_planar_coop(const float4* lines, const int* c
     const int wl = threadIdx.x & (kWave - 1);
     const int g = wl / MAXL, l = wl - g * MAXL;
     const int gbase = g * MAXL;
-    const int waves = (blockDim.x + kWave - 1) / kWave;
+    const int waves = ((int)blockDim.x + kWave - 1) / kWave;
     const float inf = __builtin_inff();
     for (int chunk = threadIdx.x / kWave; chunk * G < nA; chunk += waves) {
         const int a = chunk * G + g;
@@ -411,7 +411,7 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
     const int wl = threadIdx.x & (kWave - 1);
     const int g = wl / MAXL, l = wl - g * MAXL;
     const int gbase = g * MAXL;
-    const int waves = (blockDim.x + kWave - 1) / kWave;
+    const int waves = ((int)blockDim.x + kWave - 1) / kWave;
     const float inf = __builtin_inff();
     for (int chunk = threadIdx.x / kWave; chunk * G < n_todo; chunk += waves) {
         const bool live = g < G && chunk * G + g < n_todo;

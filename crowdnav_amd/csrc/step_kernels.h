@@ -31,7 +31,9 @@ constexpr int kMaxBlock = 512;  // threads per workgroup of the transition kerne
 struct Params {
     int B, A;          // envs, agents per env
     int E;             // envs per workgroup (their E * A agents are lanes of wave 0)
-    int threads;       // workgroup size: wave 0 runs the per-agent phases, every wave the per-pair phases
+    int threads;       // workgroup size (= blockDim.x of the transition kernels; read from HERE in the step loop: blockDim.x
+                       // is a load from the dispatch packet — a global load and a wait per use): wave 0 runs the per-agent
+                       // phases, every wave the per-pair phases
     int nA;            // E * A agent lanes
     int NC;            // A - 1 candidate neighbours per agent
     int pairs;         // nA * NC
@@ -40,6 +42,7 @@ struct Params {
     int robot_unicycle;  // external robot actions are ActionRot(v, r) (agent.py:115-135)
     int async_fill;      // CN_FLAG_ASYNC_SCENARIO_FILL: ring slots are published one by one (StateView::ring_ready)
     int kd;              // A > 10: some rvo2 simulator of an env holds more than 10 agents and splits its kd-tree (kd_order.h)
+    KdLayout kdl;        // ... and where its bookkeeping lives in LDS (offsets from Smem::kd_off)
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     double robot_safety, human_safety;
     OrcaParams orca;
@@ -115,7 +118,7 @@ struct Smem {
     float4* res;      // [nA] ... and output: (result.x, result.y, first infeasible line or n, -)
     int* todo;        // [nA + 1] agents that need the 3-D fallback, compacted; [nA] = how many
     double* disc;     // [kMaxDiscount] discount table gamma^(t dt v_pref) (rollout kernel only)
-    KdSmem kd;        // kd-tree visiting order of simulators with more than 10 agents (Params::kd)
+    uint32_t kd_off;  // byte offset (from the start of LDS) of the kd-tree region, simulators of more than 10 agents: kd_view
 };
 
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
@@ -172,11 +175,10 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
     s.pinfo = reinterpret_cast<int*>(p), p += 4 * P.pairs;
     s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
-    s.kd = KdSmem{};
-    if (P.kd) {
+    {
         char* q = reinterpret_cast<char*>(s.disc + kMaxDiscount);
         q += (16 - (reinterpret_cast<size_t>(q) & 15)) & 15;
-        s.kd = kd_carve(q, nA, P.A, P.E);
+        s.kd_off = (uint32_t)(q - reinterpret_cast<char*>(smem_raw));
     }
     return s;
 }
@@ -214,7 +216,7 @@ __device__ __forceinline__ void load_agent(const StateView& S, size_t gi, AgentR
 // (crowd_sim.py:325-327, orca.py:102-104); the robot's own sim holds every human.
 //   bits 0-7 agent lane, 8-15 lane of the candidate, 16-23 candidate slot, 24 pair exists, 25 agent is a robot
 __device__ __forceinline__ void build_pairs(const Params& P, const Smem& s) {
-    for (int p = threadIdx.x; p < P.pairs; p += blockDim.x) {
+    for (int p = threadIdx.x; p < P.pairs; p += P.threads) {
         const int q = p / P.NC;
         const int c = p - q * P.NC;
         const int el = q / P.A;
@@ -260,10 +262,16 @@ __device__ __forceinline__ void load_robot_view(const Params& P, const StateView
 }
 
 // ---------------------------------------------------------------------------------------------- kd-tree order (kd_order.h)
+// The kd region's pointers: region offset + the host-computed layout in the kernel arguments (KdLayout).
+__device__ __forceinline__ KdSmem kd_view(const Params& P, const Smem& s) {
+    extern __shared__ double2 smem_raw[];
+    return kd_carve(reinterpret_cast<char*>(smem_raw) + s.kd_off, P.kdl);
+}
+
 // A launch keeps the permutations of its envs' simulators in LDS: loaded here (or built fresh), stored by kd_store.
 __device__ __forceinline__ void kd_load(const Params& P, const StateView& S, const Smem& s, const Lane& L) {
     if (!P.kd) return;
-    const KdSmem& k = s.kd;
+    const KdSmem k = kd_view(P, s);
     if (L.lane < P.nA) {
         uint8_t* row = k.ord + (size_t)L.lane * k.row;
         if (L.valid && S.kd_valid[L.gi] != 0) {
@@ -274,12 +282,12 @@ __device__ __forceinline__ void kd_load(const Params& P, const StateView& S, con
         }
     }
     if (threadIdx.x == 0) *k.gen = 0;
-    for (int i = threadIdx.x; i < P.E * 2 * 2; i += blockDim.x) k.count[i] = 0;  // no "last step's tree" yet
+    for (int i = threadIdx.x; i < P.E * 2 * 2; i += P.threads) k.count[i] = 0;  // no "last step's tree" yet
 }
 
 __device__ __forceinline__ void kd_store(const Params& P, const StateView& S, const Smem& s, const Lane& L) {
     if (!P.kd || !L.valid) return;
-    const KdSmem& k = s.kd;
+    const KdSmem k = kd_view(P, s);
     const uint32_t* row = reinterpret_cast<const uint32_t*>(k.ord + (size_t)L.lane * k.row);
     uint32_t* dst = reinterpret_cast<uint32_t*>(S.kd_order + L.gi * k.row);
     for (int w = 0; w < k.row / 4; ++w) dst[w] = row[w];
@@ -290,19 +298,19 @@ __device__ __forceinline__ void kd_store(const Params& P, const StateView& S, co
 // policy object, hence its simulator, lives on.  Called by the lanes of an env that has just loaded its next scenario.
 __device__ __forceinline__ void kd_new_episode(const Params& P, const Smem& s, const Lane& L) {
     if (!P.kd) return;
-    const KdSmem& k = s.kd;
+    const KdSmem k = kd_view(P, s);
     if (L.a > 0) kd_identity_row(k.ord + (size_t)L.lane * k.row, k.row, P.A, L.a, P.robot_visible);
-    if (L.a == 0) {  // nothing of this env's previous tree says anything about the fresh rows
-        const int prev = *k.gen ^ 1, el = L.ebase / P.A;
-        k.count[(prev * P.E + el) * 2 + 0] = 0;
-        k.count[(prev * P.E + el) * 2 + 1] = 0;
+    if (L.a == 0) {  // nothing of this env's last tree says anything about the fresh rows
+        const int last = *k.gen, el = L.ebase / P.A;
+        k.count[(last * P.E + el) * 2 + 0] = 0;
+        k.count[(last * P.E + el) * 2 + 1] = 0;
     }
 }
 
 // The tree(s) of every env of the workgroup from this step's float32 positions (s.kin), breadth first on agent sets: the
 // nodes that split, in `generation` g of the node lists.  All threads (barriers inside).
 __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, const Lane& L, int g) {
-    const KdSmem& k = s.kd;
+    const KdSmem k = kd_view(P, s);
     const int tid = threadIdx.x;
     const bool agent = L.lane < P.nA;
     const int el = agent ? L.ebase / P.A : 0;
@@ -316,12 +324,15 @@ __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, c
             if (agent && L.a == 0) *cnt = 0;
             continue;
         }
-        for (int i = tid; i < P.E * k.mn; i += blockDim.x) {
+        for (int i = tid; i < P.E * k.mn; i += P.threads) {
             k.bb[4 * i + 0] = 0xffffffffu, k.bb[4 * i + 1] = 0u, k.bb[4 * i + 2] = 0xffffffffu, k.bb[4 * i + 3] = 0u;
         }
+        const KdNode* old = k.nodes + ((size_t)((g ^ 1) * P.E + el) * 2 + t) * k.mn;
+        const int n_old = agent ? k.count[((g ^ 1) * P.E + el) * 2 + t] : 0;
+        int first_dirty = 1 << 20;
         if (agent && L.a == 0) {  // the env's robot lane keeps the books (whether or not the robot is in this tree)
             list[0].meta = (uint32_t)kd_tree_size(P.A, t) << 8;
-            list[0].left = t == 0 ? amask : (amask & ~1ull);
+            list[0].set = t == 0 ? amask : (amask & ~1ull);
             *cnt = 1;
         }
         __syncthreads();
@@ -329,12 +340,12 @@ __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, c
             const int c = agent ? *cnt : 0;
             const bool live = agent && r < c;
             if (!__syncthreads_or(live ? 1 : 0)) break;
-            KdNode nd = KdNode{0u, 0u, 0ull};
+            KdNode nd = KdNode{0u, 0u, 0ull, 0ull, 0ull};
             bool member = false;
             uint32_t* acc = k.bb + ((size_t)el * k.mn + r) * 4;
             if (live) {
                 nd = list[r];
-                member = (t == 0 || L.a > 0) && ((nd.left >> L.a) & 1ull) != 0ull;
+                member = (t == 0 || L.a > 0) && ((nd.set >> L.a) & 1ull) != 0ull;
                 if (member) {
                     atomicMin(acc + 0, kx), atomicMax(acc + 1, kx);
                     atomicMin(acc + 2, ky), atomicMax(acc + 3, ky);
@@ -353,29 +364,134 @@ __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, c
                 const uint64_t lm = (ballot >> L.ebase) & amask;
                 const int begin = nd.meta & 0xff, end = (nd.meta >> 8) & 0xff, nl = __popcll(lm);
                 const bool degenerate = nl == 0;
-                list[r].meta = (uint32_t)begin | ((uint32_t)end << 8) | ((uint32_t)nl << 16) | (degenerate ? 1u << 24 : 0u);
+                const uint32_t meta = (uint32_t)begin | ((uint32_t)end << 8) | ((uint32_t)nl << 16) | (degenerate ? 1u << 24 : 0u);
+                list[r].meta = meta;
                 list[r].left = lm;
+                if (first_dirty > r && (r >= n_old || old[r].meta != meta || old[r].left != lm)) first_dirty = r;
                 int n = c;
                 if (!degenerate && nl > kKdLeaf && n < k.mn) {
                     list[n].meta = (uint32_t)begin | ((uint32_t)(begin + nl) << 8);
-                    list[n].left = lm;
+                    list[n].set = lm;
                     ++n;
                 }
                 if (!degenerate && end - begin - nl > kKdLeaf && n < k.mn) {
                     list[n].meta = (uint32_t)(begin + nl) | ((uint32_t)end << 8);
-                    list[n].left = nd.left & ~lm;
+                    list[n].set = nd.set & ~lm;
                     ++n;
                 }
                 *cnt = n;
+                k.dirty[el * 2 + t] = first_dirty;
             }
         }
     }
 }
 
+// The same for the usual geometry of these crowds — one env per single-wave workgroup: every quantity of a node is uniform
+// over the wave, so the bounding box is four DPP wave reductions, the lower side a ballot, and the control flow scalar: no LDS
+// atomics, no barriers (the cooperative version above spent ~1 400 clock ticks per node on them).
+// Most steps (84 % at 20 humans) leave the tree as it was, and that can be PROVED for a fraction of a rebuild: if the four
+// agents that attained a node's bounding box last time still bound every member, the box is theirs; with it the split; and if
+// every member is still on its old side of it, the node's record — and, node by node, the whole tree — is unchanged: then
+// nothing is written and no simulator has anything to do.  Returns the generation that holds this step's lists.
+__device__ __forceinline__ int kd_build_trees_wave(const Params& P, const Smem& s, const Lane& L, int g_last) {
+    const KdSmem k = kd_view(P, s);
+    const bool agent = L.lane < P.nA;  // = L.lane < P.A: one env
+    const float4 me = agent ? s.kin[L.lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t kx = kd_key(me.x), ky = kd_key(me.y);
+    const uint64_t amask = P.A >= 64 ? ~0ull : ((1ull << P.A) - 1ull);
+    // ---- unchanged?
+    bool same = true;
+    for (int t = 0; t < 2 && same; ++t) {
+        if (!kd_tree_on(P.A, t, P.robot_visible)) continue;
+        const KdNode* old = k.nodes + ((size_t)g_last * 2 + t) * k.mn;
+        const int n_old = k.count[g_last * 2 + t];
+        same = n_old > 0;
+        for (int r = 0; r < n_old && same; ++r) {
+            const KdNode od = old[r];
+            const bool member = agent && ((od.set >> L.lane) & 1ull) != 0ull;
+            const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)kx, od.ext & 0xff);
+            const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)kx, (od.ext >> 8) & 0xff);
+            const uint32_t y0 = (uint32_t)__builtin_amdgcn_readlane((int)ky, (od.ext >> 16) & 0xff);
+            const uint32_t y1 = (uint32_t)__builtin_amdgcn_readlane((int)ky, (od.ext >> 24) & 0xff);
+            const float min_x = kd_unkey(x0), max_x = kd_unkey(x1), min_y = kd_unkey(y0), max_y = kd_unkey(y1);
+            const bool vertical = (max_x - min_x) > (max_y - min_y);
+            const float split = vertical ? 0.5f * (max_x + min_x) : 0.5f * (max_y + min_y);
+            const bool inside = kx >= x0 && kx <= x1 && ky >= y0 && ky <= y1;
+            const bool lower = (vertical ? me.x : me.y) < split;
+            const bool was_lower = ((od.left >> L.lane) & 1ull) != 0ull;
+            const bool moved = member && (!inside || lower != was_lower);
+            same = __ballot(moved) == 0ull && ((od.meta >> 24) & 1u) == 0u;
+        }
+    }
+    if (same) {
+        if (L.lane == 0) {
+            k.dirty[0] = k.count[g_last * 2 + 0];
+            k.dirty[1] = k.count[g_last * 2 + 1];
+        }
+        return g_last;
+    }
+    // ---- rebuild into the other generation
+    const int g = g_last ^ 1;
+    for (int t = 0; t < 2; ++t) {
+        KdNode* list = k.nodes + ((size_t)g * 2 + t) * k.mn;
+        const KdNode* old = k.nodes + ((size_t)g_last * 2 + t) * k.mn;
+        int* cnt = k.count + g * 2 + t;
+        if (!kd_tree_on(P.A, t, P.robot_visible)) {
+            if (L.lane == 0) *cnt = 0, k.dirty[t] = 0;
+            continue;
+        }
+        const int n_old = k.count[g_last * 2 + t];
+        int first_dirty = 1 << 20, n = 1;
+        if (L.lane == 0) {
+            list[0].meta = (uint32_t)kd_tree_size(P.A, t) << 8;
+            list[0].set = t == 0 ? amask : (amask & ~1ull);
+        }
+        for (int r = 0; r < n; ++r) {  // n, r, the node and everything derived from it are wave-uniform
+            const KdNode nd = list[r];
+            const bool had = r < n_old;
+            const KdNode od = old[had ? r : 0];
+            const bool member = agent && ((nd.set >> L.lane) & 1ull) != 0ull;
+            uint32_t b0 = member ? kx : 0xffffffffu, b1 = member ? kx : 0u, b2 = member ? ky : 0xffffffffu, b3 = member ? ky : 0u;
+            kd_wave_bbox(b0, b1, b2, b3);
+            const float min_x = kd_unkey(b0), max_x = kd_unkey(b1), min_y = kd_unkey(b2), max_y = kd_unkey(b3);
+            const bool vertical = (max_x - min_x) > (max_y - min_y);
+            const float split = vertical ? 0.5f * (max_x + min_x) : 0.5f * (max_y + min_y);
+            const uint64_t lm = __ballot(member && (vertical ? me.x : me.y) < split) & amask;
+            // the members that attain the box (any one of them each: the box is what matters)
+            const uint32_t ext = (uint32_t)(__ffsll((long long)__ballot(member && kx == b0)) - 1) |
+                                 ((uint32_t)(__ffsll((long long)__ballot(member && kx == b1)) - 1) << 8) |
+                                 ((uint32_t)(__ffsll((long long)__ballot(member && ky == b2)) - 1) << 16) |
+                                 ((uint32_t)(__ffsll((long long)__ballot(member && ky == b3)) - 1) << 24);
+            const int begin = nd.meta & 0xff, end = (nd.meta >> 8) & 0xff, nl = __popcll(lm);
+            const bool degenerate = nl == 0;
+            const uint32_t meta = (uint32_t)begin | ((uint32_t)end << 8) | ((uint32_t)nl << 16) | (degenerate ? 1u << 24 : 0u);
+            if (first_dirty > r && (!had || od.meta != meta || od.left != lm)) first_dirty = r;
+            const bool lo = !degenerate && nl > kKdLeaf && n < k.mn;
+            const bool hi = !degenerate && end - begin - nl > kKdLeaf && n + (lo ? 1 : 0) < k.mn;
+            if (L.lane == 0) {
+                list[r].meta = meta;
+                list[r].ext = ext;
+                list[r].left = lm;
+                if (lo) {
+                    list[n].meta = (uint32_t)begin | ((uint32_t)(begin + nl) << 8);
+                    list[n].set = lm;
+                }
+                if (hi) {
+                    list[n + (lo ? 1 : 0)].meta = (uint32_t)(begin + nl) | ((uint32_t)end << 8);
+                    list[n + (lo ? 1 : 0)].set = nd.set & ~lm;
+                }
+            }
+            n += (lo ? 1 : 0) + (hi ? 1 : 0);
+        }
+        if (L.lane == 0) *cnt = n, k.dirty[t] = first_dirty;
+    }
+    return g;
+}
+
 // Every simulator's permutation follows this step's tree (lane = the simulator's own agent).  A node whose record equals
 // last step's, under ancestors that did not move anything either, is partitioned already.
 __device__ __forceinline__ void kd_update_orders(const Params& P, const Smem& s, const Lane& L, int g) {
-    const KdSmem& k = s.kd;
+    const KdSmem k = kd_view(P, s);
     if (L.lane >= P.nA) return;
     const int el = L.ebase / P.A, t = kd_tree_of(L.a, P.robot_visible);
     if (!kd_tree_on(P.A, t, P.robot_visible)) return;
@@ -383,17 +499,15 @@ __device__ __forceinline__ void kd_update_orders(const Params& P, const Smem& s,
     const KdNode* old = k.nodes + ((size_t)((g ^ 1) * P.E + el) * 2 + t) * k.mn;
     const int n_cur = k.count[(g * P.E + el) * 2 + t], n_old = k.count[((g ^ 1) * P.E + el) * 2 + t];
     uint8_t* row = k.ord + (size_t)L.lane * k.row;
-    bool dirty = false;
-    for (int r = 0; r < n_cur; ++r) {
+    (void)old, (void)n_old;
+    // every node from the first one whose record differs from last step's (the builder found it): conservative — a later node
+    // of another subtree is partitioned already and is left as it is by a second partition
+    for (int r = k.dirty[el * 2 + t]; r < n_cur; ++r) {
         const KdNode c = cur[r];
-        if (!dirty) {
-            dirty = r >= n_old;
-            if (!dirty) {
-                const KdNode o = old[r];
-                dirty = o.meta != c.meta || o.left != c.left;
-            }
-        }
-        if (dirty && ((c.meta >> 24) & 1u) == 0u)
+        if (((c.meta >> 24) & 1u) != 0u) continue;
+        if (P.A <= 32)
+            kd_partition32(row, c.meta & 0xff, (c.meta >> 8) & 0xff, (c.meta >> 16) & 0xff, (uint32_t)c.left);
+        else
             kd_partition(row, c.meta & 0xff, (c.meta >> 8) & 0xff, (c.meta >> 16) & 0xff, c.left);
     }
 }
@@ -402,7 +516,7 @@ __device__ __forceinline__ void kd_update_orders(const Params& P, const Smem& s,
 // pruning, which only drops candidates that would be rejected): nearer child first, a leaf in permutation order.  Serial on
 // the lane; runs only for simulators with an exact distance tie.
 __device__ __forceinline__ void kd_visit_order(const Params& P, const Smem& s, const Lane& L, int g) {
-    const KdSmem& k = s.kd;
+    const KdSmem k = kd_view(P, s);
     const int el = L.ebase / P.A, t = kd_tree_of(L.a, P.robot_visible);
     const KdNode* cur = k.nodes + ((size_t)(g * P.E + el) * 2 + t) * k.mn;
     const int n_cur = kd_tree_on(P.A, t, P.robot_visible) ? k.count[(g * P.E + el) * 2 + t] : 0;
@@ -441,6 +555,87 @@ __device__ __forceinline__ void kd_visit_order(const Params& P, const Smem& s, c
         } else {
             for (int p = b; p < en; ++p) vis[row[p]] = (uint8_t)next++;
         }
+    }
+}
+
+// Second sweep of the 20-candidate pair phase (orca_phases, two_sweeps): lane = (agent, slot), 6 agents per pass of a wave
+// (lanes 60..63 idle): the half-plane of every kept neighbour, the number kept.  DETECT: a simulator has an exact distance tie
+// that RVO2's visiting order decides if two of its kept neighbours are equally far (adjacent slots) or the last kept one is
+// as far as the nearest dropped one.
+template <bool DETECT>
+__device__ __forceinline__ void pair_sweep2(const Params& P, const Smem& s) {
+    const int* kept = reinterpret_cast<const int*>(s.proj);
+    const int wl = threadIdx.x & (kWave - 1), g = wl / 10, slot = wl - g * 10;
+    const int waves = (P.threads + kWave - 1) / kWave;
+    const KdSmem k = DETECT ? kd_view(P, s) : KdSmem{};
+    for (int q0 = (threadIdx.x / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
+        const int q = q0 + g;
+        const bool lane_ok = wl < 60 && q < P.nA;
+        const int e = lane_ok ? kept[q * 10 + slot] : -1;
+        const bool valid = e >= 0;
+        const unsigned long long vm = __ballot(valid);
+        const int qq = lane_ok ? q : 0;
+        const int ol = valid ? (e & 0xff) : qq;  // unused slots: a finite dummy (the agent against itself), not stored
+        const bool robot_sim = (e >> 8) & 1;
+        const float4 me = s.kin[qq];
+        const float4 ot = s.kin[ol];
+        const float rq_r = s.rview[qq], ro_r = s.rview[ol], rq_h = s.hview[qq], ro_h = s.hview[ol];
+        const float rsum = (valid && robot_sim) ? rq_r + ro_r : rq_h + ro_h;
+        if (lane_ok && slot == 0) s.count[q] = __popcll((vm >> (10 * g)) & 0x3ffull);
+        if (valid)
+            s.lines[q * kLineStride + slot] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
+        if (DETECT) {
+            const float ddx = me.x - ot.x, ddy = me.y - ot.y;
+            const float dsq = ddx * ddx + ddy * ddy;  // = s.d2 of the pair (same operands, same operations)
+            // the previous slot's distance: DPP wave_shr 1 (a ds_bpermute would cost an LDS round trip per pass)
+            const float before = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dsq), 0x138, 0xf, 0xf, false));
+            const bool tie = valid && ((slot > 0 && before == dsq) || (slot == 9 && dsq == k.dnext[qq]));
+            if (tie) k.tie[qq] = 1;
+        }
+    }
+}
+
+// Exact distance ties (rare: never in random scenes): work out RVO2's visiting order for the simulators that have one and rank
+// their candidates again, ties by visiting order.  (Tried as a real call, __attribute__((noinline)): the mere presence of a call
+// cost the 20-human rollout 4-5 % on every step — 62.3 vs 59.4 M env-steps/s instrumented — so it is inlined, and the few
+// registers the rare path spills go to scratch.)  All threads of the workgroup (barriers inside).
+__device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, const Lane& L, int kd_gen, int two_sweeps) {
+    const KdSmem k = kd_view(P, s);
+    const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
+    if (L.lane < P.nA && k.tie[L.lane] != 0) kd_visit_order(P, s, L, kd_gen);
+    __syncthreads();
+    int* kept = reinterpret_cast<int*>(s.proj);
+    for (int p = L.lane; p < P.pairs; p += P.threads) {
+        const int info = s.pinfo[p];
+        const int q = info & 0xff, c = (info >> 16) & 0xff, ol = (info >> 8) & 0xff;
+        if (k.tie[q] == 0) continue;
+        const int qb = q / P.A * P.A;
+        const uint8_t* vq = k.visit + (size_t)q * k.row;
+        const float mine = s.d2[p];
+        const float* row = s.d2 + (p - c);
+        const int my_visit = vq[ol - qb];
+        int rank = 0;
+        for (int kk = 0; kk < P.NC; ++kk) {
+            const float v = row[kk];
+            const int visit = vq[((s.pinfo[p - c + kk] >> 8) & 0xff) - qb];
+            rank += (v < range_sq ? 1 : 0) & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (visit < my_visit ? 1 : 0)));
+        }
+        if (mine < range_sq && rank < P.orca.max_neighbors) {
+            const bool robot_sim = (info >> 25) & 1;
+            if (two_sweeps) {
+                kept[q * 10 + rank] = ol | ((robot_sim ? 1 : 0) << 8);
+            } else {
+                const float4 me = s.kin[q];
+                const float4 ot = s.kin[ol];
+                const float rsum = robot_sim ? s.rview[q] + s.rview[ol] : s.hview[q] + s.hview[ol];
+                s.lines[q * kLineStride + rank] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
+            }
+        }
+    }
+    __syncthreads();
+    if (two_sweeps) {
+        pair_sweep2<false>(P, s);
+        __syncthreads();
     }
 }
 
@@ -495,7 +690,9 @@ struct PhaseClock {};
 #define CN_PAR_LP5 1
 #endif
 
-template <int MAXL>
+// KD (compile time): the instantiation carries the kd-tree bookkeeping of simulators with more than 10 agents (kd_order.h);
+// crowds of at most 9 humans run the one without it.
+template <int MAXL, bool KD>
 __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
                                             float robot_max_speed, bool solve, float& out_vx, float& out_vy,
                                             PhaseClock* clk = nullptr) {
@@ -514,7 +711,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     };
     if (MAXL == 10 && P.NC == 20 && P.orca.max_neighbors == 10) {  // two-sweep pair phase: no neighbour in any slot yet
         int4* kept4 = reinterpret_cast<int4*>(s.proj);
-        for (int i = threadIdx.x; i * 4 < P.nA * 10; i += blockDim.x) kept4[i] = make_int4(-1, -1, -1, -1);
+        for (int i = threadIdx.x; i * 4 < P.nA * 10; i += P.threads) kept4[i] = make_int4(-1, -1, -1, -1);
     }
     if (L.lane < P.nA) {
         s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
@@ -528,25 +725,37 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         } else if (kCoop3 || kCand3) {
             s.sol[L.lane] = make_float4(0.0f, 0.0f, max_speed, solve ? 1.0f : 0.0f);
         }
-        if (P.kd) {
-            s.kd.tie[L.lane] = 0;
-            s.kd.dnext[L.lane] = std::numeric_limits<float>::infinity();
+        if (KD) {
+            const KdSmem k = kd_view(P, s);
+            k.tie[L.lane] = 0;
+            k.dnext[L.lane] = std::numeric_limits<float>::infinity();
         }
     }
     __syncthreads();
     // simulators of more than 10 agents: this step's kd-tree(s) and every simulator's permutation (kd_order.h); the visiting
     // order itself is only worked out further down if a simulator turns out to have an exact distance tie
-    int kd_gen = 0;
-    if (P.kd) {
-        kd_gen = *s.kd.gen;
-        kd_build_trees(P, s, L, kd_gen);
+    int kd_gen = 0;  // the generation of node lists that holds this step's tree
+    if (KD) {
+        const int g_last = *kd_view(P, s).gen;
+        CN_TICK(clk, 0);
+        if (P.E == 1 && P.threads == kWave) {
+            kd_gen = kd_build_trees_wave(P, s, L, g_last);
+            __syncthreads();  // (one wave: orders the builder's LDS records before the simulator lanes read them)
+        } else {
+            kd_gen = g_last ^ 1;
+            kd_build_trees(P, s, L, kd_gen);
+        }
+        CN_TICK(clk, 4);  // (probe builds: the tree build is booked under "robot action publish")
+#if defined(CN_PHASE_TIMING) && defined(CN_X_COUNT_REBUILD)
+        if (clk && kd_gen != g_last) clk->acc[9] += 1000;  // rebuilds, in thousandths of the "agents in the fallback" line
+#endif
         kd_update_orders(P, s, L, kd_gen);
-        if (threadIdx.x == 0) *s.kd.gen = kd_gen ^ 1;  // this step's node lists are the next step's "last step"
+        if (threadIdx.x == 0) *kd_view(P, s).gen = kd_gen;
     }
     CN_TICK(clk, 0);
 
     // pairs-1: squared distances, self.pos - other.pos (Appendix A.2)
-    for (int p = L.lane; p < P.pairs; p += blockDim.x) {
+    for (int p = L.lane; p < P.pairs; p += P.threads) {
         const int info = s.pinfo[p];
         const float4 me = s.kin[info & 0xff];
         const float4 ot = s.kin[(info >> 8) & 0xff];
@@ -564,38 +773,6 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     // the half-plane is computed in a second sweep over the (agent, kept slot) lanes only — 210 of the 420 ordered pairs,
     // four passes of a wave instead of seven.  Same comparisons and the same half-plane arithmetic: bit-identical.
     const bool two_sweeps = MAXL == 10 && P.NC == 20 && P.orca.max_neighbors == 10;
-    // second sweep of that path: lane = (agent, slot), 6 agents per pass of a wave (lanes 60..63 idle).  detect_ties: a
-    // simulator has an exact distance tie that RVO2's visiting order decides if two of its kept neighbours are equally far
-    // (adjacent slots) or the last kept one is as far as the nearest dropped one.
-    auto sweep2 = [&](bool detect_ties) {
-        const int* kept = reinterpret_cast<const int*>(s.proj);
-        const int wl = threadIdx.x & (kWave - 1), g = wl / 10, slot = wl - g * 10;
-        const int waves = (blockDim.x + kWave - 1) / kWave;
-        for (int q0 = (threadIdx.x / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
-            const int q = q0 + g;
-            const bool lane_ok = wl < 60 && q < P.nA;
-            const int e = lane_ok ? kept[q * 10 + slot] : -1;
-            const bool valid = e >= 0;
-            const unsigned long long vm = __ballot(valid);
-            const int qq = lane_ok ? q : 0;
-            const int ol = valid ? (e & 0xff) : qq;  // unused slots: a finite dummy (the agent against itself), not stored
-            const bool robot_sim = (e >> 8) & 1;
-            const float4 me = s.kin[qq];
-            const float4 ot = s.kin[ol];
-            const float rq_r = s.rview[qq], ro_r = s.rview[ol], rq_h = s.hview[qq], ro_h = s.hview[ol];
-            const float rsum = (valid && robot_sim) ? rq_r + ro_r : rq_h + ro_h;
-            if (lane_ok && slot == 0) s.count[q] = __popcll((vm >> (10 * g)) & 0x3ffull);
-            if (valid)
-                s.lines[q * kLineStride + slot] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
-            if (P.kd && detect_ties) {
-                const float ddx = me.x - ot.x, ddy = me.y - ot.y;
-                const float dsq = ddx * ddx + ddy * ddy;  // = s.d2 of the pair (same operands, same operations)
-                const float before = __shfl_up(dsq, 1);
-                const bool tie = valid && ((slot > 0 && before == dsq) || (slot == 9 && dsq == s.kd.dnext[qq]));
-                if (tie) s.kd.tie[qq] = 1;
-            }
-        }
-    };
     if (two_sweeps) {
         // kept [nA][10]: candidate lane | robot's-sim bit << 8 of the pair that ranks there, -1 = no such neighbour (cleared in
         // the stage phase; proj is free until the solve).  A pair inside the range ranks by (v < mine) | (v == mine & k < c)
@@ -603,7 +780,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         // the ranks of an agent's in-range candidates are a permutation of 0 .. within - 1, so the neighbours kept are
         // exactly the filled slots and their number falls out of the second sweep's ballot.
         int* kept = reinterpret_cast<int*>(s.proj);
-        for (int p = L.lane; p < P.pairs; p += blockDim.x) {
+        float* const dnext = KD ? kd_view(P, s).dnext : nullptr;
+        for (int p = L.lane; p < P.pairs; p += P.threads) {
             const int info = s.pinfo[p];
             const int c = (info >> 16) & 0xff;
             const float mine = s.d2[p];
@@ -618,12 +796,15 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 #pragma unroll
             for (int k = 0; k < 20; ++k) rank += ((v[k] < mine) | ((v[k] == mine) & (k < c))) ? 1 : 0;
             if (mine < range_sq && rank < 10) kept[(info & 0xff) * 10 + rank] = ((info >> 8) & 0xff) | (((info >> 25) & 1) << 8);
-            if (P.kd && mine < range_sq && rank == 10) s.kd.dnext[info & 0xff] = mine;  // the nearest one that is dropped
+            if (KD && mine < range_sq && rank == 10) dnext[info & 0xff] = mine;  // the nearest one that is dropped
         }
         __syncthreads();
-        sweep2(true);
+        if (KD)
+            pair_sweep2<true>(P, s);
+        else
+            pair_sweep2<false>(P, s);
     } else
-    for (int p = L.lane; p < P.pairs; p += blockDim.x) {
+    for (int p = L.lane; p < P.pairs; p += P.threads) {
         const int info = s.pinfo[p];
         const int q = info & 0xff, c = (info >> 16) & 0xff;
         const float mine = s.d2[p];
@@ -636,7 +817,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             same += v == mine ? 1 : 0;  // itself included
             rank += in & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (k < c ? 1 : 0)));
         }
-        if (P.kd && mine < range_sq && same > 1) s.kd.tie[q] = 1;  // an exact tie: RVO2's kd-tree visiting order decides
+        if (KD && mine < range_sq && same > 1) kd_view(P, s).tie[q] = 1;  // an exact tie: RVO2's kd-tree visiting order decides
         if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
         if (mine < range_sq && rank < P.orca.max_neighbors) {
             const int ol = (info >> 8) & 0xff;
@@ -649,53 +830,17 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         }
     }
     __syncthreads();
-    if (P.kd) {
-        const bool my_tie = L.lane < P.nA && s.kd.tie[L.lane] != 0;
-        if (__syncthreads_or(my_tie ? 1 : 0)) {  // rare: rank the candidates of those simulators again, ties by visiting order
-            if (my_tie) kd_visit_order(P, s, L, kd_gen);
-            __syncthreads();
-            int* kept = reinterpret_cast<int*>(s.proj);
-            for (int p = L.lane; p < P.pairs; p += blockDim.x) {
-                const int info = s.pinfo[p];
-                const int q = info & 0xff, c = (info >> 16) & 0xff, ol = (info >> 8) & 0xff;
-                if (s.kd.tie[q] == 0) continue;
-                const int qb = q / P.A * P.A;
-                const uint8_t* vq = s.kd.visit + (size_t)q * s.kd.row;
-                const float mine = s.d2[p];
-                const float* row = s.d2 + (p - c);
-                const int my_visit = vq[ol - qb];
-                int rank = 0;
-                for (int k = 0; k < P.NC; ++k) {
-                    const float v = row[k];
-                    const int visit = vq[((s.pinfo[p - c + k] >> 8) & 0xff) - qb];
-                    rank += (v < range_sq ? 1 : 0) & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (visit < my_visit ? 1 : 0)));
-                }
-                if (mine < range_sq && rank < P.orca.max_neighbors) {
-                    const bool robot_sim = (info >> 25) & 1;
-                    if (two_sweeps) {
-                        kept[q * 10 + rank] = ol | ((robot_sim ? 1 : 0) << 8);
-                    } else {
-                        const float4 me = s.kin[q];
-                        const float4 ot = s.kin[ol];
-                        const float rsum = robot_sim ? s.rview[q] + s.rview[ol] : s.hview[q] + s.hview[ol];
-                        s.lines[q * kLineStride + rank] =
-                            make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
-                    }
-                }
-            }
-            __syncthreads();
-            if (two_sweeps) {
-                sweep2(false);
-                __syncthreads();
-            }
-        }
+    if (KD) {
+        const KdSmem k = kd_view(P, s);
+        const bool my_tie = L.lane < P.nA && k.tie[L.lane] != 0;
+        if (__syncthreads_or(my_tie ? 1 : 0)) kd_resolve_ties(P, s, L, kd_gen, two_sweeps ? 1 : 0);
     }
     CN_TICK(clk, 2);
 
     out_vx = 0.0f, out_vy = 0.0f;
     if (kPar) {
         // candidates: lane = (agent, half-plane)
-        for (int p = threadIdx.x; p < P.nA * MAXL; p += blockDim.x) {
+        for (int p = threadIdx.x; p < P.nA * MAXL; p += P.threads) {
             const int q = p / MAXL, k = p - q * MAXL;
             const float4 so = s.sol[q];
             const float4* lq = s.lines + q * kLineStride;
@@ -729,7 +874,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             __syncthreads();
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int items = s.todo[P.nA] * kPairs;
-            for (int p = threadIdx.x; p < items; p += blockDim.x) {  // projections: lane = (agent, i, j)
+            for (int p = threadIdx.x; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
                 const int t = p / kPairs, m = p - t * kPairs;
                 const int a = s.todo[t];
                 const int i = lp3_program_of(m), j = m - i * (i - 1) / 2;
@@ -737,7 +882,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
             }
             __syncthreads();
-            for (int p = threadIdx.x; p < items; p += blockDim.x) {  // their candidates: lane = (agent, i, k)
+            for (int p = threadIdx.x; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
                 const int t = p / kPairs, m = p - t * kPairs;
                 const int a = s.todo[t];
                 const int i = lp3_program_of(m), base = i * (i - 1) / 2;
@@ -799,7 +944,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 for (int t0 = 0; t0 < n_todo; t0 += kLp3Agents) {
                     const int nt = n_todo - t0 < kLp3Agents ? n_todo - t0 : kLp3Agents;
                     const int items = nt * kPairs;
-                    for (int p = threadIdx.x; p < items; p += blockDim.x) {  // projections: lane = (agent, i, j)
+                    for (int p = threadIdx.x; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
                         const int t = p / kPairs, m = p - t * kPairs;
                         const int a = s.todo[t0 + t];
                         const int i = lp3_program_of_n<MAXL>(m), j = m - i * (i - 1) / 2;
@@ -807,7 +952,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                         projc[p] = lp3_project(la[i], la[j]);
                     }
                     __syncthreads();
-                    for (int p = threadIdx.x; p < items; p += blockDim.x) {  // their candidates: lane = (agent, i, k)
+                    for (int p = threadIdx.x; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
                         const int t = p / kPairs, m = p - t * kPairs;
                         const int a = s.todo[t0 + t];
                         const int i = lp3_program_of_n<MAXL>(m), base = i * (i - 1) / 2;
@@ -863,14 +1008,14 @@ __device__ __forceinline__ double python_fmod(double x, double y) {  // python's
 
 // UNI (compile time): the robot may be a unicycle.  The holonomic instantiation carries none of that code — it sits
 // inside the fused rollout loop, where 20 extra VGPRs and a few dead branches cost 7 % (712 -> 665 M env-steps/s).
-template <int MAXL, bool UNI>
+template <int MAXL, bool UNI, bool KD>
 __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
                                           double& gtime, float robot_max_speed, const double* ext_action,
                                           int update, StepResult& res, double& new_vx, double& new_vy,
                                           double* theta_io = nullptr, PhaseClock* clk = nullptr) {
     (void)clk;
     float ovx, ovy;
-    orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
+    orca_phases<MAXL, KD>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
     new_vx = ovx;
     new_vy = ovy;
     // unicycle robot (ActionRot v, r): the collision test uses v (cos, sin)(r + theta) (crowd_sim.py:339-341), the
@@ -976,7 +1121,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
 
 // ---------------------------------------------------------------------------------------------- kernels
 
-template <int MAXL>
+template <int MAXL, bool KD>
 __global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, float* out_vel) {
     const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
@@ -985,10 +1130,10 @@ __global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, 
     float robot_max_speed;
     load_robot_view(P, S, s, L, r, robot_max_speed);
     build_pairs(P, s);
-    kd_load(P, S, s, L);
+    if (KD) kd_load(P, S, s, L);
     float vx, vy;
-    orca_phases<MAXL>(P, s, L, r, robot_max_speed, L.valid, vx, vy);
-    kd_store(P, S, s, L);
+    orca_phases<MAXL, KD>(P, s, L, r, robot_max_speed, L.valid, vx, vy);
+    if (KD) kd_store(P, S, s, L);
     if (L.valid) {
         out_vel[2 * L.gi] = vx;
         out_vel[2 * L.gi + 1] = vy;
@@ -996,7 +1141,7 @@ __global__ __launch_bounds__(kMaxBlock) void orca_kernel(Params P, StateView S, 
     }
 }
 
-template <int MAXL, bool UNI>
+template <int MAXL, bool UNI, bool KD>
 __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, StepIo io) {
     const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
@@ -1005,15 +1150,15 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
     float robot_max_speed = 0.0f;
     if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
     build_pairs(P, s);
-    kd_load(P, S, s, L);
+    if (KD) kd_load(P, S, s, L);
     double gtime = (L.valid && L.a == 0) ? S.gtime[L.env] : 0.0;
     const AgentRegs before = r;
 
     double theta = (L.valid && L.a == 0) ? S.theta[L.env] : 0.0;
     StepResult res;
     double nvx, nvy;
-    step_core<MAXL, UNI>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta);
-    kd_store(P, S, s, L);  // (a lookahead rebuilds the humans' trees too: the reference's onestep_lookahead runs doStep)
+    step_core<MAXL, UNI, KD>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta);
+    if (KD) kd_store(P, S, s, L);  // (a lookahead rebuilds the humans' trees too: the reference's onestep_lookahead runs doStep)
     if (!L.valid) return;
 
     if (L.a == 0) {
@@ -1484,9 +1629,13 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
 #ifndef CN_MAXL10_WAVES
 #define CN_MAXL10_WAVES 1
 #endif
-template <int MAXL, bool UNI, bool HEADLINE = false>
-__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void rollout_kernel(Params P_in, StateView S, RolloutView R, int n_steps,
-                                                            const double* ext_action) {
+template <int MAXL, bool UNI, bool HEADLINE = false, bool KD = false>
+__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
+                                                            RolloutView R, int n_steps, const double* ext_action) {
+    // The ~20 state pointers are needed before and after the step loop and when an episode ends, never inside a step: they
+    // are re-read from the engine's device copy of the StateView there (scalar loads) instead of holding 40 SGPRs — spilled
+    // into VGPR lanes, and at 10 half-planes pushing vector registers into scratch — across the loop.  ring_filled_in is the
+    // one pointer the host swaps between launches (fill_ring_if_needed), hence a direct argument.
     // HEADLINE: the geometry of BASELINE configs[1] (5 humans + robot, 2 envs per 64-lane workgroup) as compile-time
     // constants — the pair loops become single passes, the 5-candidate rank loop unrolls, divisions by A / NC fold:
     // 706 -> 740 M env-steps/s.  Every other geometry runs the generic instantiation.
@@ -1497,17 +1646,21 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
-    if (L.valid) load_agent(S, L.gi, r);
     float robot_max_speed = 0.0f;
-    if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
-    build_pairs(P, s);
-    kd_load(P, S, s, L);
-
     const bool robot = L.valid && L.a == 0;
-    double theta = robot ? S.theta[L.env] : 0.0;  // heading of a unicycle robot (external actions only)
+    double theta = 0.0;  // heading of a unicycle robot (external actions only)
     double gtime = 0.0, cur_return = 0.0, cur_dsum = 0.0;
     int cur_steps = 0, cur_danger = 0, ep_count = 0, ring_filled = 0, state = kRetired;
+    {
+        const StateView S = *Sd;
+        if (L.valid) load_agent(S, L.gi, r);
+        if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
+        if (KD) kd_load(P, S, s, L);
+        if (robot) theta = S.theta[L.env];
+    }
+    build_pairs(P, s);
     if (robot) {
+        const StateView S = *Sd;
         const cn_rollout_io io = *R.io;
         gtime = S.gtime[L.env];
         state = io.active[L.env];
@@ -1516,7 +1669,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         cur_return = io.cur_return[L.env];
         if (io.cur_danger) cur_danger = io.cur_danger[L.env];
         if (io.cur_danger_dmin_sum) cur_dsum = io.cur_danger_dmin_sum[L.env];
-        ring_filled = S.ring_filled_in[L.env];
+        ring_filled = ring_filled_in[L.env];
         int f = state == kRunning ? 1 : 0;
         if (state == kWaitingScenario && scenario_ready(P, S, L.env, ep_count, ring_filled)) {  // produced since
             f = 2 + ep_count % P.ring_depth;
@@ -1527,8 +1680,8 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     }
     __syncthreads();
     if (L.valid && s.flag[L.ebase] >= 2) {
-        load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
-        kd_new_episode(P, s, L);
+        load_from_ring(P, *Sd, L, s.flag[L.ebase] - 2, r);
+        if (KD) kd_new_episode(P, s, L);
         theta = 1.5707963267948966;
     }
     unsigned int transitions = 0;
@@ -1548,7 +1701,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
 
         StepResult res;
         double nvx, nvy;
-        step_core<MAXL, UNI>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
+        step_core<MAXL, UNI, KD>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
 
         if (robot && state == kRunning) {
             int next_flag = 1;
@@ -1561,7 +1714,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
                 cur_dsum += res.dmin;
             }
             if (res.done) {
-                next_flag = finish_episode(P, S, R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
+                next_flag = finish_episode(P, *Sd, R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
                                            cur_steps, cur_return, cur_danger, cur_dsum, state);
                 cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
                 gtime = 0.0;
@@ -1570,8 +1723,8 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         }
         __syncthreads();
         if (L.valid && s.flag[L.ebase] >= 2) {
-            load_from_ring(P, S, L, s.flag[L.ebase] - 2, r);
-            kd_new_episode(P, s, L);
+            load_from_ring(P, *Sd, L, s.flag[L.ebase] - 2, r);
+            if (KD) kd_new_episode(P, s, L);
             theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
         }
         CN_TICK(clk, 7);
@@ -1583,7 +1736,8 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     }
 #endif
 
-    kd_store(P, S, s, L);
+    const StateView S = *Sd;
+    if (KD) kd_store(P, S, s, L);
     if (L.valid) {
         S.pos[L.gi] = make_double2(r.px, r.py);
         S.vel[L.gi] = make_double2(r.vx, r.vy);
