@@ -33,7 +33,7 @@ constexpr int kKdLeaf = 10;  // RVO2 MAX_LEAF_SIZE
 
 struct KdNode {      // a node that splits, of one (env, tree)
     uint32_t meta;   // begin | end << 8 | n_left << 16 | degenerate << 24
-    uint32_t ext;    // env-local agents that attain min x | max x << 8 | min y << 16 | max y << 24 of the node's bounding box
+    uint32_t pad0;
     uint64_t left;   // env-local agents on the lower side of the split
     uint64_t set;    // env-local agents of the node
     uint64_t pad;

@@ -389,48 +389,19 @@ __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, c
 // The same for the usual geometry of these crowds — one env per single-wave workgroup: every quantity of a node is uniform
 // over the wave, so the bounding box is four DPP wave reductions, the lower side a ballot, and the control flow scalar: no LDS
 // atomics, no barriers (the cooperative version above spent ~1 400 clock ticks per node on them).
-// Most steps (84 % at 20 humans) leave the tree as it was, and that can be PROVED for a fraction of a rebuild: if the four
-// agents that attained a node's bounding box last time still bound every member, the box is theirs; with it the split; and if
-// every member is still on its old side of it, the node's record — and, node by node, the whole tree — is unchanged: then
-// nothing is written and no simulator has anything to do.  Returns the generation that holds this step's lists.
+// Built every step although 84 % of the steps (20 humans) leave the tree as it was.  Proving "unchanged" first — the four
+// agents that attained a node's box last time still bound its members, every member still on its side of the new split: one
+// vector pass over (node, agent) lanes, nearly free — was built and measured: the 29 % of steps that then DID rebuild paid
+// 12 900 clock ticks each instead of 3 100, because code a wave executes once in a while is not in the instruction cache
+// when it comes (the step loop of this kernel is ~45 KB by itself), 3 780 vs 3 100 ticks per step on average.  What the
+// builder does hand on is the first node whose record differs from last step's: in unchanged steps the simulator lanes do
+// nothing.  Returns the generation that holds this step's lists.
 __device__ __forceinline__ int kd_build_trees_wave(const Params& P, const Smem& s, const Lane& L, int g_last) {
     const KdSmem k = kd_view(P, s);
     const bool agent = L.lane < P.nA;  // = L.lane < P.A: one env
     const float4 me = agent ? s.kin[L.lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const uint32_t kx = kd_key(me.x), ky = kd_key(me.y);
     const uint64_t amask = P.A >= 64 ? ~0ull : ((1ull << P.A) - 1ull);
-    // ---- unchanged?
-    bool same = true;
-    for (int t = 0; t < 2 && same; ++t) {
-        if (!kd_tree_on(P.A, t, P.robot_visible)) continue;
-        const KdNode* old = k.nodes + ((size_t)g_last * 2 + t) * k.mn;
-        const int n_old = k.count[g_last * 2 + t];
-        same = n_old > 0;
-        for (int r = 0; r < n_old && same; ++r) {
-            const KdNode od = old[r];
-            const bool member = agent && ((od.set >> L.lane) & 1ull) != 0ull;
-            const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)kx, od.ext & 0xff);
-            const uint32_t x1 = (uint32_t)__builtin_amdgcn_readlane((int)kx, (od.ext >> 8) & 0xff);
-            const uint32_t y0 = (uint32_t)__builtin_amdgcn_readlane((int)ky, (od.ext >> 16) & 0xff);
-            const uint32_t y1 = (uint32_t)__builtin_amdgcn_readlane((int)ky, (od.ext >> 24) & 0xff);
-            const float min_x = kd_unkey(x0), max_x = kd_unkey(x1), min_y = kd_unkey(y0), max_y = kd_unkey(y1);
-            const bool vertical = (max_x - min_x) > (max_y - min_y);
-            const float split = vertical ? 0.5f * (max_x + min_x) : 0.5f * (max_y + min_y);
-            const bool inside = kx >= x0 && kx <= x1 && ky >= y0 && ky <= y1;
-            const bool lower = (vertical ? me.x : me.y) < split;
-            const bool was_lower = ((od.left >> L.lane) & 1ull) != 0ull;
-            const bool moved = member && (!inside || lower != was_lower);
-            same = __ballot(moved) == 0ull && ((od.meta >> 24) & 1u) == 0u;
-        }
-    }
-    if (same) {
-        if (L.lane == 0) {
-            k.dirty[0] = k.count[g_last * 2 + 0];
-            k.dirty[1] = k.count[g_last * 2 + 1];
-        }
-        return g_last;
-    }
-    // ---- rebuild into the other generation
     const int g = g_last ^ 1;
     for (int t = 0; t < 2; ++t) {
         KdNode* list = k.nodes + ((size_t)g * 2 + t) * k.mn;
@@ -457,11 +428,6 @@ __device__ __forceinline__ int kd_build_trees_wave(const Params& P, const Smem& 
             const bool vertical = (max_x - min_x) > (max_y - min_y);
             const float split = vertical ? 0.5f * (max_x + min_x) : 0.5f * (max_y + min_y);
             const uint64_t lm = __ballot(member && (vertical ? me.x : me.y) < split) & amask;
-            // the members that attain the box (any one of them each: the box is what matters)
-            const uint32_t ext = (uint32_t)(__ffsll((long long)__ballot(member && kx == b0)) - 1) |
-                                 ((uint32_t)(__ffsll((long long)__ballot(member && kx == b1)) - 1) << 8) |
-                                 ((uint32_t)(__ffsll((long long)__ballot(member && ky == b2)) - 1) << 16) |
-                                 ((uint32_t)(__ffsll((long long)__ballot(member && ky == b3)) - 1) << 24);
             const int begin = nd.meta & 0xff, end = (nd.meta >> 8) & 0xff, nl = __popcll(lm);
             const bool degenerate = nl == 0;
             const uint32_t meta = (uint32_t)begin | ((uint32_t)end << 8) | ((uint32_t)nl << 16) | (degenerate ? 1u << 24 : 0u);
@@ -470,7 +436,6 @@ __device__ __forceinline__ int kd_build_trees_wave(const Params& P, const Smem& 
             const bool hi = !degenerate && end - begin - nl > kKdLeaf && n + (lo ? 1 : 0) < k.mn;
             if (L.lane == 0) {
                 list[r].meta = meta;
-                list[r].ext = ext;
                 list[r].left = lm;
                 if (lo) {
                     list[n].meta = (uint32_t)begin | ((uint32_t)(begin + nl) << 8);
@@ -746,9 +711,6 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             kd_build_trees(P, s, L, kd_gen);
         }
         CN_TICK(clk, 4);  // (probe builds: the tree build is booked under "robot action publish")
-#if defined(CN_PHASE_TIMING) && defined(CN_X_COUNT_REBUILD)
-        if (clk && kd_gen != g_last) clk->acc[9] += 1000;  // rebuilds, in thousandths of the "agents in the fallback" line
-#endif
         kd_update_orders(P, s, L, kd_gen);
         if (threadIdx.x == 0) *kd_view(P, s).gen = kd_gen;
     }
