@@ -210,6 +210,24 @@ __device__ __forceinline__ int lp_planar_scan(const float4* lines, const float4*
     return fail;
 }
 
+// The same scan for 10 half-planes: the slots are requested as the scan reaches them (two at a time by the unroller), not
+// all 20 float4 up front — 80 VGPRs that the 10-half-plane kernels do not have.
+template <int MAXL>
+__device__ __forceinline__ int lp_planar_scan_stream(const float4* lines, const float4* cand, int n, float& rx, float& ry) {
+    int fail = n;
+#pragma unroll 2
+    for (int k = 0; k < MAXL; ++k) {
+        const float4 lk = lines[k], ck = cand[k];
+        const float det = lk.z * (lk.y - ry) - lk.w * (lk.x - rx);
+        const bool viol = (k < fail) & (det > 0.0f);
+        const bool feasible = ck.z != 0.0f;
+        rx = (viol & feasible) ? ck.x : rx;
+        ry = (viol & feasible) ? ck.y : ry;
+        fail = (viol & !feasible) ? k : fail;
+    }
+    return fail;
+}
+
 // linearProgram3 (Appendix A.6) in the same form, for MAXL = 5: the projection of half-plane j onto half-plane i (j < i)
 // depends on nothing but the two half-planes, and the 1-D solution of projected half-plane k of program i on nothing but
 // the projections 0..k of that program — 10 (i, j) pairs and 10 (i, k) candidates per agent, one lane each
@@ -491,6 +509,83 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
                         cur2 = MAXL;
                     }
                 }
+            }
+            if (act) {
+                if (!failed) {
+                    rx = r2x;
+                    ry = r2y;
+                }
+                distance = li.z * (li.y - ry) - li.w * (li.x - rx);
+                icur = i + 1;
+            }
+        }
+        if (need && l == 0) res[a] = make_float4(rx, ry, r0.z, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------ 3-D fallback, candidate form evaluated lazily
+// linearProgram3 (Appendix A.6) for 10 half-planes.  The candidate form of lp3_scan_n computes the projections and 1-D
+// solutions of ALL 45 (i, j) pairs of an infeasible agent up front — at 5 half-planes (10 pairs) that is what makes the
+// fallback cheap, at 10 it costs as much as it saves, because the sequential program only ever visits the few outer
+// half-planes i whose violation exceeds the running distance (CN_CAND_LP3_10, rejected).  lp_relaxed_coop does visit only
+// those, but solves each projected planar program in ballot / shuffle rounds: one round per violated projected line, 18
+// ds_bpermute each.  This version keeps coop's outer structure — lane = (agent, half-plane), the agents of a pass advance
+// together to their next violated half-plane i — and solves the projected program of that ONE i in candidate form: lane l < i
+// projects its half-plane onto i (lp3_project), then computes the 1-D solution of projected line l against projected lines
+// 0 .. l-1 (lp_line_candidate, direction objective), both through the agent's LDS rows; then every lane of the agent runs the
+// same short scan over the ≤ 9 candidates (no broadcast needed).  Same operations on the same operands as the sequential
+// program: bit-identical.  One round costs ~300 instructions whatever the number of violated projected lines.
+//   lines [nA][kLineStride]; proj [nA][kLineStride] scratch rows; cand: (kWave / MAXL) * (MAXL - 1) float4 of scratch per WAVE
+//   (one row per agent of the pass); res [nA] in: (result, int bits: first infeasible line), out: result; todo [n_todo]: the
+//   agents that need the fallback, compacted (kWave / MAXL of them share a pass)
+template <int MAXL>
+__device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* proj, float4* cand, const int* count,
+                                                const float4* sol, float4* res, const int* todo, int n_todo, int threads) {
+    constexpr int G = kWave / MAXL;
+    constexpr unsigned kField = (1u << MAXL) - 1u;
+    const int wl = threadIdx.x & (kWave - 1);
+    const int g = wl / MAXL, l = wl - g * MAXL;
+    const int gbase = g * MAXL;
+    const int waves = (threads + kWave - 1) / kWave;
+    for (int chunk = threadIdx.x / kWave; chunk * G < n_todo; chunk += waves) {
+        const bool live = g < G && chunk * G + g < n_todo;
+        const int a = live ? todo[chunk * G + g] : 0;
+        const float4 r0 = res[a];
+        const int n = live ? count[a] : 0;
+        const int begin = __float_as_int(r0.z);
+        const bool need = live && begin < n;
+        const float radius = sol[a].z;
+        const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* const prow = proj + a * kLineStride;
+        float4* const crow = cand + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * (MAXL - 1);
+        float rx = r0.x, ry = r0.y, distance = 0.0f;
+        int icur = need ? begin : n;
+        while (true) {
+            const bool cond = l >= icur && l < n && (my.z * (my.y - ry) - my.w * (my.x - rx) > distance);
+            const unsigned long long m = __ballot(cond);
+            if (m == 0ull) break;
+            const unsigned gm = (unsigned)(m >> gbase) & kField;
+            const bool act = gm != 0u;
+            const int i = act ? __ffs(gm) - 1 : 0;
+            const float4 li = lines[a * kLineStride + i];
+            // my half-plane projected onto half-plane i (the ones RVO2 leaves out, and lanes l >= i, hold an inert line)
+            const float4 pr = (act && l < i) ? lp3_project(li, my) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && l < MAXL - 1) prow[l] = pr;
+            // 1-D solution on projected line l against projected lines 0 .. l-1, optimising along the normal of half-plane i
+            const float4 cd = lp_line_candidate<MAXL - 2>(pr, prow, l, radius, -li.w, li.z, true);
+            if (live && l < MAXL - 1) crow[l] = cd;
+            // linearProgram2 over the projected lines as a scan of the candidates (every lane of the agent, identically)
+            float r2x = -li.w * radius, r2y = li.z * radius;
+            bool failed = false;
+#pragma unroll
+            for (int k = 0; k < MAXL - 1; ++k) {
+                const float4 pk = prow[k], ck = crow[k];
+                const float det = pk.z * (pk.y - r2y) - pk.w * (pk.x - r2x);
+                const bool viol = (k < i) & !failed & (det > 0.0f);
+                const bool feasible = ck.z != 0.0f;
+                r2x = (viol & feasible) ? ck.x : r2x;
+                r2y = (viol & feasible) ? ck.y : r2y;
+                failed = failed | (viol & !feasible);
             }
             if (act) {
                 if (!failed) {

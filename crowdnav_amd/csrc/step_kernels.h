@@ -26,6 +26,18 @@
 
 namespace cn {
 
+// CN_CAND_LP10 (compile time, default on): MAXL = 10 solves in candidate form too — the planar program's 1-D solutions on
+// (agent, half-plane) lanes + a streaming scan per agent (instead of lp_planar_reg<10>: 10 half-planes in 40 VGPRs, ~1 500
+// fully unrolled instructions), and the 3-D fallback as lp_relaxed_lazy (orca_device.h) instead of lp_relaxed_coop's shuffle
+// rounds.  Less code (the step loop of the 20-human kernel was ~45 KB: instruction-cache bound) and far fewer live registers.
+// Measured at 20 humans (4096 envs, radius 12): planar program 7.8 k -> 15.1 k clock ticks per wave-step in candidate form (210
+// candidate lanes x 9 divisions: twice the work of the register program, which skips what it does not need), fallback
+// 25.7 k -> 18.5 k.  So the default, CN_CAND_LP10 = 2, keeps lp_planar_reg for the planar program and takes only the fallback
+// (lp_relaxed_lazy); 1 = both in candidate form; 0 = the round-2 kernels (lp_relaxed_coop).
+#ifndef CN_CAND_LP10
+#define CN_CAND_LP10 2
+#endif
+
 constexpr int kMaxBlock = 512;  // threads per workgroup of the transition kernels (1..8 waves)
 
 struct Params {
@@ -139,10 +151,10 @@ __host__ __device__ inline size_t proj_bytes(int nA, int maxl) {
     return (CN_CAND_LP3_10 != 0 && maxl == 10 && lp3 > rows) ? lp3 : rows;
 }
 
-// maxl: the candidate-form buffers (cand2, cand3) exist for the 5-half-plane kernels only — at 21 agents per env they
-// would cost the 10-half-plane kernels a resident workgroup per CU
+// maxl: the 5-half-plane kernels have two candidate-form buffers (cand2, cand3); the 10-half-plane kernels none (their lazy
+// fallback's candidate rows live in d2) unless built all-candidate-form (CN_CAND_LP10 == 1)
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl, int A = 0, int E = 1) {
-    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 3 : 1) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + proj_bytes(nA, maxl) +
+    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 || CN_CAND_LP10 == 1 ? 3 : 1) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + proj_bytes(nA, maxl) +
            (size_t)pairs * 8 + 64 + 8 + 16 + 16 + sizeof(double) * kMaxDiscount + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
 }
 
@@ -159,6 +171,9 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.proj = reinterpret_cast<float4*>(p), p += proj_bytes(nA, MAXL);
     s.cand2 = s.cand3 = nullptr;
     if (MAXL == 5) {
+        s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+        s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
+    } else if (CN_CAND_LP10 == 1) {  // the all-candidate-form build of the 10-half-plane kernels
         s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
         s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
     }
@@ -666,6 +681,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     constexpr bool kCand3 = (MAXL == 10) && (CN_CAND_LP3_10 != 0);  // candidate-form fallback, chunks of kLp3Agents agents
     constexpr bool kCoop3 = !kCand3 && ((MAXL == 5) ? (CN_COOP_LP3_5 != 0) : (CN_COOP_LP3_10 != 0));
     constexpr bool kPar = (MAXL == 5) && (CN_PAR_LP5 != 0) && !kCoop;
+    constexpr bool kCand10 = (MAXL == 10) && (CN_CAND_LP10 == 1) && !kCoop && !kCand3;
+    constexpr bool kLazy3 = (MAXL == 10) && (CN_CAND_LP10 == 2) && !kCoop && !kCand3;  // register planar program, lazy fallback
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
     auto preferred = [&](float& pref_x, float& pref_y) {
@@ -676,18 +693,18 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     };
     if (MAXL == 10 && P.NC == 20 && P.orca.max_neighbors == 10) {  // two-sweep pair phase: no neighbour in any slot yet
         int4* kept4 = reinterpret_cast<int4*>(s.proj);
-        for (int i = threadIdx.x; i * 4 < P.nA * 10; i += P.threads) kept4[i] = make_int4(-1, -1, -1, -1);
+        for (int i = L.lane; i * 4 < P.nA * 10; i += P.threads) kept4[i] = make_int4(-1, -1, -1, -1);
     }
     if (L.lane < P.nA) {
         s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
         s.posd[L.lane] = make_double2(r.px, r.py);
         s.rad[L.lane] = r.rad;
         s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
-        if (kCoop || kPar) {
+        if (kCoop || kPar || kCand10) {
             float pref_x, pref_y;
             preferred(pref_x, pref_y);
             s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
-        } else if (kCoop3 || kCand3) {
+        } else if (kCoop3 || kCand3 || kLazy3) {
             s.sol[L.lane] = make_float4(0.0f, 0.0f, max_speed, solve ? 1.0f : 0.0f);
         }
         if (KD) {
@@ -712,7 +729,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         }
         CN_TICK(clk, 4);  // (probe builds: the tree build is booked under "robot action publish")
         kd_update_orders(P, s, L, kd_gen);
-        if (threadIdx.x == 0) *kd_view(P, s).gen = kd_gen;
+        if (L.lane == 0) *kd_view(P, s).gen = kd_gen;
     }
     CN_TICK(clk, 0);
 
@@ -802,7 +819,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     out_vx = 0.0f, out_vy = 0.0f;
     if (kPar) {
         // candidates: lane = (agent, half-plane)
-        for (int p = threadIdx.x; p < P.nA * MAXL; p += P.threads) {
+        for (int p = L.lane; p < P.nA * MAXL; p += P.threads) {
             const int q = p / MAXL, k = p - q * MAXL;
             const float4 so = s.sol[q];
             const float4* lq = s.lines + q * kLineStride;
@@ -836,7 +853,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             __syncthreads();
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int items = s.todo[P.nA] * kPairs;
-            for (int p = threadIdx.x; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
+            for (int p = L.lane; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
                 const int t = p / kPairs, m = p - t * kPairs;
                 const int a = s.todo[t];
                 const int i = lp3_program_of(m), j = m - i * (i - 1) / 2;
@@ -844,7 +861,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
             }
             __syncthreads();
-            for (int p = threadIdx.x; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
+            for (int p = L.lane; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
                 const int t = p / kPairs, m = p - t * kPairs;
                 const int a = s.todo[t];
                 const int i = lp3_program_of(m), base = i * (i - 1) / 2;
@@ -856,6 +873,51 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             if (need)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
                          fail, max_speed, rx, ry);
+        }
+        out_vx = rx, out_vy = ry;
+    } else if (kCand10) {
+        // candidates of the planar program: lane = (agent, half-plane), four passes of a wave at 21 agents
+        for (int p = L.lane; p < P.nA * MAXL; p += P.threads) {
+            const int q = p / MAXL, k = p - q * MAXL;
+            const float4 so = s.sol[q];
+            const float4* lq = s.lines + q * kLineStride;
+            s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
+            if (k == 0) {
+                float sx, sy;
+                lp_start_point(so.z, so.x, so.y, sx, sy);
+                s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
+            }
+        }
+        __syncthreads();
+        float rx = 0.0f, ry = 0.0f;
+        int n = 0, fail = 0;
+        if (solve) {
+            n = s.count[L.lane];
+            const float4 start = s.res[L.lane];
+            rx = start.x, ry = start.y;
+            fail = lp_planar_scan_stream<MAXL>(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, rx, ry);
+        }
+        CN_TICK(clk, 3);
+        const bool need = solve && fail < n;
+#ifdef CN_PHASE_TIMING
+        if (clk) clk->acc[9] += __popcll(__ballot(need));
+#endif
+        if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+            if (L.lane < kWave) {
+                const unsigned long long nm = __ballot(need);
+                if (need) {
+                    s.res[L.lane] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
+                    s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
+                }
+                if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
+            }
+            __syncthreads();
+            lp_relaxed_lazy<MAXL>(s.lines, s.proj, s.cand3, s.count, s.sol, s.res, s.todo, s.todo[P.nA], P.threads);
+            __syncthreads();
+            if (need) {
+                const float4 got = s.res[L.lane];
+                rx = got.x, ry = got.y;
+            }
         }
         out_vx = rx, out_vy = ry;
     } else if (kCoop) {
@@ -906,7 +968,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 for (int t0 = 0; t0 < n_todo; t0 += kLp3Agents) {
                     const int nt = n_todo - t0 < kLp3Agents ? n_todo - t0 : kLp3Agents;
                     const int items = nt * kPairs;
-                    for (int p = threadIdx.x; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
+                    for (int p = L.lane; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
                         const int t = p / kPairs, m = p - t * kPairs;
                         const int a = s.todo[t0 + t];
                         const int i = lp3_program_of_n<MAXL>(m), j = m - i * (i - 1) / 2;
@@ -914,7 +976,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                         projc[p] = lp3_project(la[i], la[j]);
                     }
                     __syncthreads();
-                    for (int p = threadIdx.x; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
+                    for (int p = L.lane; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
                         const int t = p / kPairs, m = p - t * kPairs;
                         const int a = s.todo[t0 + t];
                         const int i = lp3_program_of_n<MAXL>(m), base = i * (i - 1) / 2;
@@ -928,7 +990,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                     __syncthreads();  // the next chunk overwrites the buffers
                 }
             }
-        } else if (kCoop3) {
+        } else if (kCoop3 || kLazy3) {
             if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible
                 if (L.lane < kWave) {  // agent lanes live in wave 0: compact the infeasible ones
                     const unsigned long long nm = __ballot(need);
@@ -939,7 +1001,12 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                     if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
                 }
                 __syncthreads();
-                lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
+                // (its candidate rows — 6 agents x 9 float4 per wave — live in d2, free after the pair phases: enough for one wave)
+                if (kLazy3 && P.threads == kWave && P.pairs * 4 >= (kWave / MAXL) * (MAXL - 1) * 16)
+                    lp_relaxed_lazy<MAXL>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
+                                          s.todo[P.nA], P.threads);
+                else
+                    lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
                 __syncthreads();
                 if (need) {
                     const float4 got = s.res[L.lane];
@@ -1658,7 +1725,11 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     PhaseClock* clk = nullptr;
 #endif
     for (int step = 0; step < n_steps; ++step) {
+        // The lane ids of this step are opaque to the compiler: everything derived from them — LDS addresses of every phase —
+        // is recomputed in the step instead of being hoisted out of the step loop and held in VGPRs across it (step_kernel,
+        // the same code without the loop, needs 92 VGPRs; this kernel needed 182 before).
         Lane Ls = L;
+        asm volatile("" : "+v"(Ls.lane), "+v"(Ls.a), "+v"(Ls.ebase));
         Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env is running
 
         StepResult res;
