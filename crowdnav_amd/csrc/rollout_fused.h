@@ -42,23 +42,29 @@ __device__ __forceinline__ T in_vgpr(T x) {
     return x;
 }
 
+// What the NEXT step's pair and collide phases read: the float32 view of the agents, float64 position, radii.
 __device__ __forceinline__ void stage_agent(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
-                                            float robot_max_speed, bool solve, double human_safety) {
+                                            double human_safety) {
     if (L.lane >= P.nA) return;
-    // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
-    const double gdx = r.gx - r.px, gdy = r.gy - r.py;
-    const double speed = norm2(gdx, gdy);
-    const float pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
-    const float pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
-    const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
     s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
     s.posd[L.lane] = make_double2(r.px, r.py);
     s.rad[L.lane] = r.rad;
     s.hview[L.lane] = (float)(r.rad + 0.01 + human_safety);
-    s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
-    float sx, sy;  // linearProgram2's start point (Appendix A.4): a function of the preferred velocity only
+}
+
+// The agent's preferred velocity — towards its goal, unit length once farther than 1 m (orca.py:113-115): a float64 norm and
+// two float64 divisions, ~450 clock ticks of dependent latency on 12 lanes — and linearProgram2's start point (Appendix A.4).
+// Nothing reads them before the candidates phase, so they are computed INSIDE the pair phase, branch-free on every lane: one
+// basic block with the float32 pair arithmetic, and the scheduler interleaves the two dependency chains.
+__device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max_speed, bool solve, float4& sol, float4& start) {
+    const double gdx = r.gx - r.px, gdy = r.gy - r.py;
+    const double speed = norm2(gdx, gdy);
+    const float pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
+    const float pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
+    sol = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
+    float sx, sy;
     lp_start_point(max_speed, pref_x, pref_y, sx, sy);
-    s.res[L.lane] = make_float4(sx, sy, 0.0f, 0.0f);
+    start = make_float4(sx, sy, 0.0f, 0.0f);
 }
 
 template <bool HEADLINE>
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     const double c_success = in_vgpr(P.success_reward), c_collision = in_vgpr(P.collision_penalty);
     const double c_ddist = in_vgpr(P.discomfort_dist), c_dfactor = in_vgpr(P.discomfort_factor);
     const double c_hsafety = in_vgpr(P.human_safety);
-    stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca), c_hsafety);
+    stage_agent(P, s, L, r, c_hsafety);
     __syncthreads();
 
 #ifdef CN_PHASE_TIMING
@@ -179,10 +185,17 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 within += in;
                 rank += in & before;
             }
+            // (agent lanes are pair lanes too: their preferred velocity, same block)
+            float4 sol4, start4;
+            preferred_velocity(r, (L.a == 0) ? robot_max_speed : (float)r.vpref, solve, sol4, start4);
             if (c == 0) s.count[q] = within < P.orca.max_neighbors ? within : P.orca.max_neighbors;
             if (mine < range_sq && rank < P.orca.max_neighbors)
                 s.lines[q * kLineStride + rank] =
                     make_half_plane(P.orca, me.x, me.y, me.z, me.w, other.x, other.y, other.z, other.w, rsum);
+            if (L.lane < P.nA) {
+                s.sol[L.lane] = sol4;
+                s.res[L.lane] = start4;
+            }
         }
         __syncthreads();
         CN_TICK(clk, 2);
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 }
             }
         }
-        stage_agent(P, s, L, r, robot_max_speed, L.valid && ep.state == kRunning && (L.a > 0 || P.robot_orca), c_hsafety);
+        stage_agent(P, s, L, r, c_hsafety);
         __syncthreads();
         CN_TICK(clk, 7);
     }
