@@ -47,14 +47,15 @@ def algorithmic_bytes_per_env_step(H):
     return 72 * (H + 1) + 26
 
 
-def pmc_profile(envs, humans, steps_per_launch):
+def pmc_profile(envs, humans, steps_per_launch, circle_radius=4.0):
     """The committed rocprofv3 PMC record (separate FETCH_SIZE / WRITE_SIZE / SQ passes of this command, per-dispatch
     averages of cn::rollout_kernel) whose launch shape equals the one just timed, or None: counters of a 1000-step
     launch say nothing about a 20-step one."""
     if not os.path.exists(PMC_PROFILE):
         return None
     for rec in json.load(open(PMC_PROFILE)).get('profiles', []):
-        if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch')) == (envs, humans, steps_per_launch):
+        if (rec.get('envs'), rec.get('humans'), rec.get('steps_per_launch'), rec.get('circle_radius', 4.0)) == \
+                (envs, humans, steps_per_launch, circle_radius):
             return rec
     return None
 
@@ -451,7 +452,7 @@ def main():
     steps_per_launch = shapes[-1]  # = min(chunk, steps); a shorter tail launch exists when chunk does not divide steps
     avg_launch_s = kernel_s / launches
     achieved = algorithmic_bytes_per_env_step(H) * B * args.steps / kernel_s / 1e9
-    prof = pmc_profile(B, H, steps_per_launch) if len(shapes) == 1 and args.circle_radius == 4.0 else None
+    prof = pmc_profile(B, H, steps_per_launch, args.circle_radius) if len(shapes) == 1 else None
     s = [float(v) for v in summary.cpu().tolist()]
     out = {
         'metric': 'env-steps/sec (whole node), %d envs x %d humans, ORCA step' % (B, H),

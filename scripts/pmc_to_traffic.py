@@ -12,8 +12,9 @@ import os
 import sys
 
 out, envs, humans, spl, kernel, which = sys.argv[1:7]
-rec = dict(envs=int(envs), humans=int(humans), steps_per_launch=int(spl), kernel=kernel, dispatches=which,
-           source='rocprofv3 --pmc, separate passes per counter group (scripts/gpu_r02_prof.sh); per-dispatch values of the '
+rec = dict(envs=int(envs), humans=int(humans), steps_per_launch=int(spl), circle_radius=float(os.environ.get('CN_PMC_RADIUS', 4.0)),
+           kernel=kernel, dispatches=which,
+           source='rocprofv3 --pmc, separate passes per counter group (scripts/gpu.sh pmc); per-dispatch values of the '
                   'rollout kernel')
 vals = {}
 for d in sys.argv[7:]:
@@ -48,7 +49,8 @@ if 'sq_thread_cycles_valu' in rec and 'sq_active_inst_valu' in rec and rec['sq_a
     # lanes active per VALU issue cycle / 64 (both counters in quad-cycles of the same unit)
     rec['lane_occupancy'] = rec['sq_thread_cycles_valu'] / (64.0 * rec['sq_active_inst_valu'])
 doc = json.load(open(out)) if os.path.exists(out) else {'profiles': []}
-doc['profiles'] = [p for p in doc['profiles'] if (p['envs'], p['humans'], p['steps_per_launch']) != (rec['envs'], rec['humans'], rec['steps_per_launch'])]
+key = lambda p: (p['envs'], p['humans'], p['steps_per_launch'], p.get('circle_radius', 4.0))  # noqa: E731
+doc['profiles'] = [p for p in doc['profiles'] if key(p) != key(rec)]
 doc['profiles'].append(rec)
 json.dump(doc, open(out, 'w'), indent=1)
 print(json.dumps(rec, indent=1))

@@ -33,7 +33,7 @@ def test_committed_pmc_profile_is_well_formed():
     if not os.path.exists(bench.PMC_PROFILE):
         return
     doc = json.load(open(bench.PMC_PROFILE))
-    shapes = [(p['envs'], p['humans'], p['steps_per_launch']) for p in doc['profiles']]
+    shapes = [(p['envs'], p['humans'], p['steps_per_launch'], p.get('circle_radius', 4.0)) for p in doc['profiles']]
     assert len(shapes) == len(set(shapes))
     for p in doc['profiles']:
         assert p['fetch_size_kb'] > 0 and p['write_size_kb'] > 0 and p['sq_insts_valu'] > 0
