@@ -1672,6 +1672,13 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     if (HEADLINE) {
         P.A = 6, P.NC = 5, P.E = 2, P.nA = 12, P.pairs = 60, P.threads = 64;
     }
+    // the float64 parameters of a step as VALU operands live in VGPRs (rollout_fused.h: in_vgpr): as SGPR kernel arguments the
+    // 16-dword block was spilled into VGPR lanes and re-read with v_readlane several times per step
+    {
+        auto pin = [](double& x) { asm volatile("" : "+v"(x)); };
+        pin(P.dt), pin(P.time_limit), pin(P.success_reward), pin(P.collision_penalty), pin(P.discomfort_dist);
+        pin(P.discomfort_factor), pin(P.human_safety);
+    }
     const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
