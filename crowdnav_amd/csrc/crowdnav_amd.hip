@@ -654,6 +654,7 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
 static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, const double* action) {
     const cn::Params& P = e->P;
     static const bool use_fused = env_int("CROWDNAV_AMD_FUSED", 1) != 0;
+    static const bool use_geom20 = env_int("CROWDNAV_AMD_GEOM20", 1) != 0;  // the compile-time geometry of configs[3]'s shard
     const bool headline = P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 && P.threads == 64;
     // (the fused kernel reads the launch-time fill level only: never with the asynchronous fill, whose slots are published
     // one by one — CROWDNAV_AMD_WAVE_SCENARIOS=1 can switch that on for a small crowd)
@@ -667,6 +668,10 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
                                (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else if (e->maxl == 5 && !P.robot_unicycle && headline) {
         hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
+                           (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
+    } else if (use_geom20 && e->maxl == 10 && !P.robot_unicycle && P.A == 21 && P.NC == 20 && P.E == 1 && P.threads == 64 &&
+               P.orca.max_neighbors == 10 && P.kd) {
+        hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
                            (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else {
         CN_LAUNCH_ROLLOUT(e, grid_envs(e), e->P, (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);

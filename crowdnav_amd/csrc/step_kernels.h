@@ -1669,8 +1669,15 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     // constants — the pair loops become single passes, the 5-candidate rank loop unrolls, divisions by A / NC fold:
     // 706 -> 740 M env-steps/s.  Every other geometry runs the generic instantiation.
     Params P = P_in;
-    if (HEADLINE) {
+    if (HEADLINE && MAXL == 5) {
         P.A = 6, P.NC = 5, P.E = 2, P.nA = 12, P.pairs = 60, P.threads = 64;
+    }
+    if (HEADLINE && MAXL == 10) {  // BASELINE configs[3]'s shard: 20 humans + robot, one env per 64-lane workgroup, 10 neighbours
+        // kept of 20 candidates — every LDS offset an immediate, no scalar registers for the layout (the generic instantiation
+        // spills 200+ SGPRs into VGPR lanes)
+        P.A = 21, P.NC = 20, P.E = 1, P.nA = 21, P.pairs = 420, P.threads = 64, P.kd = KD ? 1 : 0;
+        P.orca.max_neighbors = 10;
+        P.kdl = kd_layout(21, 21, 1);
     }
     // the float64 parameters of a step as VALU operands live in VGPRs (rollout_fused.h: in_vgpr): as SGPR kernel arguments the
     // 16-dword block was spilled into VGPR lanes and re-read with v_readlane several times per step
