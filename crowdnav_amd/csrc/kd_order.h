@@ -60,7 +60,7 @@ struct KdSmem {
     int* count;       // [2 generations][E][2 trees]
     int* dirty;       // [E][2 trees] first node of this step's list that differs from last step's (= count: none does)
     uint32_t* bb;     // [E][mn][4] min x, max x, min y, max y as order-preserving integers
-    float* dnext;     // [nA] squared distance of the nearest candidate that did NOT make the list (+inf if none)
+    float* dnext;     // [nA] (as int) slots below maxNeighbors claimed by the agent's candidates in the first sweep of the pair phase
     int* tie;         // [nA] this simulator has an exact tie that the visiting order decides
     int* gen;         // [1] the generation that holds the most recent node lists
     int row, mn;

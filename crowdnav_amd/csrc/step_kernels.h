@@ -540,8 +540,7 @@ __device__ __forceinline__ void kd_visit_order(const Params& P, const Smem& s, c
 
 // Second sweep of the 20-candidate pair phase (orca_phases, two_sweeps): lane = (agent, slot), 6 agents per pass of a wave
 // (lanes 60..63 idle): the half-plane of every kept neighbour, the number kept.  DETECT: a simulator has an exact distance tie
-// that RVO2's visiting order decides if two of its kept neighbours are equally far (adjacent slots) or the last kept one is
-// as far as the nearest dropped one.
+// that RVO2's visiting order decides if candidates of one agent shared a slot in the first sweep (strict ranks).
 template <bool DETECT>
 __device__ __forceinline__ void pair_sweep2(const Params& P, const Smem& s) {
     const int* kept = reinterpret_cast<const int*>(s.proj);
@@ -564,13 +563,8 @@ __device__ __forceinline__ void pair_sweep2(const Params& P, const Smem& s) {
         if (lane_ok && slot == 0) s.count[q] = __popcll((vm >> (10 * g)) & 0x3ffull);
         if (valid)
             s.lines[q * kLineStride + slot] = make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
-        if (DETECT) {
-            const float ddx = me.x - ot.x, ddy = me.y - ot.y;
-            const float dsq = ddx * ddx + ddy * ddy;  // = s.d2 of the pair (same operands, same operations)
-            // the previous slot's distance: DPP wave_shr 1 (a ds_bpermute would cost an LDS round trip per pass)
-            const float before = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dsq), 0x138, 0xf, 0xf, false));
-            const bool tie = valid && ((slot > 0 && before == dsq) || (slot == 9 && dsq == k.dnext[qq]));
-            if (tie) k.tie[qq] = 1;
+        if (DETECT) {  // more candidates claimed a slot than slots are filled: some share one, i.e. are equally far
+            if (lane_ok && slot == 0 && reinterpret_cast<const int*>(k.dnext)[q] != (int)__popcll((vm >> (10 * g)) & 0x3ffull)) k.tie[q] = 1;
         }
     }
 }
@@ -710,7 +704,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         if (KD) {
             const KdSmem k = kd_view(P, s);
             k.tie[L.lane] = 0;
-            k.dnext[L.lane] = std::numeric_limits<float>::infinity();
+            reinterpret_cast<int*>(k.dnext)[L.lane] = 0;  // slots below 10 claimed by this agent's candidates (two-sweep pair phase)
         }
     }
     __syncthreads();
@@ -758,8 +752,12 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         // alone: every candidate that precedes it is inside the range too — 4 vector instructions per candidate instead of 7;
         // the ranks of an agent's in-range candidates are a permutation of 0 .. within - 1, so the neighbours kept are
         // exactly the filled slots and their number falls out of the second sweep's ballot.
+        // With the kd bookkeeping (always, at 20 candidates) the rank counts STRICTLY nearer candidates only — 2 vector
+        // instructions per candidate instead of 4-5: candidates at exactly the same distance then share a rank and a slot, which
+        // the second sweep notices (more candidates claimed a slot below 10 than slots are filled) and kd_resolve_ties ranks
+        // that agent's candidates again, ties by RVO2's visiting order.
         int* kept = reinterpret_cast<int*>(s.proj);
-        float* const dnext = KD ? kd_view(P, s).dnext : nullptr;
+        int* const claimed = KD ? reinterpret_cast<int*>(kd_view(P, s).dnext) : nullptr;
         for (int p = L.lane; p < P.pairs; p += P.threads) {
             const int info = s.pinfo[p];
             const int c = (info >> 16) & 0xff;
@@ -772,10 +770,17 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 v[4 * j] = t.x, v[4 * j + 1] = t.y, v[4 * j + 2] = t.z, v[4 * j + 3] = t.w;
             }
             int rank = 0;
+            if (KD) {
 #pragma unroll
-            for (int k = 0; k < 20; ++k) rank += ((v[k] < mine) | ((v[k] == mine) & (k < c))) ? 1 : 0;
-            if (mine < range_sq && rank < 10) kept[(info & 0xff) * 10 + rank] = ((info >> 8) & 0xff) | (((info >> 25) & 1) << 8);
-            if (KD && mine < range_sq && rank == 10) dnext[info & 0xff] = mine;  // the nearest one that is dropped
+                for (int k = 0; k < 20; ++k) rank += v[k] < mine ? 1 : 0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 20; ++k) rank += ((v[k] < mine) | ((v[k] == mine) & (k < c))) ? 1 : 0;
+            }
+            if (mine < range_sq && rank < 10) {
+                kept[(info & 0xff) * 10 + rank] = ((info >> 8) & 0xff) | (((info >> 25) & 1) << 8);
+                if (KD) atomicAdd(claimed + (info & 0xff), 1);  // (LDS, no return value)
+            }
         }
         __syncthreads();
         if (KD)
