@@ -144,6 +144,56 @@ def test_ties_are_decided_by_the_history_of_the_permutation(amd, oracle_mod, H, 
     assert np.array_equal(_np(eng.get_state()[0]), o.get_state()[0])
 
 
+@pytest.mark.parametrize('H,visible,envs_per_wave,waves', [(12, 1, 2, 1), (20, 1, 3, 1), (20, 0, 2, 1), (12, 1, 4, 2), (20, 1, 1, 2)])
+def test_ties_with_several_envs_per_workgroup(amd, oracle_mod, H, visible, envs_per_wave, waves):
+    """Large batches pack several envs into a workgroup (more than 4096 envs of 10+ humans; CROWDNAV_AMD_ENVS_PER_WAVE forces
+    it here) and a workgroup may have more than one wave (CROWDNAV_AMD_WAVES_PER_BLOCK): the kd-trees are then built by the
+    cooperative builder (LDS min / max per env, kd_build_trees) instead of the wave-uniform one, and the fallback by the
+    shuffle-round program.  Lattice scenes, history-carrying simulators: bit for bit vs the oracle."""
+    import os
+    rng = np.random.RandomState(31 * H + 7 * visible + envs_per_wave)
+    B = 13  # a partial last workgroup
+    cfg = dict(num_humans=H, robot_visible=visible, circle_radius=6.0)
+    old = {k: os.environ.get(k) for k in ('CROWDNAV_AMD_ENVS_PER_WAVE', 'CROWDNAV_AMD_WAVES_PER_BLOCK')}
+    os.environ['CROWDNAV_AMD_ENVS_PER_WAVE'] = str(envs_per_wave)
+    os.environ['CROWDNAV_AMD_WAVES_PER_BLOCK'] = str(waves)
+    try:
+        eng = amd.BatchedCrowdSim(num_envs=B, robot_policy=amd.ROBOT_ORCA, **cfg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    o = oracle_mod.CrowdOracle(num_envs=B, robot_policy=1, **cfg)
+    o.reset(500 + np.arange(B))
+    eng.drop_sims()
+    eng.set_state(o.get_state()[0], np.zeros(B))
+    for rnd in range(3):
+        for t in range(4 if rnd else 0):
+            g, w = eng.step(None, update=True, want_obs=False), o.step(None, update=True)
+            assert np.array_equal(_np(g['orca_vel']).view(np.uint32), w['orca_vel'].view(np.uint32)), (rnd, t)
+        state = lattice_state(rng, B, H + 1)
+        for obj in (eng, o):
+            obj.set_state(state, np.zeros(B))
+        for t in range(2):
+            g, w = eng.step(None, update=True, want_obs=False), o.step(None, update=True)
+            assert np.array_equal(_np(g['orca_vel']).view(np.uint32), w['orca_vel'].view(np.uint32)), (rnd, t)
+            for k in ('reward', 'done', 'info', 'dmin'):
+                assert np.array_equal(_np(g[k]), w[k]), k
+    # the rollout kernel on the same geometry: a few steps, then a lattice teleport
+    eng.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=-1, record_capacity=4)
+    eng.rollout(30)
+    o.reset(1000 + np.arange(B))
+    o.rollout(30, 1000, 500, 4, np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.float64))
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+    state = lattice_state(rng, B, H + 1)
+    for obj in (eng, o):
+        obj.set_state(state, np.zeros(B))
+    g, w = eng.step(None, update=True, want_obs=False), o.step(None, update=True)
+    assert np.array_equal(_np(g['orca_vel']).view(np.uint32), w['orca_vel'].view(np.uint32))
+
+
 def test_rollout_keeps_simulators_across_steps_and_renews_them_at_resets(amd, oracle_mod):
     """cn_rollout at 12 humans carries the permutations in LDS from step to step and rebuilds the humans' simulators at every
     auto-reset; afterwards the agents are teleported onto a lattice: the tie order of the very next step depends on what the
