@@ -402,6 +402,24 @@ __device__ __forceinline__ void rotate_row(float px, float py, float vx, float v
     f[12] = radius + radius1;
 }
 
+// The occupancy-map columns of X (features 13.. and the zero padding) for every (group, human) row: what
+// sarl_feature_kernel leaves out with om_cols = 0.  Only cn_sarl_export uses it, so that an exported X is the whole input
+// matrix of the value network whichever way the kernel read it.
+__global__ void sarl_om_columns_kernel(SarlCfg C, int in_dim, int ks_x, const float* om, float* X, size_t n_tiles) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_tiles * C.H * kSarlGroups) return;
+    const int g = (int)(idx % kSarlGroups);
+    const int h = (int)((idx / kSarlGroups) % C.H);
+    const size_t tile = idx / ((size_t)kSarlGroups * C.H);
+    const size_t G = tile * kSarlGroups + g;
+    if (G >= (size_t)C.B * C.n_actions) return;  // padding groups are zero already
+    float* x = X + ((tile * C.H + h) * ks_x) * 64 + g;
+    const int extra = in_dim - 13;
+    const float* m = om + ((G / C.n_actions) * C.H + h) * (size_t)extra;
+    for (int k = 0; k < extra; ++k) x[((13 + k) >> 2) * 64 + ((13 + k) & 3) * 16] = m[k];
+    for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+}
+
 // X row of (env b, action a, human h): CADRL.rotate of the float32 joint row
 // [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written straight in the MLP
 // kernel's LDS order: group G = b * K + a -> tile G / 16, g = G % 16, row tile = h;
@@ -410,7 +428,10 @@ __device__ __forceinline__ void rotate_row(float px, float py, float vx, float v
 __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
                                     const double2* rv, const double* theta, const double* actions,
                                     const double* next_obs, const float* om, float* X, size_t n_tiles,
-                                    int* hcount /*[n_tiles * 16] humans present per group*/) {
+                                    int* hcount /*[n_tiles * 16] humans present per group*/,
+                                    int om_cols = 1 /* 0: the consumer reads the occupancy maps from `om` itself (they do
+                                    not depend on the action: written into X they are 81 copies, 48 of every 61 floats);
+                                    only k-steps 0..3 — the 13 rotated features and map values 0..2 — are written */) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_tiles * C.H * kSarlGroups) return;
     const int g = (int)(idx % kSarlGroups);
@@ -453,8 +474,10 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     for (int k = 0; k < 13; ++k) x[(k >> 2) * 64 + (k & 3) * 16] = f[k];
     const int extra = in_dim - 13;
     const float* m = om + ((size_t)b * C.H + h) * (extra > 0 ? extra : 0);
-    for (int k = 0; k < extra; ++k) x[((13 + k) >> 2) * 64 + ((13 + k) & 3) * 16] = m[k];
-    for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+    const int n_om = om_cols ? extra : (extra < 3 ? extra : 3);
+    for (int k = 0; k < n_om; ++k) x[((13 + k) >> 2) * 64 + ((13 + k) & 3) * 16] = m[k];
+    if (om_cols)
+        for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------ replay-memory side

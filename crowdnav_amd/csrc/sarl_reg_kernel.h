@@ -331,9 +331,15 @@ __device__ __forceinline__ void reg_dense1(RegStream& ws, In in, f32x4 (&out)[MT
 // X: the feature kernel's fragment order, X[((tile * 5 + h) * ks_x + ks) * 64 + lane] = feature 4 ks + (lane >> 4) of human h
 // of group lane & 15 — exactly the B operand of k-step ks.  V[group] out.  Persistent: wave w of the grid takes tiles
 // w, w + waves, ...; the next tile's X is requested while the value head of the current one runs.
+// om (XKS = 16 only; nullptr: everything comes from X): the occupancy maps [env][human][48] of the lookahead kernel.  They do
+// not depend on the action, so instead of 81 copies inside X (425 MB written by the feature kernel and read back here per
+// decision, 48 of every 61 floats) k-steps 4..15 are read from the maps themselves: lane l wants feature 4 ks + (l >> 4) of
+// group l & 15, i.e. map value 4 ks + (l >> 4) - 13 of the group's env — 16 consecutive groups are one or two envs, so the
+// loads of a k-step hit one or two cache lines.
 template <int XKS>
 __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* stream, const float* X, float* V, int n_groups,
-                                                                  int n_tiles, int ks_x, const int* hcount) {
+                                                                  int n_tiles, int ks_x, const int* hcount,
+                                                                  const float* om = nullptr, int n_actions = 1) {
     constexpr int NT = kRegHumans;
     constexpr int QT = reg_total_quads(XKS);
     const int lane = threadIdx.x & 63;
@@ -347,14 +353,27 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
     const gfloat_p Xg = as_global(X) + lane;
     float x[NT][XKS];
     int cnt;
-    {
-        const gfloat_p xt = Xg + (size_t)wid * NT * ks_x * 64;
+    const bool om_direct = XKS == 16 && om != nullptr;
+    const auto load_x = [&](int t) {
+        const gfloat_p xt = Xg + (size_t)t * NT * ks_x * 64;
+        gfloat_p ob = as_global(om);
+        if (om_direct) {
+            const long long G = (long long)t * kSarlGroups + (lane & 15);
+            const int env = (int)((G < n_groups ? G : (long long)n_groups - 1) / n_actions);
+            ob += (size_t)env * NT * 48 + (lane >> 4);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int ks = 0; ks < XKS; ++ks) x[nt][ks] = xt[(nt * ks_x + ks) * 64];
-        cnt = hcount[(size_t)wid * kSarlGroups + (lane & 15)];
-    }
+            for (int ks = 0; ks < XKS; ++ks) {
+                if (om_direct && ks >= 4)  // map value 4 ks + (lane >> 4) - 13; 61..63 do not exist (k-step 15, lanes 16..63)
+                    x[nt][ks] = (ks < 15 || lane < 16) ? ob[nt * 48 + 4 * ks - 13] : 0.0f;
+                else
+                    x[nt][ks] = xt[(nt * ks_x + ks) * 64];
+            }
+    };
+    load_x(wid < n_tiles ? wid : 0);
+    cnt = hcount[(size_t)(wid < n_tiles ? wid : 0) * kSarlGroups + (lane & 15)];
     // per-human features (mlp2 output, 80 registers) wait in LDS while the attention layers run: wave-private, no barrier
     __shared__ f32x4 park[kRegWaves][NT * 4][64];
     f32x4(*const mypark)[64] = park[threadIdx.x >> 6];
@@ -438,13 +457,7 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         CN_SARL_TICK(9);
         // the next tile's input (and this tile's last use of x is behind us)
         const int next = tile + nw < n_tiles ? tile + nw : tile;
-        {
-            const gfloat_p xt = Xg + (size_t)next * NT * ks_x * 64;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int ks = 0; ks < XKS; ++ks) x[nt][ks] = xt[(nt * ks_x + ks) * 64];
-        }
+        load_x(next);
         const int cnt_next = hcount[(size_t)next * kSarlGroups + (lane & 15)];
         // value head on joint = [self | weighted feature] (sarl.py:61-62)
         f32x4 j1[10], j2[7], j3[7], val[1];

@@ -12,6 +12,7 @@
 #   pmc                   separate rocprofv3 --pmc passes: FETCH / WRITE / SQ for the fused kernel (both shapes), rollout_kernel<10>,
 #                         sarl_reg_kernel<4> and <16> (MFMA busy) -> r03_traffic.json
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp
+shopt -s nullglob
 REPO=$GRAFT_REPO_ROOT; TAG=${CN_TAG:-r03}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; cd $REPO
 line() { timeout 20 python scripts/bench_line.py "$1"; }
 bench() { # name, [VAR=val ...] -- args
