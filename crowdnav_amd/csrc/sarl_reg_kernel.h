@@ -28,7 +28,7 @@
 namespace cn {
 
 constexpr int kRegDepth = 4;   // weight quads in flight per wave
-constexpr int kRegHumans = 5;  // N tiles per wave
+constexpr int kRegHumans = 5;  // N tiles per wave, at most
 constexpr int kRegWaves = 4;   // waves per workgroup = SIMDs per CU
 
 enum {
@@ -230,7 +230,10 @@ __device__ __forceinline__ float reg_relu1(float x) {
 }
 
 // out[nt][mt] = relu(W x + b).  Every instruction a wave issues between two MFMAs delays the second one by ~5 cycles (one wave
-// per SIMD: nothing else hides it; measured: tile time = 32 cycles x MFMAs + 5.4 x everything else), so the layer is written
+// per SIMD: nothing else hides it; measured: tile time = 32 cycles x MFMAs + 5.4 x everything else — and WHERE it sits does
+// not matter: round 3 spread the ReLU burst of tile mt - 1 one value per MFMA gap over tile mt's first 20 MFMAs with
+// sched_group_barrier(MFMA 1, VALU 3) — gap histogram 62-instruction bursts -> 3..7 per gap — and cn_sarl_select went
+// 1.834 -> 1.839 ms; -mllvm -amdgpu-mfma-vgpr-form removes the 802 v_accvgpr_read per tile and gains 0.8 %), so the layer is written
 // for instruction count: a VGPR array (AG = false) is accumulated in place and rectified with one v_max_i32 per value; an
 // AGPR array is accumulated in VGPRs, rectified there and moved with one v_accvgpr_write (2 per value; read - max - write on
 // an AGPR accumulator would be 3).  The ReLU of tile mt - 1 follows the first MFMAs of tile mt, so that it never waits for
@@ -336,11 +339,13 @@ __device__ __forceinline__ void reg_dense1(RegStream& ws, In in, f32x4 (&out)[MT
 // decision, 48 of every 61 floats) k-steps 4..15 are read from the maps themselves: lane l wants feature 4 ks + (l >> 4) of
 // group l & 15, i.e. map value 4 ks + (l >> 4) - 13 of the group's env — 16 consecutive groups are one or two envs, so the
 // loads of a k-step hit one or two cache lines.
-template <int XKS>
+// NT = humans of the crowd (N tiles per wave), 1..5.  With NT = 1 the MFMAs of a k-step chain are dependent (40 instead of 32
+// cycles each); from 2 humans on consecutive MFMAs alternate between accumulators.
+template <int XKS, int NT>
 __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* stream, const float* X, float* V, int n_groups,
                                                                   int n_tiles, int ks_x, const int* hcount,
                                                                   const float* om = nullptr, int n_actions = 1) {
-    constexpr int NT = kRegHumans;
+    static_assert(NT >= 1 && NT <= kRegHumans, "the activations of at most 5 humans fit the register file");
     constexpr int QT = reg_total_quads(XKS);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;

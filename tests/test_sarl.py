@@ -139,6 +139,41 @@ def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans', [1, 2, 3, 4])
+@pytest.mark.parametrize('with_om', [False, True])
+def test_register_resident_value_network_for_one_to_four_humans(humans, with_om, monkeypatch):
+    """sarl_reg_kernel<XKS, NT> for crowds of 1..4 humans (NT N tiles per wave; 3 / 2 waves per SIMD at 1 / 2 humans) against the
+    torch module and the LDS kernel on the same engine configuration, with a ragged last tile and more tiles than resident
+    waves at 3 and 4 humans."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    if with_om and humans == 1:
+        pytest.skip('occupancy maps need another human (multi_human_rl.py:117): cn_sarl_configure refuses, as the reference does')
+    torch.manual_seed(20 + humans)
+    d = 61 if with_om else 13
+    net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    B = 203
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for reg in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                           robot_visible=1)
+        eng.reset(3000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[reg] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), eng.sarl_export('X').cpu())
+    with torch.no_grad():
+        want = net(got['1'][2].reshape(B * 81, humans, d)).reshape(B, 81).numpy()
+    assert torch.equal(got['1'][2], got['0'][2])
+    assert np.abs(got['1'][0] - want).max() <= 2e-5 and np.abs(got['0'][0] - want).max() <= 2e-5
+    assert np.abs(got['1'][0] - got['0'][0]).max() <= 1e-6
+    assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True])
 def test_value_network_at_the_full_benchmark_size_vs_torch(with_om):
     """BASELINE configs[2] at full size: 4096 envs x 81 actions x 5 humans = 20 736 tiles through the register-resident kernel
