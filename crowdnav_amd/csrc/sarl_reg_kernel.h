@@ -45,8 +45,21 @@ struct RegShape {
 
 __host__ __device__ constexpr int reg_cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// xks = k-steps of the network input: 4 (13 features) or 16 (13 + 48 occupancy-map features)
+// The functions below describe a weight stream by a NETWORK KEY: for sarl.ValueNetwork the k-steps of its input, 4 (13
+// features) or 16 (13 + 48 occupancy-map features); kRegCadrl for cadrl.ValueNetwork (cadrl.py:22-29: 13 -> 150 -> 100 ->
+// 100 -> 1 on every (robot, human) row; layers 0..3).
+constexpr int kRegCadrl = 1004;
+__host__ __device__ constexpr int reg_layers(int key) { return key == kRegCadrl ? 4 : (int)kRegLayers; }
+
 __host__ __device__ constexpr RegShape reg_shape(int l, int xks) {
+    if (xks == kRegCadrl) {
+        switch (l) {
+            case 0: return {4, 10, 1, 0};
+            case 1: return {38, 7, 1, 0};
+            case 2: return {25, 7, 1, 0};
+            default: return {25, 1, 1, 0};
+        }
+    }
     switch (l) {
         case kR_mlp1_0: return {xks, 10, 1, 0};
         case kR_mlp1_2: return {38, 7, 1, 0};
@@ -70,7 +83,9 @@ __host__ __device__ constexpr int reg_qbase(int l, int xks) {
     return q;
 }
 // the stream is padded to a multiple of kRegDepth so that quad I always lives in register slot I % kRegDepth
-__host__ __device__ constexpr int reg_total_quads(int xks) { return reg_cdiv(reg_qbase(kRegLayers, xks), kRegDepth) * kRegDepth; }
+__host__ __device__ constexpr int reg_total_quads(int xks) {
+    return reg_cdiv(reg_qbase(reg_layers(xks), xks), kRegDepth) * kRegDepth;
+}
 // position of item j (0 = bias if the layer has one, then the weight quads) of output tile mt inside its layer
 __host__ __device__ constexpr int reg_qpos(int l, int xks, int mt, int j) {
     const RegShape s = reg_shape(l, xks);
@@ -82,8 +97,8 @@ __host__ __device__ constexpr int reg_qpos(int l, int xks, int mt, int j) {
 // (sarl.py:61): k-steps 0..11 and lanes 0..31 of k-step 12 are the weighted feature's registers; lanes 32..63 of k-step 12
 // take self features 2, 3 from X k-step 0, k-step 13 takes 4, 5 from X k-step 1 and k-step 14 takes 0, 1 from X k-step 0 —
 // the registers that already hold them in those lanes.
-__host__ __device__ constexpr int reg_kcol(int l, int K, int k_off, int ks, int lg) {
-    if (l != kR_mlp3_0) return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
+__host__ __device__ constexpr int reg_kcol(int key, int l, int K, int k_off, int ks, int lg) {
+    if (key == kRegCadrl || l != kR_mlp3_0) return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
     if (ks < 12) return 6 + 4 * ks + lg;
     if (ks == 12) return lg < 2 ? 6 + 48 + lg : lg;
     if (ks == 13) return lg < 2 ? 4 + lg : -1;
@@ -97,7 +112,7 @@ struct RegPackLayer {
 };
 struct RegPackPlan {
     RegPackLayer L[kRegLayers];
-    int xks;
+    int xks;  // the network key
 };
 
 __global__ void sarl_reg_pack_kernel(RegPackPlan plan, float* stream) {
@@ -109,8 +124,9 @@ __global__ void sarl_reg_pack_kernel(RegPackPlan plan, float* stream) {
     const int lg = lane >> 4, m = lane & 15;
     float v = 0.0f;
     int l = 0, base = 0;
-    while (l < kRegLayers && quad >= base + reg_layer_quads(l, xks)) base += reg_layer_quads(l++, xks);
-    if (l < kRegLayers) {
+    const int n_layers = reg_layers(xks);
+    while (l < n_layers && quad >= base + reg_layer_quads(l, xks)) base += reg_layer_quads(l++, xks);
+    if (l < n_layers) {
         const RegShape s = reg_shape(l, xks);
         const int S = reg_tile_quads(l, xks);
         const RegPackLayer& L = plan.L[l];
@@ -130,7 +146,7 @@ __global__ void sarl_reg_pack_kernel(RegPackPlan plan, float* stream) {
         } else {
             const int ks = 4 * (j - s.bias) + kk;
             const int n = L.replicate ? 0 : 16 * mt + 4 * (m & 3) + (m >> 2);
-            const int col = ks < s.ks ? reg_kcol(l, L.K, L.k_off, ks, lg) : -1;
+            const int col = ks < s.ks ? reg_kcol(xks, l, L.K, L.k_off, ks, lg) : -1;
             v = (n < L.N && col >= 0) ? L.W[(size_t)n * L.ldw + col] : 0.0f;
         }
     }
@@ -482,10 +498,69 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         cnt = cnt_next;
         // the stream position wraps to quad 0 here: the padding quads are consumed so that slot I % kRegDepth stays aligned
 #pragma unroll
-        for (int i = reg_qbase(kRegLayers, XKS); i < QT; ++i) (void)reg_take<QT>(ws, i);
+        for (int i = reg_qbase(reg_layers(XKS), XKS); i < QT; ++i) (void)reg_take<QT>(ws, i);
         CN_SARL_TICK(13);
     }
     CN_SARL_CLOCK_END_N((n_tiles - wid + nw - 1) / nw);
+}
+
+// cadrl.ValueNetwork (cadrl.py:22-29) with the activations in registers: the same MLP for every (group, human) row — NT N tiles
+// of 16 rows per wave, layers chained through the accumulator layout as above — then the minimum over the humans present
+// (cadrl.py:162-163: torch.min over dim 0, the first minimum's value).  X, hcount, V as for sarl_reg_kernel.
+template <int NT>
+__global__ __launch_bounds__(kRegWaves * 64) void cadrl_reg_kernel(const float* stream, const float* X, float* V, int n_groups,
+                                                                   int n_tiles, int ks_x, const int* hcount) {
+    static_assert(NT >= 1 && NT <= kRegHumans, "the activations of at most 5 humans fit the register file");
+    constexpr int NK = kRegCadrl, QT = reg_total_quads(NK);
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
+    RegStream ws;
+    ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, QT * 1024, 0x00020000);
+    ws.voff = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < kRegDepth; ++i) ws.q[i] = reg_quad(ws, i);
+    if (wid >= n_tiles) return;
+    const gfloat_p Xg = as_global(X) + lane;
+    float x[NT][4];
+    const auto load_x = [&](int t) {
+        const gfloat_p xt = Xg + (size_t)t * NT * ks_x * 64;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) x[nt][ks] = xt[(nt * ks_x + ks) * 64];
+    };
+    load_x(wid);
+    int cnt = hcount[(size_t)wid * kSarlGroups + (lane & 15)];
+    const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+    for (int tile = wid; tile < n_tiles; tile += nw) {
+        const int next = tile + nw < n_tiles ? tile + nw : tile;
+        int cnt_next;
+        f32x4 h3[NT][7];
+        {
+            f32x4 h2[NT][7];
+            {
+                f32x4 h1[NT][10];
+                reg_dense_arr<NK, 0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
+                load_x(next);  // x is dead: the next tile's rows travel while this one computes
+                cnt_next = hcount[(size_t)next * kSarlGroups + (lane & 15)];
+                reg_dense_arr<NK, 1, NT, false>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
+            }
+            reg_dense_arr<NK, 2, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, h3);
+        }
+        float sc[NT];
+        reg_dense<NK, 3, NT, false>(ws, [&](int nt, int ks) { return h3[nt][ks >> 2][ks & 3]; }, none,
+                                    [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
+        float m = sc[0];
+#pragma unroll
+        for (int nt = 1; nt < NT; ++nt) m = (nt < cnt && sc[nt] < m) ? sc[nt] : m;
+        if (lane < kSarlGroups) {
+            const size_t G = (size_t)tile * kSarlGroups + lane;
+            if (G < (size_t)n_groups) V[G] = m;
+        }
+        cnt = cnt_next;
+#pragma unroll
+        for (int i = reg_qbase(reg_layers(NK), NK); i < QT; ++i) (void)reg_take<QT>(ws, i);
+    }
 }
 
 }  // namespace cn

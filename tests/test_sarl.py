@@ -174,6 +174,37 @@ def test_register_resident_value_network_for_one_to_four_humans(humans, with_om,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans', [1, 2, 3, 4, 5])
+def test_register_resident_cadrl_value_network(humans, monkeypatch):
+    """cadrl_reg_kernel<NT> (cadrl.ValueNetwork with the activations in registers, minimum over the humans in the epilogue)
+    against the torch module and the LDS kernel, on more tiles than resident waves and a ragged last tile."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import cadrl
+    from crowdnav_amd.compat.sarl import build_action_space
+    torch.manual_seed(40 + humans)
+    net = cadrl.ValueNetwork(13, [150, 100, 100, 1])
+    B = 203
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for reg in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                           robot_visible=1)
+        eng.reset(3000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='cadrl', mlp3_dims=(150, 100, 100, 1))
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[reg] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), eng.sarl_export('X').cpu())
+    with torch.no_grad():
+        want = net(got['1'][2].reshape(B * 81 * humans, 13)).reshape(B * 81, humans).min(dim=1).values.reshape(B, 81).numpy()
+    assert torch.equal(got['1'][2], got['0'][2])
+    assert np.abs(got['1'][0].reshape(B, 81) - want).max() <= 2e-5 and np.abs(got['0'][0].reshape(B, 81) - want).max() <= 2e-5
+    assert np.abs(got['1'][0] - got['0'][0]).max() <= 1e-6
+    assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True])
 def test_value_network_at_the_full_benchmark_size_vs_torch(with_om):
     """BASELINE configs[2] at full size: 4096 envs x 81 actions x 5 humans = 20 736 tiles through the register-resident kernel
