@@ -49,12 +49,19 @@ __host__ __device__ constexpr int reg_cdiv(int a, int b) { return (a + b - 1) / 
 // features) or 16 (13 + 48 occupancy-map features); kRegCadrl for cadrl.ValueNetwork (cadrl.py:22-29: 13 -> 150 -> 100 ->
 // 100 -> 1 on every (robot, human) row; layers 0..3).
 constexpr int kRegCadrl = 1004;
-__host__ __device__ constexpr int reg_layers(int key) { return key == kRegCadrl ? 4 : (int)kRegLayers; }
+// lstm_rl.ValueNetwork1 (lstm_rl.py:9-33) is two streams: the LSTM cell's gate layer (one layer, re-read for every human:
+// kRegLstmGates + k-steps of the input) and the value head on [self (6) | h_n (50)] (4 layers).
+constexpr int kRegLstmGates = 2000, kRegLstmHead = 2100, kRegLstmHid = 50, kRegLstmKs = 13;  // 13 k-steps / output tiles of 50 units
+__host__ __device__ constexpr bool reg_is_gates(int key) { return key > kRegLstmGates && key < kRegLstmHead; }
+__host__ __device__ constexpr int reg_layers(int key) {
+    return key == kRegCadrl || key == kRegLstmHead ? 4 : reg_is_gates(key) ? 1 : (int)kRegLayers;
+}
 
 __host__ __device__ constexpr RegShape reg_shape(int l, int xks) {
-    if (xks == kRegCadrl) {
+    if (reg_is_gates(xks)) return {xks - kRegLstmGates + kRegLstmKs, kRegLstmKs, 1, 0};  // [x_t | h_(t-1)] -> i, f, g, o of 4 units per tile
+    if (xks == kRegCadrl || xks == kRegLstmHead) {
         switch (l) {
-            case 0: return {4, 10, 1, 0};
+            case 0: return {xks == kRegCadrl ? 4 : 15, 10, 1, 0};
             case 1: return {38, 7, 1, 0};
             case 2: return {25, 7, 1, 0};
             default: return {25, 1, 1, 0};
@@ -97,8 +104,12 @@ __host__ __device__ constexpr int reg_qpos(int l, int xks, int mt, int j) {
 // (sarl.py:61): k-steps 0..11 and lanes 0..31 of k-step 12 are the weighted feature's registers; lanes 32..63 of k-step 12
 // take self features 2, 3 from X k-step 0, k-step 13 takes 4, 5 from X k-step 1 and k-step 14 takes 0, 1 from X k-step 0 —
 // the registers that already hold them in those lanes.
+// The LSTM-RL head reads joint = [self (6) | h_n (50)] (lstm_rl.py:30-31): k-steps 0..12 are the hidden state's registers
+// (unit 4 ks + lg), k-step 13 is X k-step 0 of the first human's row (self features 0..3), k-step 14 its k-step 1 (4, 5).
 __host__ __device__ constexpr int reg_kcol(int key, int l, int K, int k_off, int ks, int lg) {
-    if (key == kRegCadrl || l != kR_mlp3_0) return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
+    if (key == kRegLstmHead && l == 0)
+        return ks < kRegLstmKs ? (4 * ks + lg < kRegLstmHid ? 6 + 4 * ks + lg : -1) : ks == 13 ? lg : lg < 2 ? 4 + lg : -1;
+    if (key >= 1000 || l != kR_mlp3_0) return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
     if (ks < 12) return 6 + 4 * ks + lg;
     if (ks == 12) return lg < 2 ? 6 + 48 + lg : lg;
     if (ks == 13) return lg < 2 ? 4 + lg : -1;
@@ -109,6 +120,10 @@ struct RegPackLayer {
     const float* W;     // torch.nn.Linear weight [N][ldw]
     const float* b;     // bias or nullptr
     int N, ldw, K, k_off, replicate;  // replicate: the single output feature fills all 16 slots (attention score: every lane gets it)
+    // LSTM gate layer (W = weight_ih [4 hid][K], b = bias_ih): the recurrent half; k-steps from k_split on multiply h
+    const float* W2;    // weight_hh [4 hid][hid]
+    const float* b2;    // bias_hh
+    int k_split;
 };
 struct RegPackPlan {
     RegPackLayer L[kRegLayers];
@@ -140,7 +155,21 @@ __global__ void sarl_reg_pack_kernel(RegPackPlan plan, float* stream) {
             const int r2 = r - pairs * 2 * S;
             mt = 2 * pairs + r2 / S, j = r2 % S;
         }
-        if (s.bias && j == 0) {  // accumulator register kk of lane group lg = feature 16 mt + 4 kk + lg
+        if (reg_is_gates(xks)) {
+            // output tile mt = units 4 mt .. 4 mt + 3: accumulator register kk of lane group lg = gate kk (torch order i, f, g, o)
+            // of unit 4 mt + lg, so that a tile's f32x4 is everything the cell update of its 4 units needs and the new hidden
+            // state lands in the B-operand layout of k-step mt
+            if (j == 0) {
+                const int u = 4 * mt + lg;
+                v = u < kRegLstmHid ? L.b[kk * kRegLstmHid + u] + L.b2[kk * kRegLstmHid + u] : 0.0f;
+            } else {
+                const int ks = 4 * (j - 1) + kk, u = 4 * mt + (m >> 2), n = (m & 3) * kRegLstmHid + u;
+                if (u < kRegLstmHid && ks < s.ks) {
+                    if (ks < L.k_split) v = 4 * ks + lg < L.K ? L.W[(size_t)n * L.ldw + 4 * ks + lg] : 0.0f;
+                    else v = 4 * (ks - L.k_split) + lg < kRegLstmHid ? L.W2[(size_t)n * kRegLstmHid + 4 * (ks - L.k_split) + lg] : 0.0f;
+                }
+            }
+        } else if (s.bias && j == 0) {  // accumulator register kk of lane group lg = feature 16 mt + 4 kk + lg
             const int f = L.replicate ? 0 : 16 * mt + 4 * kk + lg;
             v = (L.b && f < L.N) ? L.b[f] : 0.0f;
         } else {
@@ -561,6 +590,123 @@ __global__ __launch_bounds__(kRegWaves * 64) void cadrl_reg_kernel(const float* 
 #pragma unroll
         for (int i = reg_qbase(reg_layers(NK), NK); i < QT; ++i) (void)reg_take<QT>(ws, i);
     }
+}
+
+// ---- lstm_rl.ValueNetwork1 (lstm_rl.py:9-33) with the state in registers ------------------------------------------------
+// The recurrence is sequential over the humans of a group, so a wave carries NT TILES (16 groups each) through it side by
+// side: per human one gate layer [x_t | h] -> 4 x 50 pre-activations as 13 output tiles x (XKS + 13) k-steps x NT independent
+// MFMAs; the cell update of tile mt (sigmoid / tanh on its f32x4, c and h are one register per k-step) runs behind the first
+// MFMAs of tile mt + 1.  Any number of humans: nothing is sized by H.  sigmoid(x) = 1 / (1 + 2^(-x log2 e)) and tanh(x) =
+// 1 - 2 / (1 + 2^(2 x log2 e)) on v_exp_f32 / v_rcp_f32 (1 ulp each): absolute error ~1e-7 per activation, against expf /
+// tanhf's ~20 instructions each on a wave that has nothing to hide them behind.
+__device__ __forceinline__ float reg_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695040888963f * x));
+}
+__device__ __forceinline__ float reg_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.885390081777927f * x));
+}
+
+template <int XKS, int NT>
+__device__ __forceinline__ void lstm_reg_bundle(RegStream& wg, RegStream& wh, const float* X, float* V, int n_groups, int H, int ks_x,
+                                                const int* hcount, int base, int lane) {
+    constexpr int GK = kRegLstmGates + XKS, HK = kRegLstmHead, KS = kRegLstmKs;
+    constexpr int QG = reg_total_quads(GK), QH = reg_total_quads(HK);
+    const gfloat_p Xg = as_global(X) + lane;
+    float h[NT][KS], c[NT][KS], x[NT][XKS], self0[NT], self1[NT];
+    int cnt[NT];
+    const auto load_x = [&](int t, float (&dst)[NT][XKS]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const gfloat_p xt = Xg + ((size_t)(base + nt) * H + t) * ks_x * 64;
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) dst[nt][ks] = xt[ks * 64];
+        }
+    };
+    load_x(0, x);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cnt[nt] = hcount[(size_t)(base + nt) * kSarlGroups + (lane & 15)];
+        self0[nt] = x[nt][0], self1[nt] = x[nt][1];  // self_state = state[:, 0, :6]: the first row's k-steps 0, 1
+#pragma unroll
+        for (int j = 0; j < KS; ++j) h[nt][j] = 0.0f, c[nt][j] = 0.0f;
+    }
+    const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+#pragma unroll 1
+    for (int t = 0; t < H; ++t) {
+        float xn[NT][XKS], hn[NT][KS];
+        load_x(t + 1 < H ? t + 1 : t, xn);  // the next human's rows travel while this one computes
+        reg_dense<GK, 0, NT, false>(
+            wg, [&](int nt, int ks) { return ks < XKS ? x[nt][ks] : h[nt][ks - XKS]; }, none,
+            [&](int nt, int mt, f32x4 v) {
+                const float cn_ = reg_sigmoid(v[1]) * c[nt][mt] + reg_sigmoid(v[0]) * reg_tanh(v[2]);
+                const float hn_ = reg_sigmoid(v[3]) * reg_tanh(cn_);
+                const bool present = t < cnt[nt];  // `mixed` rule: this group's episode has fewer humans
+                c[nt][mt] = present ? cn_ : c[nt][mt];
+                hn[nt][mt] = present ? hn_ : h[nt][mt];
+            });
+#pragma unroll
+        for (int i = reg_qbase(1, GK); i < QG; ++i) (void)reg_take<QG>(wg, i);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) h[nt][j] = hn[nt][j];
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) x[nt][ks] = xn[nt][ks];
+        }
+    }
+    float val[NT];
+    {
+        f32x4 j3[NT][7];
+        {
+            f32x4 j2[NT][7];
+            {
+                f32x4 j1[NT][10];
+                reg_dense_arr<HK, 0, NT, true>(
+                    wh, [&](int nt, int ks) { return ks < KS ? h[nt][ks] : ks == KS ? self0[nt] : self1[nt]; }, none, j1);
+                reg_dense_arr<HK, 1, NT, false>(wh, [&](int nt, int ks) { return j1[nt][ks >> 2][ks & 3]; }, none, j2);
+            }
+            reg_dense_arr<HK, 2, NT, true>(wh, [&](int nt, int ks) { return j2[nt][ks >> 2][ks & 3]; }, none, j3);
+        }
+        reg_dense<HK, 3, NT, false>(wh, [&](int nt, int ks) { return j3[nt][ks >> 2][ks & 3]; }, none,
+                                    [&](int nt, int, f32x4 v) { val[nt] = v[0]; });
+    }
+#pragma unroll
+    for (int i = reg_qbase(4, HK); i < QH; ++i) (void)reg_take<QH>(wh, i);
+    if (lane < kSarlGroups) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const size_t G = (size_t)(base + nt) * kSarlGroups + lane;
+            if (G < (size_t)n_groups) V[G] = val[nt];
+        }
+    }
+}
+
+// Persistent: full rounds of 5-tile bundles over all waves, then the remainder — as one more round of bundles when that is
+// shorter than its single tiles one per wave (a single tile's MFMAs are one dependent chain: ~0.4 of a bundle's time).
+template <int XKS>
+__global__ __launch_bounds__(kRegWaves * 64) void lstm_reg_kernel(const float* gates, const float* head, const float* X, float* V,
+                                                                  int n_groups, int n_tiles, int H, int ks_x, const int* hcount) {
+    constexpr int GK = kRegLstmGates + XKS, NT = kRegHumans;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
+    RegStream wg, wh;
+    wg.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gates), 0, reg_total_quads(GK) * 1024, 0x00020000);
+    wh.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(head), 0, reg_total_quads(kRegLstmHead) * 1024, 0x00020000);
+    wg.voff = wh.voff = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < kRegDepth; ++i) wg.q[i] = reg_quad(wg, i), wh.q[i] = reg_quad(wh, i);
+    const int rounds = n_tiles / (NT * nw);
+    int done = 0;
+    for (int k = 0; k < rounds; ++k)
+        lstm_reg_bundle<XKS, NT>(wg, wh, X, V, n_groups, H, ks_x, hcount, (k * nw + wid) * NT, lane);
+    done = rounds * NT * nw;
+    if (n_tiles - done > 2 * nw) {
+        const int nb = (n_tiles - done) / NT;
+        if (wid < nb) lstm_reg_bundle<XKS, NT>(wg, wh, X, V, n_groups, H, ks_x, hcount, done + wid * NT, lane);
+        done += nb * NT;
+    }
+    for (int tile = done + wid; tile < n_tiles; tile += nw)
+        lstm_reg_bundle<XKS, 1>(wg, wh, X, V, n_groups, H, ks_x, hcount, tile, lane);
 }
 
 }  // namespace cn

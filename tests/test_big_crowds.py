@@ -56,8 +56,13 @@ def test_om_sarl_twelve_humans_vs_reference():
 
 
 @pytest.mark.gpu
-def test_lstm_rl_twelve_humans_vs_reference():
+@pytest.mark.parametrize('kernels', ['by-size', 'register-resident'])
+def test_lstm_rl_twelve_humans_vs_reference(kernels, monkeypatch):
+    """... on the LDS kernel this batch size selects, and on lstm_reg_kernel (forced): its v_exp_f32 / v_rcp_f32 sigmoid and
+    tanh through 12 LSTM steps stay within 1e-6 of the unmodified reference's network outputs."""
     from crowdnav_amd.compat.lstm_rl import ValueNetwork1
+    if kernels == 'register-resident':
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', '2')
     g = load_golden('lstm_rl_om_h12.npz')
     eng = _select(g, model='lstm_rl', with_om=True, mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
     eng.sarl_set_weights(_load(ValueNetwork1(61, 6, [150, 100, 100, 1], 50), g).state_dict())

@@ -199,12 +199,10 @@ def _parked_states(states):
 def test_value_networks_mask_the_absent_humans_of_a_mixed_episode(policy, kernels, monkeypatch):
     """SARL (attention: mean and softmax over the humans present), CADRL (minimum over them) and LSTM-RL (one LSTM step per
     human present) on episodes with 1, 2, 3 and 5 humans, vs the unmodified reference acting under test_sim = mixed.  At this
-    batch size the LDS kernels run; CROWDNAV_AMD_SARL_REG=2 forces the register-resident ones (SARL, CADRL)."""
+    batch size the LDS kernels run; CROWDNAV_AMD_SARL_REG=2 forces the register-resident ones."""
     import torch
     import crowdnav_amd
     if kernels == 'register-resident':
-        if policy == 'lstm_rl':
-            pytest.skip('LSTM-RL has no register-resident kernel')
         monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', '2')
     from crowdnav_amd.compat import cadrl, lstm_rl, sarl
     g = load_golden('mixed_sarl.npz')

@@ -205,6 +205,40 @@ def test_register_resident_cadrl_value_network(humans, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans,with_om', [(1, False), (3, False), (5, False), (5, True), (7, False), (7, True)])
+def test_register_resident_lstm_rl_value_network(humans, with_om, monkeypatch):
+    """lstm_reg_kernel (lstm_rl.ValueNetwork1: gate layer and cell update in registers, 5 tiles side by side per wave, any number
+    of humans) against the torch module and the LDS kernels: 5 569 tiles = one full round of 5-tile bundles on the 1024 waves,
+    then single tiles."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import lstm_rl
+    from crowdnav_amd.compat.sarl import build_action_space
+    torch.manual_seed(60 + humans)
+    d = 61 if with_om else 13
+    net = lstm_rl.ValueNetwork1(d, 6, [150, 100, 100, 1], 50)
+    B = 1100
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for reg in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                           robot_visible=1)
+        eng.reset(3000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='lstm_rl', mlp1_dims=(50, 1),
+                           mlp3_dims=(150, 100, 100, 1), with_om=with_om)
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[reg] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), eng.sarl_export('X').cpu())
+    with torch.no_grad():
+        want = net(got['1'][2].reshape(B * 81, humans, d)).reshape(B, 81).numpy()
+    assert torch.equal(got['1'][2], got['0'][2])
+    assert np.abs(got['1'][0] - want).max() <= 2e-5 and np.abs(got['0'][0] - want).max() <= 2e-5
+    assert np.abs(got['1'][0] - got['0'][0]).max() <= 2e-6
+    assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True])
 def test_value_network_at_the_full_benchmark_size_vs_torch(with_om):
     """BASELINE configs[2] at full size: 4096 envs x 81 actions x 5 humans = 20 736 tiles through the register-resident kernel
