@@ -20,6 +20,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 

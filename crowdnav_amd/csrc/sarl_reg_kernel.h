@@ -48,6 +48,10 @@ __host__ __device__ constexpr int reg_cdiv(int a, int b) { return (a + b - 1) / 
 // The functions below describe a weight stream by a NETWORK KEY: for sarl.ValueNetwork the k-steps of its input, 4 (13
 // features) or 16 (13 + 48 occupancy-map features); kRegCadrl for cadrl.ValueNetwork (cadrl.py:22-29: 13 -> 150 -> 100 ->
 // 100 -> 1 on every (robot, human) row; layers 0..3).
+// kRegSarlPre: sarl.ValueNetwork on 61 inputs with the occupancy-map half of mlp1.0 hoisted out of the action loop — the 48 map
+// features of (env, human) are the same for all 81 actions, so  b + W[:, 13:61] om  is computed once per (env, human)
+// (sarl_om_term_kernel) and mlp1.0's accumulators START from it: 4 k-steps instead of 16, no bias quad.
+constexpr int kRegSarlPre = 5;
 constexpr int kRegCadrl = 1004;
 // lstm_rl.ValueNetwork1 (lstm_rl.py:9-33) is two streams: the LSTM cell's gate layer (one layer, re-read for every human:
 // kRegLstmGates + k-steps of the input) and the value head on [self (6) | h_n (50)] (4 layers).
@@ -68,7 +72,7 @@ __host__ __device__ constexpr RegShape reg_shape(int l, int xks) {
         }
     }
     switch (l) {
-        case kR_mlp1_0: return {xks, 10, 1, 0};
+        case kR_mlp1_0: return xks == kRegSarlPre ? RegShape{4, 10, 0, 0} : RegShape{xks, 10, 1, 0};
         case kR_mlp1_2: return {38, 7, 1, 0};
         case kR_mlp2_0: return {25, 7, 1, 0};
         case kR_mlp2_2: return {25, 4, 1, 0};
@@ -288,12 +292,16 @@ __device__ __forceinline__ void reg_dense_arr(RegStream& ws, In in, Init init, f
     constexpr RegShape S = reg_shape(L, XKS);
     constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
     static_assert(!S.paired && MT == S.mt && S.ks >= 4, "use reg_dense1");
+    constexpr bool kPerTileInit = std::is_invocable_v<Init, int, int>;  // init(nt, mt): a start value per N tile
     f32x4 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        f32x4 c0;
-        if constexpr (S.bias != 0) c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 0));
-        else c0 = init(mt);
+        f32x4 c0[kPerTileInit ? NT : 1];
+        if constexpr (S.bias != 0) c0[0] = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, 0));
+        else if constexpr (kPerTileInit) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) c0[nt] = init(nt, mt);
+        } else c0[0] = init(mt);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const f32x4 a = reg_take<QT>(ws, QB + reg_qpos(L, XKS, mt, S.bias + q));
@@ -304,8 +312,8 @@ __device__ __forceinline__ void reg_dense_arr(RegStream& ws, In in, Init init, f
                 if (ks < S.ks) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt & 1][nt] =
-                            __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], in(nt, ks), ks == 0 ? c0 : acc[mt & 1][nt], 0, 0, 0);
+                        acc[mt & 1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[kk], in(nt, ks), ks == 0 ? c0[kPerTileInit ? nt : 0] : acc[mt & 1][nt], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -386,12 +394,16 @@ __device__ __forceinline__ void reg_dense1(RegStream& ws, In in, f32x4 (&out)[MT
 // loads of a k-step hit one or two cache lines.
 // NT = humans of the crowd (N tiles per wave), 1..5.  With NT = 1 the MFMAs of a k-step chain are dependent (40 instead of 32
 // cycles each); from 2 humans on consecutive MFMAs alternate between accumulators.
-template <int XKS, int NT>
+// PRE (XKS = 4): `om` is the term of sarl_om_term_kernel, [env][human][10 tiles][4 lane groups][4 registers] — mlp1.0's
+// accumulator for (row, output tile) in the lane's own order, one 16-byte load each, requested one output tile ahead.
+template <int XKS, int NT, bool PRE = false>
 __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* stream, const float* X, float* V, int n_groups,
                                                                   int n_tiles, int ks_x, const int* hcount,
                                                                   const float* om = nullptr, int n_actions = 1) {
     static_assert(NT >= 1 && NT <= kRegHumans, "the activations of at most 5 humans fit the register file");
-    constexpr int QT = reg_total_quads(XKS);
+    static_assert(!PRE || XKS == 4, "the hoisted occupancy-map term replaces k-steps 4..15");
+    constexpr int KEY = PRE ? kRegSarlPre : XKS;
+    constexpr int QT = reg_total_quads(KEY);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
     RegStream ws;
@@ -424,6 +436,26 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
     };
     load_x(wid < n_tiles ? wid : 0);
     cnt = hcount[(size_t)(wid < n_tiles ? wid : 0) * kSarlGroups + (lane & 15)];
+    // PRE: mlp1.0's start values, output tile mt of N tile nt in pre[mt][nt] — all 10 x NT of the NEXT group tile are requested
+    // with its X, when the value head starts and 200 registers fall free (one output tile ahead was too late: 20 MFMAs are 640
+    // cycles, a loaded L2 answers later: 1.964 ms instead of 1.88)
+    // Buffer loads as for the weight stream: ONE lane offset (the env's rows, the lane group's 16 bytes), the (nt, mt) part in the
+    // instruction's immediate — with global_load the 50 64-bit addresses were 350 VALU instructions per tile.
+    f32x4 pre[PRE ? 10 : 1][PRE ? NT : 1];
+    __amdgpu_buffer_rsrc_t prsrc = ws.rsrc;
+    if constexpr (PRE)
+        prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(om), 0, (int)(((long long)n_groups / n_actions) * NT * 640), 0x00020000);
+    const auto load_pre = [&](int t) {
+        const long long G = (long long)t * kSarlGroups + (lane & 15);
+        const int env = (int)((G < n_groups ? G : (long long)n_groups - 1) / n_actions);
+        const uint32_t voff = (uint32_t)env * (NT * 640u) + (uint32_t)(lane >> 4) * 16u;
+#pragma unroll
+        for (int mt = 0; mt < 10; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                pre[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, voff + (nt * 40 + mt * 4) * 16, 0, 0));
+    };
+    if constexpr (PRE) load_pre(wid);
     // per-human features (mlp2 output, 80 registers) wait in LDS while the attention layers run: wave-private, no barrier
     __shared__ f32x4 park[kRegWaves][NT * 4][64];
     f32x4(*const mypark)[64] = park[threadIdx.x >> 6];
@@ -436,16 +468,22 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
             f32x4 h2[NT][7];
             {
                 f32x4 h1[NT][10];
-                reg_dense_arr<XKS, kR_mlp1_0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
+                if constexpr (PRE)
+                    reg_dense_arr<KEY, kR_mlp1_0, NT, true>(
+                        ws, [&](int nt, int ks) { return x[nt][ks]; },
+                        [&](int nt, int mt) { return pre[mt][nt]; },
+                        h1);
+                else
+                    reg_dense_arr<KEY, kR_mlp1_0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
                 CN_SARL_TICK(1);
-                reg_dense_arr<XKS, kR_mlp1_2, NT, false>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
+                reg_dense_arr<KEY, kR_mlp1_2, NT, false>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
                 CN_SARL_TICK(2);
             }
             {
                 f32x4 t1[NT][7];
-                reg_dense_arr<XKS, kR_mlp2_0, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, t1);
+                reg_dense_arr<KEY, kR_mlp2_0, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, t1);
                 CN_SARL_TICK(3);
-                reg_dense<XKS, kR_mlp2_2, NT, false>(ws, [&](int nt, int ks) { return t1[nt][ks >> 2][ks & 3]; }, none,
+                reg_dense<KEY, kR_mlp2_2, NT, false>(ws, [&](int nt, int ks) { return t1[nt][ks >> 2][ks & 3]; }, none,
                                                      [&](int nt, int mt, f32x4 v) { mypark[nt * 4 + mt][lane] = v; });
                 CN_SARL_TICK(4);
             }
@@ -465,20 +503,20 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
                     for (int i = 0; i < 4; ++i) gm[t][i] = sum[i] / fc;
                 }
                 // attention.0 on [h2 | mean]: the global half (+ the layer's bias) is one N tile, shared by the 5 humans
-                reg_dense1<XKS, kR_att0_global, false>(ws, [&](int ks) { return gm[ks >> 2][ks & 3]; }, gterm);
+                reg_dense1<KEY, kR_att0_global, false>(ws, [&](int ks) { return gm[ks >> 2][ks & 3]; }, gterm);
                 CN_SARL_TICK(5);
             }
             f32x4 a0[NT][7];
-            reg_dense_arr<XKS, kR_att0_local, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; },
+            reg_dense_arr<KEY, kR_att0_local, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; },
                                                         [&](int mt) { return gterm[mt]; }, a0);
             CN_SARL_TICK(6);
-            reg_dense_arr<XKS, kR_att_2, NT, false>(ws, [&](int nt, int ks) { return a0[nt][ks >> 2][ks & 3]; }, none, att);
+            reg_dense_arr<KEY, kR_att_2, NT, false>(ws, [&](int nt, int ks) { return a0[nt][ks >> 2][ks & 3]; }, none, att);
             CN_SARL_TICK(7);
         }
         f32x4 wf[4];
         {
             float sc[NT];  // attention.4: the score of (human, group) in every register of the group's lanes
-            reg_dense<XKS, kR_att_4, NT, false>(ws, [&](int nt, int ks) { return att[nt][ks >> 2][ks & 3]; }, none,
+            reg_dense<KEY, kR_att_4, NT, false>(ws, [&](int nt, int ks) { return att[nt][ks >> 2][ks & 3]; }, none,
                                                 [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
             CN_SARL_TICK(8);
             // masked softmax without max subtraction (sarl.py:52-53); an absent human carries no weight
@@ -508,18 +546,19 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         // the next tile's input (and this tile's last use of x is behind us)
         const int next = tile + nw < n_tiles ? tile + nw : tile;
         load_x(next);
+        if constexpr (PRE) load_pre(next);
         const int cnt_next = hcount[(size_t)next * kSarlGroups + (lane & 15)];
         // value head on joint = [self | weighted feature] (sarl.py:61-62)
         f32x4 j1[10], j2[7], j3[7], val[1];
         const float mix = lane < 32 ? wf[3][0] : self0;
-        reg_dense1<XKS, kR_mlp3_0, true>(
+        reg_dense1<KEY, kR_mlp3_0, true>(
             ws, [&](int ks) { return ks < 12 ? wf[ks >> 2][ks & 3] : ks == 12 ? mix : ks == 13 ? self1 : self0; }, j1);
         CN_SARL_TICK(10);
-        reg_dense1<XKS, kR_mlp3_2, true>(ws, [&](int ks) { return j1[ks >> 2][ks & 3]; }, j2);
+        reg_dense1<KEY, kR_mlp3_2, true>(ws, [&](int ks) { return j1[ks >> 2][ks & 3]; }, j2);
         CN_SARL_TICK(11);
-        reg_dense1<XKS, kR_mlp3_4, true>(ws, [&](int ks) { return j2[ks >> 2][ks & 3]; }, j3);
+        reg_dense1<KEY, kR_mlp3_4, true>(ws, [&](int ks) { return j2[ks >> 2][ks & 3]; }, j3);
         CN_SARL_TICK(12);
-        reg_dense1<XKS, kR_mlp3_6, false>(ws, [&](int ks) { return j3[ks >> 2][ks & 3]; }, val);
+        reg_dense1<KEY, kR_mlp3_6, false>(ws, [&](int ks) { return j3[ks >> 2][ks & 3]; }, val);
         if (lane < kSarlGroups) {
             const size_t G = (size_t)tile * kSarlGroups + lane;
             if (G < (size_t)n_groups) V[G] = val[0][0];
@@ -527,10 +566,44 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         cnt = cnt_next;
         // the stream position wraps to quad 0 here: the padding quads are consumed so that slot I % kRegDepth stays aligned
 #pragma unroll
-        for (int i = reg_qbase(reg_layers(XKS), XKS); i < QT; ++i) (void)reg_take<QT>(ws, i);
+        for (int i = reg_qbase(reg_layers(KEY), KEY); i < QT; ++i) (void)reg_take<QT>(ws, i);
         CN_SARL_TICK(13);
     }
     CN_SARL_CLOCK_END_N((n_tiles - wid + nw - 1) / nw);
+}
+
+// b + W[:, 13:61] om for every (env, human) and mlp1.0 output feature, in sarl_reg_kernel<4, NT, true>'s accumulator order:
+// term[((row * 10 + mt) * 4 + lg) * 4 + kk] = feature 16 mt + 4 kk + lg of row = env * H + human (0 beyond the 150 features).
+// Plain fma chain, bias first, map values in ascending order.  wom = [150][48] then the 150 biases (sarl_om_weights_kernel).
+constexpr int kOmTermRows = 32, kOmTermThreads = 192;
+__global__ __launch_bounds__(kOmTermThreads) void sarl_om_term_kernel(const float* wom, const float* om, float* term, int rows) {
+    __shared__ float w[48][161];  // [map value][accumulator slot]: a row's 160 threads read consecutive words
+    __shared__ float bias[160];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 48 * 160; i += kOmTermThreads) w[i / 160][i % 160] = 0.0f;
+    if (tid < 160) bias[tid] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < 150 * 49; i += kOmTermThreads) {
+        const int f = i < 150 * 48 ? i / 48 : i - 150 * 48;
+        const int slot = (f >> 4) * 16 + (f & 3) * 4 + ((f >> 2) & 3);  // feature 16 mt + 4 kk + lg -> (mt, lg, kk)
+        if (i < 150 * 48) w[i % 48][slot] = wom[i];
+        else bias[slot] = wom[i];
+    }
+    __syncthreads();
+    if (tid >= 160) return;
+    const int r0 = blockIdx.x * kOmTermRows, r1 = r0 + kOmTermRows < rows ? r0 + kOmTermRows : rows;
+    for (int row = r0; row < r1; ++row) {
+        const float* m = om + (size_t)row * 48;  // uniform address: scalar loads
+        float v = bias[tid];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) v = __builtin_fmaf(w[k][tid], m[k], v);
+        term[(size_t)row * 160 + tid] = v;
+    }
+}
+__global__ void sarl_om_weights_kernel(const float* W /*[150][61]*/, const float* b, float* wom) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 150 * 48) wom[idx] = W[(idx / 48) * 61 + 13 + idx % 48];
+    else if (idx < 150 * 49) wom[idx] = b[idx - 150 * 48];
 }
 
 // cadrl.ValueNetwork (cadrl.py:22-29) with the activations in registers: the same MLP for every (group, human) row — NT N tiles

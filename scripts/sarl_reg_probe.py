@@ -25,6 +25,7 @@ STAGES = [('(tile start)', 0), ('mlp1.0 13->150', 10 * 4 * 5), ('mlp1.2 150->100
 
 
 def main():
+    om = '--om' in sys.argv
     B = 4096
     lib = _lib.load()
     probe = lib.cn_debug_sarl_cycles
@@ -33,9 +34,9 @@ def main():
     eng.reset(2000 + np.arange(B))
     eng.step(np.zeros((B, 2)), update=True)
     torch.manual_seed(0)
-    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    net = ValueNetwork(61 if om else 13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
     space, _, _ = build_action_space(1.0)
-    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=om)
     eng.sarl_set_weights(net.state_dict())
     for _ in range(2):
         eng.sarl_select(want_values=False)

@@ -108,13 +108,18 @@ def test_sarl_mlp_vs_torch_fp32_random_inputs(humans, with_om):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('with_om', [False, True])
+@pytest.mark.parametrize('with_om', [False, True, 'maps inside the kernel'])
 def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
     """5 humans at the shipped widths run sarl_reg_kernel (activations in registers); CROWDNAV_AMD_SARL_REG=0 keeps the LDS
     pipe kernel on the same engine configuration.  Same inputs, same weights: both within 2e-5 of torch and within 1e-6 of
-    each other (they add the bias at opposite ends of the same fma chain), including a last tile of padding groups."""
+    each other (they add the bias at opposite ends of the same fma chain), including a last tile of padding groups.  With
+    occupancy maps the default hoists their half of mlp1.0 out of the action loop (sarl_om_term_kernel + sarl_reg_kernel<4, 5,
+    true>); CROWDNAV_AMD_SARL_OM_HOIST=0 keeps all 16 k-steps inside sarl_reg_kernel<16, 5>."""
     import crowdnav_amd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    if with_om == 'maps inside the kernel':
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_OM_HOIST', '0')
+        with_om = True
     torch.manual_seed(5)
     d = 61 if with_om else 13
     net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
