@@ -26,6 +26,8 @@ actually limits this kernel, only when the committed PMC profile is of the same 
 loop as timed in the build container) and `secondary` (BASELINE configs[2] and configs[3] measured in the same run).
 """
 import argparse
+import contextlib
+import gc
 import json
 import os
 import socket
@@ -84,6 +86,21 @@ def pmc_issue(rec, envs, steps_per_launch, launch_seconds):
     return out
 
 
+@contextlib.contextmanager
+def no_gc():
+    """Timed regions run with the cyclic garbage collector off (as timeit does): a generation-2 collection of a process with
+    torch loaded takes ~25 ms of HOST time; the launch loop is only a few steps ahead of the GPU right after the opening
+    synchronize, so the device drains and idles (r03 kernel trace: one 24 ms hole inside the 50 timed decisions of the third
+    measure_sarl of a process, every kernel as fast as before: 2.4 ms per decision read instead of 1.8).  The caller runs
+    gc.collect() BEFORE its opening fence: 25 ms of device idle time right in front of the first launch costs the driver shape
+    ~100 us of wake-up (20 steps: 251 us instead of 150)."""
+    gc.disable()
+    try:
+        yield
+    finally:
+        gc.enable()
+
+
 def sarl_flop(B, H, om):
     """algorithmic flops of one batched value-network decision: per (env, action) tile of H humans"""
     return 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B
@@ -113,6 +130,7 @@ def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
     ro.run(preroll)
     ro.run(warm)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    gc.collect()
     for e3 in ev:
         for e in e3:
             e.record()
@@ -121,15 +139,16 @@ def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
         dist.barrier()
         torch.cuda.synchronize()
     before = int(ro.transitions.item())
-    t0 = time.perf_counter()
-    for e0, e1, e2 in ev:
-        e0.record()
-        sel = eng.sarl_select(want_values=False)
-        e1.record()
-        eng.rollout_step(sel['action'])
-        e2.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        for e0, e1, e2 in ev:
+            e0.record()
+            sel = eng.sarl_select(want_values=False)
+            e1.record()
+            eng.rollout_step(sel['action'])
+            e2.record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     transitions = int(ro.transitions.item()) - before
@@ -155,9 +174,17 @@ def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
                                'value network is cn::sarl_reg_kernel)',
                      'select_ms': select_s * 1e3, 'step_ms': step_s * 1e3,
                      'frac_of_whole_step': flop / step_s / 1e12 / 157.3,
+                     'executed_frac': sarl_flop(B, H, False) / select_s / 1e12 / 157.3,
                      'note': 'algorithmic flops of the value network over the HIP-event time of cn_sarl_select; '
-                             'frac_of_whole_step: over select + transition + reset + bookkeeping'},
+                             'frac_of_whole_step: over select + transition + reset + bookkeeping; executed_frac: the flops '
+                             'the matrix pipe actually runs - with occupancy maps their half of mlp1.0 (7200 of 69250 MACs '
+                             'per row) is computed once per (env, human) instead of once per action, so the algorithmic '
+                             'figure counts work the kernel no longer does'},
     }
+    # destroy the engine NOW: left to the cyclic garbage collector, cn_destroy (a stream synchronize + hipFree of ~0.5 GB) ran in
+    # the middle of a LATER measurement's timed region - one 24 ms stall, +0.48 ms on each of its 50 decisions (r03: the second
+    # or third measure_sarl of a process read 2.3-2.5 ms instead of 1.8; kernel trace: every kernel as fast as before)
+    eng.close()
     del ro, eng
     torch.cuda.empty_cache()
     return out
@@ -203,6 +230,7 @@ def measure_h20(B, local_rank):
                'paused_env_steps': B * sum(lengths) - done,
                'roofline_frac_hbm': algorithmic_bytes_per_env_step(H) * done / secs / 1e9 / HBM_PEAK_GBS}
         sim.sync()
+        sim.close()
         del sim, bufs
         torch.cuda.empty_cache()
         return res
@@ -221,16 +249,65 @@ def measure_h20(B, local_rank):
     }
 
 
+def measure_policy_decision(B, H, policy, local_rank, iters=20):
+    """cn_sarl_select alone for the reference's two baseline value networks (cadrl.py:22-29, lstm_rl.py:9-33; random-init
+    weights): HIP-event time per batched decision and the algorithmic flops of the network over it."""
+    import numpy as np
+    import torch
+    import crowdnav_amd
+    from crowdnav_amd.compat import cadrl, lstm_rl
+    from crowdnav_amd.compat.sarl import build_action_space
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1,
+                                       device=local_rank)
+    eng.reset(2000 + np.arange(B))
+    eng.step(np.zeros((B, 2)), update=True)
+    torch.manual_seed(0)
+    space, _, _ = build_action_space(1.0)
+    acts = np.array([[a.vx, a.vy] for a in space])
+    head = 150 * 100 + 100 * 100 + 100
+    if policy == 'cadrl':
+        net = cadrl.ValueNetwork(13, [150, 100, 100, 1])
+        eng.sarl_configure(actions=acts, model='cadrl', mlp3_dims=(150, 100, 100, 1))
+        flop = 2 * 81 * H * (13 * 150 + head) * B
+    else:
+        net = lstm_rl.ValueNetwork1(13, 6, [150, 100, 100, 1], 50)
+        eng.sarl_configure(actions=acts, model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
+        flop = 2 * 81 * (H * 200 * (13 + 50) + 56 * 150 + head) * B
+    eng.sarl_set_weights(net.state_dict())
+    for _ in range(3):
+        eng.sarl_select(want_values=False)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    gc.collect()
+    with no_gc():
+        for a, b in ev:
+            a.record()
+            eng.sarl_select(want_values=False)
+            b.record()
+        torch.cuda.synchronize()
+    select_s = sum(a.elapsed_time(b) for a, b in ev) / 1e3 / iters
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return {'workload': '%d envs x %d humans, 81 actions, %s value network, one batched decision' % (B, H, policy),
+            'decisions_per_s': B / select_s,
+            'roofline': {'bound': 'mfma', 'achieved': flop / select_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
+                         'frac': flop / select_s / 1e12 / 157.3, 'select_ms': select_s * 1e3,
+                         'kernel': 'cn_sarl_select; the value network is cn::%s' %
+                                   ('cadrl_reg_kernel' if policy == 'cadrl' else 'lstm_reg_kernel'),
+                         'note': 'algorithmic flops (unpadded layer widths) over the HIP-event time of cn_sarl_select'}}
+
+
 def secondary(B, local_rank):
     """BASELINE configs[2] (SARL / OM-SARL value-network rollouts) and configs[3] (20 humans) measured in the SAME run as
     the headline, after its timed region, so that the driver's record carries them."""
     out = {}
-    for om in (True, False):  # (OM first: measured after the plain engine has been freed, its 425 MB feature buffer lands on
-                              # recycled allocations and the same kernels run 16 % slower; in this order both match their standalone runs)
+    for om in (False, True):
         r = measure_sarl(B, 5, om, 50, 10, 30, 1, 0, local_rank)
         key = 'om_sarl' if om else 'sarl'
         out[key] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'roofline')}
         out[key]['workload'] = r['config']['workload']
+    for policy in ('cadrl', 'lstm_rl'):
+        out[policy] = measure_policy_decision(B, 5, policy, local_rank)
     out['h20'] = measure_h20(B, local_rank)
     return out
 
@@ -415,6 +492,7 @@ def main():
         return eng.records_summary(cd.gather_blocks(bufs['blocks']), record_capacity=4)
 
     run(args.preroll)
+    gc.collect()  # (before the warm-up launches: see no_gc)
     run(args.warmup)
     shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
     fence()
@@ -422,10 +500,11 @@ def main():
     ep_before = float(bufs['summary'][0].item())
     events = []
     fence()  # barrier + synchronize
-    t0 = time.perf_counter()
-    run(args.steps, events)
-    drain()  # this rank's K steps are done (synchronize) ...
-    elapsed = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        run(args.steps, events)
+        drain()  # this rank's K steps are done (synchronize) ...
+        elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()  # ... and every rank's, before anything else is launched
     tb = time.perf_counter()
@@ -488,6 +567,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(B, H)
     if rank == 0 and world == 1 and not args.no_secondary and (B, H) == (4096, 5):
         eng.sync()
+        eng.close()
         del eng, bufs
         torch.cuda.empty_cache()
         out['secondary'] = secondary(B, local_rank)

@@ -82,17 +82,44 @@ struct cn_engine {
     bool mt_in_lds;    // lane-per-scenario generators keep their MT19937 state in LDS instead of HBM
     bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
     size_t smem;       // dynamic LDS bytes per workgroup
-    std::vector<void*> allocs;
+    // Device memory comes from a few large slabs, not one hipMalloc per buffer: an engine has ~60 device buffers, most of them a
+    // few KiB; one 32 MiB slab (plus one per buffer larger than that) is 2-4 mappings to create and - each hipFree being a device
+    // synchronisation - 2-4 to tear down, and cn_sarl_configure can roll a failed configuration back to a mark.
+    struct Slab {
+        char* base;
+        size_t size, used;
+    };
+    std::vector<Slab> slabs;
+    struct AllocMark {
+        size_t n_slabs, used;
+    };
+    AllocMark alloc_mark() const { return {slabs.size(), slabs.empty() ? 0 : slabs.back().used}; }
+    void alloc_rollback(AllocMark m) {  // frees everything allocated since alloc_mark()
+        while (slabs.size() > m.n_slabs) {
+            (void)hipFree(slabs.back().base);
+            slabs.pop_back();
+        }
+        if (!slabs.empty()) slabs.back().used = m.used;
+    }
 };
 
 namespace {
 
+constexpr size_t kSlabBytes = (size_t)32 << 20, kSlabAlign = 4096;
+
 template <typename T>
 int dev_alloc(cn_engine* e, T** out, size_t n) {
-    void* p = nullptr;
-    CN_HIP(hipMalloc(&p, n * sizeof(T)));
-    CN_HIP(hipMemset(p, 0, n * sizeof(T)));
-    e->allocs.push_back(p);
+    const size_t bytes = (n * sizeof(T) + kSlabAlign - 1) / kSlabAlign * kSlabAlign;
+    if (e->slabs.empty() || e->slabs.back().used + bytes > e->slabs.back().size) {
+        const size_t size = bytes > kSlabBytes ? (bytes + ((size_t)2 << 20) - 1) >> 21 << 21 : kSlabBytes;
+        void* p = nullptr;
+        CN_HIP(hipMalloc(&p, size));
+        e->slabs.push_back({static_cast<char*>(p), size, 0});
+    }
+    cn_engine::Slab& sl = e->slabs.back();
+    void* p = sl.base + sl.used;
+    sl.used += bytes;
+    CN_HIP(hipMemset(p, 0, bytes));
     *out = static_cast<T*>(p);
     return CN_OK;
 }
@@ -341,7 +368,7 @@ int cn_destroy(cn_engine* e) {
             (void)hipStreamDestroy(e->fill_streams[i]);
         }
     if (e->rollout_done) (void)hipEventDestroy(e->rollout_done);
-    for (void* p : e->allocs) (void)hipFree(p);
+    e->alloc_rollback({0, 0});
     if (e->discount) (void)hipFree(e->discount);
     sarl_release(e);
     delete e;

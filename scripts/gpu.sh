@@ -37,6 +37,8 @@ for l in open('$OUT/bench_driver.log'):
         d = json.loads(l); s = d.get('secondary') or {}
         for k in ('sarl', 'om_sarl'):
             if k in s: print(k, round(s[k]['value'] / 1e6, 3), 'M env-steps/s, select ms', round(s[k]['roofline']['select_ms'], 3), 'mfma frac', round(s[k]['roofline']['frac'], 3))
+        for k in ('cadrl', 'lstm_rl'):
+            if k in s: print(k, 'select ms', round(s[k]['roofline']['select_ms'], 3), 'mfma frac', round(s[k]['roofline']['frac'], 3))
         for k, v in (s.get('h20') or {}).items():
             if isinstance(v, dict): print('h20', k, round(v['value'] / 1e6, 2), 'M env-steps/s, paused', v['paused_env_steps'])
         print('cpu', {k: (round(v) if isinstance(v, float) else v) for k, v in (d.get('cpu_baseline') or {}).items() if k in ('value', 'cores', 'single_core_value')})
