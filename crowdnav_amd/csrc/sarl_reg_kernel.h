@@ -57,12 +57,41 @@ constexpr int kRegCadrl = 1004;
 // kRegLstmGates + k-steps of the input) and the value head on [self (6) | h_n (50)] (4 layers).
 constexpr int kRegLstmGates = 2000, kRegLstmHead = 2100, kRegLstmHid = 50, kRegLstmKs = 13;  // 13 k-steps / output tiles of 50 units
 __host__ __device__ constexpr bool reg_is_gates(int key) { return key > kRegLstmGates && key < kRegLstmHead; }
+// sarl.ValueNetwork for MORE than 5 humans (sarl_reg_chunk_kernel): the humans pass in chunks of NT, so the network is three
+// streams — A: mlp1.0, mlp1.2 (re-read per chunk, first pass; APre: mlp1.0 starts from the hoisted occupancy-map term),
+// G: attention.0's global half, then — after the second pass — the value head (read once per tile, in this order),
+// B: mlp2.0, mlp2.2, attention.0 local, attention.2, attention.4 (re-read per chunk, second pass).
+constexpr int kRegChunkA = 3001, kRegChunkAPre = 3002, kRegChunkB = 3003, kRegChunkG = 3004;
 __host__ __device__ constexpr int reg_layers(int key) {
-    return key == kRegCadrl || key == kRegLstmHead ? 4 : reg_is_gates(key) ? 1 : (int)kRegLayers;
+    return key == kRegCadrl || key == kRegLstmHead ? 4
+           : reg_is_gates(key)                       ? 1
+           : key == kRegChunkA || key == kRegChunkAPre ? 2
+           : key == kRegChunkB || key == kRegChunkG    ? 5
+                                                       : (int)kRegLayers;
 }
 
 __host__ __device__ constexpr RegShape reg_shape(int l, int xks) {
     if (reg_is_gates(xks)) return {xks - kRegLstmGates + kRegLstmKs, kRegLstmKs, 1, 0};  // [x_t | h_(t-1)] -> i, f, g, o of 4 units per tile
+    if (xks == kRegChunkA || xks == kRegChunkAPre)
+        return l == 0 ? (xks == kRegChunkAPre ? RegShape{4, 10, 0, 0} : RegShape{4, 10, 1, 0}) : RegShape{38, 7, 1, 0};
+    if (xks == kRegChunkB) {
+        switch (l) {
+            case 0: return {25, 7, 1, 0};   // mlp2.0
+            case 1: return {25, 4, 1, 0};   // mlp2.2
+            case 2: return {25, 7, 0, 0};   // attention.0, local half: starts from the global term
+            case 3: return {25, 7, 1, 0};   // attention.2
+            default: return {25, 1, 1, 0};  // attention.4
+        }
+    }
+    if (xks == kRegChunkG) {
+        switch (l) {
+            case 0: return {25, 7, 1, 1};   // attention.0, global half (+ the layer's bias)
+            case 1: return {15, 10, 1, 1};  // mlp3.0 on [weighted feature | self], as kR_mlp3_0
+            case 2: return {38, 7, 1, 1};
+            case 3: return {25, 7, 1, 1};
+            default: return {25, 1, 1, 1};
+        }
+    }
     if (xks == kRegCadrl || xks == kRegLstmHead) {
         switch (l) {
             case 0: return {xks == kRegCadrl ? 4 : 15, 10, 1, 0};
@@ -113,7 +142,8 @@ __host__ __device__ constexpr int reg_qpos(int l, int xks, int mt, int j) {
 __host__ __device__ constexpr int reg_kcol(int key, int l, int K, int k_off, int ks, int lg) {
     if (key == kRegLstmHead && l == 0)
         return ks < kRegLstmKs ? (4 * ks + lg < kRegLstmHid ? 6 + 4 * ks + lg : -1) : ks == 13 ? lg : lg < 2 ? 4 + lg : -1;
-    if (key >= 1000 || l != kR_mlp3_0) return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
+    if ((key >= 1000 && !(key == kRegChunkG && l == 1)) || (key < 1000 && l != kR_mlp3_0))
+        return 4 * ks + lg < K ? k_off + 4 * ks + lg : -1;
     if (ks < 12) return 6 + 4 * ks + lg;
     if (ks == 12) return lg < 2 ? 6 + 48 + lg : lg;
     if (ks == 13) return lg < 2 ? 4 + lg : -1;
@@ -780,6 +810,189 @@ __global__ __launch_bounds__(kRegWaves * 64) void lstm_reg_kernel(const float* g
     }
     for (int tile = done + wid; tile < n_tiles; tile += nw)
         lstm_reg_bundle<XKS, 1>(wg, wh, X, V, n_groups, H, ks_x, hcount, tile, lane);
+}
+
+// ---- sarl.ValueNetwork (sarl.py:28-65) for more than 5 humans, activations in registers ----------------------------------
+// The humans of a tile's 16 groups pass in n_chunks chunks of NT (3 or 4: human h = chunk * NT + nt; indices beyond the crowd
+// repeat its last human and are masked like the absent humans of the `mixed` rule).  Two passes, because attention.0 needs
+// the mean of mlp1's output over ALL humans (sarl.py:42-46) before any score exists:
+//   pass 1  per chunk: mlp1 -> h2 (NT x 7 registers of f32x4), summed over the humans present, and parked in a per-wave
+//           global scratch (7 KiB per human: written and read back by the same lane, loads bypass L1);
+//   then    the mean, attention.0's global term (one N tile);
+//   pass 2  per chunk: h2 back from the scratch, mlp2 -> features (wave-private LDS), attention -> score, and — as the chunked
+//           LDS kernel does — exp(score) and exp(score) x feature accumulate per group; the division by the total comes last
+//           (the reference divides first: w_h = e_h / total, then sums w_h f_h — same value to rounding);
+//   then    the value head.
+// PRE as in sarl_reg_kernel: mlp1.0 starts from the hoisted occupancy-map term instead of its bias.
+template <int NT, bool PRE>
+__global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_chunk_kernel(const float* sa, const float* sb, const float* sg, const float* X,
+                                                                        float* V, float* scratch, int n_groups, int n_tiles, int H,
+                                                                        int n_chunks, int ks_x, const int* hcount, const float* term,
+                                                                        int n_actions) {
+    static_assert(NT == 3 || NT == 4, "two accumulator sets, mlp1's 17 tiles and three weight queues fit the register file up to 4 N tiles");
+    constexpr int KA = PRE ? kRegChunkAPre : kRegChunkA, KB = kRegChunkB, KG = kRegChunkG;
+    constexpr int QA = reg_total_quads(KA), QB = reg_total_quads(KB), QG = reg_total_quads(KG);
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
+    RegStream wa, wb, wg;
+    wa.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa), 0, QA * 1024, 0x00020000);
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sb), 0, QB * 1024, 0x00020000);
+    wg.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg), 0, QG * 1024, 0x00020000);
+    wa.voff = wb.voff = wg.voff = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < kRegDepth; ++i) wa.q[i] = reg_quad(wa, i), wb.q[i] = reg_quad(wb, i), wg.q[i] = reg_quad(wg, i);
+    if (wid >= n_tiles) return;
+    // the wave's scratch: [chunk][nt][7 quads][64 lanes] of f32x4
+    const int wave_bytes = n_chunks * NT * 7 * 1024;
+    const __amdgpu_buffer_rsrc_t hrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(scratch + (size_t)wid * (wave_bytes / 4), 0, wave_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t prsrc = wa.rsrc;
+    if constexpr (PRE)
+        prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(term), 0, (int)(((long long)n_groups / n_actions) * H * 640), 0x00020000);
+    const gfloat_p Xg = as_global(X) + lane;
+    __shared__ f32x4 park[kRegWaves][NT * 4][64];
+    f32x4(*const mypark)[64] = park[threadIdx.x >> 6];
+    const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+    const auto human = [&](int c, int nt) { return c * NT + nt < H ? c * NT + nt : H - 1; };
+    for (int tile = wid; tile < n_tiles; tile += nw) {
+        const int cnt = hcount[(size_t)tile * kSarlGroups + (lane & 15)];
+        const long long G = (long long)tile * kSarlGroups + (lane & 15);
+        const uint32_t env_off = (uint32_t)((G < n_groups ? G : (long long)n_groups - 1) / n_actions) * (uint32_t)(H * 640) +
+                                 (uint32_t)(lane >> 4) * 16u;
+        float x[NT][4];
+        // PRE: the term of output tile mt in pre[mt & 1][nt]; tile 0 travels with the chunk's X, tile mt + 1 is requested when tile mt
+        // is consumed (all ten at once do not fit beside mlp1's 17 tiles of activations here)
+        f32x4 pre[2][PRE ? NT : 1];
+        uint32_t prow[NT];
+        const auto load_chunk = [&](int c) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int h = human(c, nt);
+                const gfloat_p xt = Xg + ((size_t)tile * H + h) * ks_x * 64;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x[nt][ks] = xt[ks * 64];
+                if constexpr (PRE) {
+                    prow[nt] = env_off + (uint32_t)h * 640u;
+                    pre[0][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, prow[nt], 0, 0));
+                }
+            }
+        };
+        // ---- pass 1
+        load_chunk(0);
+        const float self0 = x[0][0], self1 = x[0][1];  // self state = features 0..5 of any row (sarl.py:37)
+        f32x4 gsum[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) gsum[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            f32x4 h2[NT][7];
+            {
+                f32x4 h1[NT][10];
+                if constexpr (PRE)
+                    reg_dense_arr<KA, 0, NT, true>(
+                        wa, [&](int nt, int ks) { return x[nt][ks]; },
+                        [&](int nt, int mt) {
+                            const f32x4 v = pre[mt & 1][nt];
+                            if (mt + 1 < 10)
+                                pre[(mt + 1) & 1][nt] =
+                                    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, prow[nt] + (mt + 1) * 64, 0, 0));
+                            return v;
+                        },
+                        h1);
+                else
+                    reg_dense_arr<KA, 0, NT, true>(wa, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
+                load_chunk(c + 1 < n_chunks ? c + 1 : c);  // x / pre are dead: the next chunk's travel while this one computes
+                reg_dense_arr<KA, 1, NT, false>(wa, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
+            }
+#pragma unroll
+            for (int i = reg_qbase(2, KA); i < QA; ++i) (void)reg_take<QA>(wa, i);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool present = c * NT + nt < cnt;
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gsum[t][i] += present ? h2[nt][t][i] : 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h2[nt][t]), hrsrc, (uint32_t)lane * 16u + (nt * 7 + t) * 1024,
+                                                           c * (NT * 7 * 1024), 0);
+                }
+            }
+        }
+        // ---- the global state and its attention term
+        f32x4 gterm[7];
+        {
+            const float fc = (float)cnt;
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gsum[t][i] = gsum[t][i] / fc;
+            reg_dense1<KG, 0, false>(wg, [&](int ks) { return gsum[ks >> 2][ks & 3]; }, gterm);
+        }
+        // ---- pass 2
+        f32x4 wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        float den = 0.0f;
+        f32x4 h2[NT][7];
+        const auto load_h2 = [&](int c) {  // glc: the lines were written by this lane a moment ago and may sit stale in L1
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int t = 0; t < 7; ++t)
+                    h2[nt][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (uint32_t)lane * 16u + (nt * 7 + t) * 1024,
+                                                                                               c * (NT * 7 * 1024), 1));
+        };
+        load_h2(0);
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            f32x4 att[NT][7];
+            {
+                {
+                    f32x4 t1[NT][7];
+                    reg_dense_arr<KB, 0, NT, true>(wb, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, t1);
+                    reg_dense<KB, 1, NT, false>(wb, [&](int nt, int ks) { return t1[nt][ks >> 2][ks & 3]; }, none,
+                                                [&](int nt, int mt, f32x4 v) { mypark[nt * 4 + mt][lane] = v; });
+                }
+                f32x4 a0[NT][7];
+                reg_dense_arr<KB, 2, NT, true>(wb, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; },
+                                               [&](int mt) { return gterm[mt]; }, a0);
+                load_h2(c + 1 < n_chunks ? c + 1 : c);  // h2 is dead: the next chunk's comes back during attention.2 / .4
+                reg_dense_arr<KB, 3, NT, false>(wb, [&](int nt, int ks) { return a0[nt][ks >> 2][ks & 3]; }, none, att);
+            }
+            float sc[NT];
+            reg_dense<KB, 4, NT, false>(wb, [&](int nt, int ks) { return att[nt][ks >> 2][ks & 3]; }, none,
+                                        [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
+#pragma unroll
+            for (int i = reg_qbase(5, KB); i < QB; ++i) (void)reg_take<QB>(wb, i);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {  // masked softmax without max subtraction (sarl.py:52-53), unnormalised
+                const float s_ = sc[nt];
+                const float e = c * NT + nt < cnt ? expf(s_) * (s_ != 0.0f ? 1.0f : 0.0f) : 0.0f;
+                den += e;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 f = mypark[nt * 4 + t][lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[t][i] += e * f[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[t][i] = wf[t][i] / den;
+        // ---- value head on joint = [self | weighted feature] (sarl.py:61-62)
+        f32x4 j1[10], j2[7], j3[7], val[1];
+        const float mix = lane < 32 ? wf[3][0] : self0;
+        reg_dense1<KG, 1, true>(
+            wg, [&](int ks) { return ks < 12 ? wf[ks >> 2][ks & 3] : ks == 12 ? mix : ks == 13 ? self1 : self0; }, j1);
+        reg_dense1<KG, 2, true>(wg, [&](int ks) { return j1[ks >> 2][ks & 3]; }, j2);
+        reg_dense1<KG, 3, true>(wg, [&](int ks) { return j2[ks >> 2][ks & 3]; }, j3);
+        reg_dense1<KG, 4, false>(wg, [&](int ks) { return j3[ks >> 2][ks & 3]; }, val);
+#pragma unroll
+        for (int i = reg_qbase(5, KG); i < QG; ++i) (void)reg_take<QG>(wg, i);
+        if (lane < kSarlGroups && G < (long long)n_groups) V[G] = val[0][0];
+    }
 }
 
 }  // namespace cn

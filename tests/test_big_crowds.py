@@ -43,8 +43,12 @@ def test_big_crowd_fixtures_hold_twelve_humans_cpu():
 
 
 @pytest.mark.gpu
-def test_om_sarl_twelve_humans_vs_reference():
+@pytest.mark.parametrize('kernels', ['by-size', 'register-resident'])
+def test_om_sarl_twelve_humans_vs_reference(kernels, monkeypatch):
+    """... on the chunked LDS kernel this batch size selects, and on sarl_reg_chunk_kernel<4, true> (forced: 3 chunks of 4)."""
     from crowdnav_amd.compat.sarl import ValueNetwork
+    if kernels == 'register-resident':
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', '2')
     g = load_golden('sarl_om_h12.npz')
     eng = _select(g, with_om=True)
     eng.sarl_set_weights(_load(ValueNetwork(61, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4),

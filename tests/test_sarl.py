@@ -179,6 +179,38 @@ def test_register_resident_value_network_for_one_to_four_humans(humans, with_om,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans,with_om', [(6, False), (6, True), (7, False), (9, True), (10, False), (13, True)])
+def test_register_resident_value_network_for_more_than_five_humans(humans, with_om, monkeypatch):
+    """sarl_reg_chunk_kernel<NT, PRE>: the humans pass in chunks of 3 or 4 (6 = 3 + 3, 7 = 4 + 3 with one repeated and masked
+    row, 9 = 3 x 3, 10 = 4 + 4 + 2, 13 = 4 x 4 - 3), mlp1's output parked in the per-wave scratch between the two passes; against
+    the torch module and the chunked LDS kernel, on more tiles than resident waves and a ragged last tile."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(80 + humans)
+    d = 61 if with_om else 13
+    net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    B = 203
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for reg in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                           robot_visible=1, circle_radius=6.0)
+        eng.reset(3000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[reg] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), eng.sarl_export('X').cpu())
+    with torch.no_grad():
+        want = net(got['1'][2].reshape(B * 81, humans, d)).reshape(B, 81).numpy()
+    assert torch.equal(got['1'][2], got['0'][2])
+    assert np.abs(got['1'][0] - want).max() <= 2e-5 and np.abs(got['0'][0] - want).max() <= 2e-5
+    assert np.abs(got['1'][0] - got['0'][0]).max() <= 2e-6
+    assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('humans', [1, 2, 3, 4, 5])
 def test_register_resident_cadrl_value_network(humans, monkeypatch):
     """cadrl_reg_kernel<NT> (cadrl.ValueNetwork with the activations in registers, minimum over the humans in the epilogue)
