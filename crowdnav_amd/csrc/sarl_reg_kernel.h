@@ -641,7 +641,7 @@ __global__ void sarl_om_weights_kernel(const float* W /*[150][61]*/, const float
 // (cadrl.py:162-163: torch.min over dim 0, the first minimum's value).  X, hcount, V as for sarl_reg_kernel.
 template <int NT>
 __global__ __launch_bounds__(kRegWaves * 64) void cadrl_reg_kernel(const float* stream, const float* X, float* V, int n_groups,
-                                                                   int n_tiles, int ks_x, const int* hcount) {
+                                                                   int n_tiles, int ks_x, const int* hcount, int H, int n_chunks) {
     static_assert(NT >= 1 && NT <= kRegHumans, "the activations of at most 5 humans fit the register file");
     constexpr int NK = kRegCadrl, QT = reg_total_quads(NK);
     const int lane = threadIdx.x & 63;
@@ -654,44 +654,50 @@ __global__ __launch_bounds__(kRegWaves * 64) void cadrl_reg_kernel(const float* 
     if (wid >= n_tiles) return;
     const gfloat_p Xg = as_global(X) + lane;
     float x[NT][4];
-    const auto load_x = [&](int t) {
-        const gfloat_p xt = Xg + (size_t)t * NT * ks_x * 64;
+    // chunk c of a tile = humans c NT .. c NT + NT - 1 (more than 5 humans: n_chunks > 1; indices beyond the crowd repeat its last
+    // human and never win the minimum)
+    const auto load_x = [&](int t, int c) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            const int h = c * NT + nt < H ? c * NT + nt : H - 1;
+            const gfloat_p xt = Xg + ((size_t)t * H + h) * ks_x * 64;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) x[nt][ks] = xt[(nt * ks_x + ks) * 64];
+            for (int ks = 0; ks < 4; ++ks) x[nt][ks] = xt[ks * 64];
+        }
     };
-    load_x(wid);
-    int cnt = hcount[(size_t)wid * kSarlGroups + (lane & 15)];
+    load_x(wid, 0);
     const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
     for (int tile = wid; tile < n_tiles; tile += nw) {
-        const int next = tile + nw < n_tiles ? tile + nw : tile;
-        int cnt_next;
-        f32x4 h3[NT][7];
-        {
-            f32x4 h2[NT][7];
+        const int cnt = hcount[(size_t)tile * kSarlGroups + (lane & 15)];
+        float m = 0.0f;
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            f32x4 h3[NT][7];
             {
-                f32x4 h1[NT][10];
-                reg_dense_arr<NK, 0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
-                load_x(next);  // x is dead: the next tile's rows travel while this one computes
-                cnt_next = hcount[(size_t)next * kSarlGroups + (lane & 15)];
-                reg_dense_arr<NK, 1, NT, false>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
+                f32x4 h2[NT][7];
+                {
+                    f32x4 h1[NT][10];
+                    reg_dense_arr<NK, 0, NT, true>(ws, [&](int nt, int ks) { return x[nt][ks]; }, none, h1);
+                    // x is dead: the next chunk's (or the next tile's first chunk's) rows travel while this one computes
+                    if (c + 1 < n_chunks) load_x(tile, c + 1);
+                    else load_x(tile + nw < n_tiles ? tile + nw : tile, 0);
+                    reg_dense_arr<NK, 1, NT, false>(ws, [&](int nt, int ks) { return h1[nt][ks >> 2][ks & 3]; }, none, h2);
+                }
+                reg_dense_arr<NK, 2, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, h3);
             }
-            reg_dense_arr<NK, 2, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, h3);
-        }
-        float sc[NT];
-        reg_dense<NK, 3, NT, false>(ws, [&](int nt, int ks) { return h3[nt][ks >> 2][ks & 3]; }, none,
-                                    [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
-        float m = sc[0];
+            float sc[NT];
+            reg_dense<NK, 3, NT, false>(ws, [&](int nt, int ks) { return h3[nt][ks >> 2][ks & 3]; }, none,
+                                        [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
 #pragma unroll
-        for (int nt = 1; nt < NT; ++nt) m = (nt < cnt && sc[nt] < m) ? sc[nt] : m;
+            for (int i = reg_qbase(reg_layers(NK), NK); i < QT; ++i) (void)reg_take<QT>(ws, i);
+            if (c == 0) m = sc[0];  // torch.min over dim 0: the first minimum's value
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) m = (c * NT + nt < cnt && sc[nt] < m) ? sc[nt] : m;
+        }
         if (lane < kSarlGroups) {
             const size_t G = (size_t)tile * kSarlGroups + lane;
             if (G < (size_t)n_groups) V[G] = m;
         }
-        cnt = cnt_next;
-#pragma unroll
-        for (int i = reg_qbase(reg_layers(NK), NK); i < QT; ++i) (void)reg_take<QT>(ws, i);
     }
 }
 

@@ -104,8 +104,11 @@ def test_lstm_rl_pairwise_twelve_humans_vs_torch():
 
 
 @pytest.mark.gpu
-def test_cadrl_twelve_humans_vs_reference():
+@pytest.mark.parametrize('kernels', ['by-size', 'register-resident'])
+def test_cadrl_twelve_humans_vs_reference(kernels, monkeypatch):
     from crowdnav_amd.compat.cadrl import ValueNetwork
+    if kernels == 'register-resident':
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', '2')  # cadrl_reg_kernel<4>, 3 chunks
     g = load_golden('cadrl_h12.npz')
     eng = _select(g, model='cadrl', mlp3_dims=(150, 100, 100, 1))
     eng.sarl_set_weights(_load(ValueNetwork(13, [150, 100, 100, 1]), g).state_dict())

@@ -211,10 +211,11 @@ def test_register_resident_value_network_for_more_than_five_humans(humans, with_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('humans', [1, 2, 3, 4, 5])
+@pytest.mark.parametrize('humans', [1, 2, 3, 4, 5, 6, 7, 11])
 def test_register_resident_cadrl_value_network(humans, monkeypatch):
     """cadrl_reg_kernel<NT> (cadrl.ValueNetwork with the activations in registers, minimum over the humans in the epilogue)
-    against the torch module and the LDS kernel, on more tiles than resident waves and a ragged last tile."""
+    against the torch module and the LDS kernels, on more tiles than resident waves and a ragged last tile; more than 5 humans
+    pass in chunks (6 = 3 + 3, 7 = 4 + 3 with one repeated row, 11 = 4 + 4 + 3 with one)."""
     import crowdnav_amd
     from crowdnav_amd.compat import cadrl
     from crowdnav_amd.compat.sarl import build_action_space
@@ -226,7 +227,7 @@ def test_register_resident_cadrl_value_network(humans, monkeypatch):
     for reg in ('1', '0'):
         monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
         eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
-                                           robot_visible=1)
+                                           robot_visible=1, circle_radius=4.0 if humans <= 5 else 6.0)
         eng.reset(3000 + np.arange(B))
         eng.step(np.zeros((B, 2)), update=True)
         eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='cadrl', mlp3_dims=(150, 100, 100, 1))
