@@ -321,28 +321,30 @@ class Explorer(object):
             dmn = torch.zeros(max_steps, B, dtype=torch.float64, device=eng.device)
             act = torch.zeros(max_steps, B, dtype=torch.int32, device=eng.device)
             alive = torch.ones(B, dtype=torch.uint8, device=eng.device)
-            bad = torch.zeros(B, dtype=torch.bool, device=eng.device)
+            done = torch.zeros(B, dtype=torch.uint8, device=eng.device)
+            action = torch.zeros(B, 2, dtype=torch.float64, device=eng.device)
             T = 0
+            # Per step: the engine's kernels and ONE torch kernel — every result lands in its row of the histories (the dozen
+            # torch copies / compares per step this loop used to issue cost as much host time as the step costs device time:
+            # 158 us per step at one env, BASELINE configs[4]'s sampling)
             for t in range(max_steps):
-                sel = eng.sarl_select(want_values=False)
+                sel = eng.sarl_select(want_values=False, best=act[t], action=action)
                 eng.sarl_explore(sel, policy.epsilon, mask=alive, want_explored=False)
-                bad |= (sel['best'] == -2) & (alive != 0)  # greedy branch without a finite value
                 eng.sarl_transform(out=traj[:, t], env_stride=max_steps * human_num * D)
-                out = eng.step(sel['action'], update=True, want_obs=False)
-                rew[t], inf[t], dmn[t], act[t] = out['reward'], out['info'], out['dmin'], sel['best']
-                alive = alive & (out['done'] == 0).to(torch.uint8)
+                eng.step_into(action, rew[t], done, inf[t], dmn[t])
+                alive.masked_fill_(done.view(torch.bool), 0)
                 T = t + 1
                 if t % 8 == 7 and not bool(alive.any().item()):
                     break
             eng.sync()
-            if bool(bad.any().item()):
-                raise ValueError('Value network is not well trained. ')  # multi_human_rl.py:57-58
             R, I, Dm = rew[:T].cpu().numpy(), inf[:T].cpu().numpy(), dmn[:T].cpu().numpy()
             Ac = act[:T].cpu().numpy()
             terminal = I >= _lib.REACH_GOAL
             if not terminal.any(axis=0).all():
                 raise ValueError('Invalid end signal from environment')
             Tb = terminal.argmax(axis=0) + 1                                   # steps of every episode
+            if ((Ac == -2) & (np.arange(T)[:, None] < Tb[None, :])).any():    # greedy branch without a finite value
+                raise ValueError('Value network is not well trained. ')       # multi_human_rl.py:57-58
             n_steps += int(Tb.sum())
             last = I[Tb - 1, np.arange(B)]
             keep = np.flatnonzero((last == _lib.REACH_GOAL) | (last == _lib.COLLISION))

@@ -165,6 +165,15 @@ class BatchedCrowdSim(object):
             self.sync()  # `a` is a temporary copy
         return out
 
+    def step_into(self, action, reward, done, info, dmin, update=True):
+        """CrowdSim.step for every env, results written into the caller's device tensors (reward / dmin float64 [B], done / info
+        uint8 [B]; e.g. row t of a [T, B] history) — nothing allocated, no optional outputs: the per-step form of the RL
+        sampling loop, where a dozen small torch kernels per step were as expensive as the step itself."""
+        for t, dt in ((action, torch.float64), (reward, torch.float64), (dmin, torch.float64), (done, torch.uint8), (info, torch.uint8)):
+            assert t.dtype == dt and t.is_contiguous() and t.device.type == self.device.type
+        check(self._lib.cn_step(self._h, _ptr(action), int(bool(update)), _ptr(reward), _ptr(done), _ptr(info), _ptr(dmin),
+                                None, None, None))
+
     # ---------------------------------------------------------------- fused rollouts
     def set_gamma(self, gamma):
         check(self._lib.cn_set_gamma(self._h, float(gamma)))
@@ -301,11 +310,16 @@ def _sarl_set_weights(self, state_dict):
     self.sync()  # the temporaries above must outlive the repack kernels
 
 
-def _sarl_select(self, want_values=True):
-    """Greedy SARL action of every env: dict(values [B,K] f64, best [B] i32, action [B,2] f64)."""
+def _sarl_select(self, want_values=True, best=None, action=None):
+    """Greedy SARL action of every env: dict(values [B,K] f64, best [B] i32, action [B,2] f64).  best / action: the caller's
+    device tensors to write into (e.g. row t of an action history) instead of fresh ones."""
     K = self.sarl['n_actions']
-    out = dict(values=self._new((self.B, K), torch.float64) if want_values else None,
-               best=self._new((self.B,), torch.int32), action=self._new((self.B, 2), torch.float64))
+    if best is None:
+        best = self._new((self.B,), torch.int32)
+    if action is None:
+        action = self._new((self.B, 2), torch.float64)
+    assert best.dtype == torch.int32 and best.is_contiguous() and action.dtype == torch.float64 and action.is_contiguous()
+    out = dict(values=self._new((self.B, K), torch.float64) if want_values else None, best=best, action=action)
     check(self._lib.cn_sarl_select(self._h, _ptr(out['values']), _ptr(out['best']), _ptr(out['action'])))
     return out
 
