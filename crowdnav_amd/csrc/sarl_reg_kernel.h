@@ -604,36 +604,32 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
 
 // b + W[:, 13:61] om for every (env, human) and mlp1.0 output feature, in sarl_reg_kernel<4, NT, true>'s accumulator order:
 // term[((row * 10 + mt) * 4 + lg) * 4 + kk] = feature 16 mt + 4 kk + lg of row = env * H + human (0 beyond the 150 features).
-// Plain fma chain, bias first, map values in ascending order.  wom = [150][48] then the 150 biases (sarl_om_weights_kernel).
-constexpr int kOmTermRows = 32, kOmTermThreads = 192;
-__global__ __launch_bounds__(kOmTermThreads) void sarl_om_term_kernel(const float* wom, const float* om, float* term, int rows) {
-    __shared__ float w[48][161];  // [map value][accumulator slot]: a row's 160 threads read consecutive words
-    __shared__ float bias[160];
+// Plain fma chain, bias first, map values in ascending order.  Thread = accumulator slot: its 48 weights and its bias stay in
+// registers for the block's rows, a row's 48 map values are scalar loads (uniform address).  wom = sarl_om_weights_kernel's
+// [48][160] (map value, slot) then the 160 biases — already in slot order, zero beyond the 150 features.
+constexpr int kOmTermRows = 8, kOmTermThreads = 192;  // (80 rows per block: 36 us — 640 waves, each waiting for its scalar loads row by row; 8: many waves per SIMD)
+__global__ __launch_bounds__(kOmTermThreads) void sarl_om_term_kernel(const float* __restrict__ wom, const float* __restrict__ om, float* __restrict__ term, int rows) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < 48 * 160; i += kOmTermThreads) w[i / 160][i % 160] = 0.0f;
-    if (tid < 160) bias[tid] = 0.0f;
-    __syncthreads();
-    for (int i = tid; i < 150 * 49; i += kOmTermThreads) {
-        const int f = i < 150 * 48 ? i / 48 : i - 150 * 48;
-        const int slot = (f >> 4) * 16 + (f & 3) * 4 + ((f >> 2) & 3);  // feature 16 mt + 4 kk + lg -> (mt, lg, kk)
-        if (i < 150 * 48) w[i % 48][slot] = wom[i];
-        else bias[slot] = wom[i];
-    }
-    __syncthreads();
     if (tid >= 160) return;
+    float w[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) w[k] = wom[k * 160 + tid];
+    const float bias = wom[48 * 160 + tid];
     const int r0 = blockIdx.x * kOmTermRows, r1 = r0 + kOmTermRows < rows ? r0 + kOmTermRows : rows;
     for (int row = r0; row < r1; ++row) {
-        const float* m = om + (size_t)row * 48;  // uniform address: scalar loads
-        float v = bias[tid];
+        const float* m = om + (size_t)row * 48;
+        float v = bias;
 #pragma unroll
-        for (int k = 0; k < 48; ++k) v = __builtin_fmaf(w[k][tid], m[k], v);
+        for (int k = 0; k < 48; ++k) v = __builtin_fmaf(w[k], m[k], v);
         term[(size_t)row * 160 + tid] = v;
     }
 }
 __global__ void sarl_om_weights_kernel(const float* W /*[150][61]*/, const float* b, float* wom) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 150 * 48) wom[idx] = W[(idx / 48) * 61 + 13 + idx % 48];
-    else if (idx < 150 * 49) wom[idx] = b[idx - 150 * 48];
+    if (idx >= 49 * 160) return;
+    const int k = idx / 160, slot = idx % 160;
+    const int mt = slot >> 4, lg = (slot >> 2) & 3, kk = slot & 3, f = 16 * mt + 4 * kk + lg;  // slot (mt, lg, kk) <- feature
+    wom[idx] = f < 150 ? (k < 48 ? W[f * 61 + 13 + k] : b[f]) : 0.0f;
 }
 
 // cadrl.ValueNetwork (cadrl.py:22-29) with the activations in registers: the same MLP for every (group, human) row — NT N tiles
