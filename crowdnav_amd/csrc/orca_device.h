@@ -541,11 +541,15 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
 template <int MAXL>
 __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* proj, float4* cand, const int* count,
                                                 const float4* sol, float4* res, const int* todo, int n_todo, int threads) {
-    constexpr int G = kWave / MAXL;
-    constexpr unsigned kField = (1u << MAXL) - 1u;
+    // W = MAXL - 1 lanes per agent: lane l holds half-plane l (projections and candidates exist for l < MAXL - 1 only), and the
+    // agent's last lane also tests half-plane MAXL - 1 for violation — 7 agents per pass at 10 half-planes instead of 6 with a
+    // lane per half-plane (a step of the 20-human shard has 6.0 infeasible agents on average: a second pass for the 7th
+    // was the common case).
+    constexpr int W = MAXL - 1, G = kWave / W;
+    constexpr unsigned kField = (1u << W) - 1u;
     const int wl = threadIdx.x & (kWave - 1);
-    const int g = wl / MAXL, l = wl - g * MAXL;
-    const int gbase = g * MAXL;
+    const int g = wl / W, l = wl - g * W;
+    const int gbase = g * W;
     const int waves = (threads + kWave - 1) / kWave;
     for (int chunk = threadIdx.x / kWave; chunk * G < n_todo; chunk += waves) {
         const bool live = g < G && chunk * G + g < n_todo;
@@ -556,24 +560,27 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
         const bool need = live && begin < n;
         const float radius = sol[a].z;
         const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool tail = l == W - 1 && W < n;  // this lane also watches half-plane W
+        const float4 last = tail ? lines[a * kLineStride + W] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4* const prow = proj + a * kLineStride;
-        float4* const crow = cand + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * (MAXL - 1);
+        float4* const crow = cand + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * W;
         float rx = r0.x, ry = r0.y, distance = 0.0f;
         int icur = need ? begin : n;
         while (true) {
             const bool cond = l >= icur && l < n && (my.z * (my.y - ry) - my.w * (my.x - rx) > distance);
-            const unsigned long long m = __ballot(cond);
-            if (m == 0ull) break;
-            const unsigned gm = (unsigned)(m >> gbase) & kField;
+            const bool condw = tail && W >= icur && (last.z * (last.y - ry) - last.w * (last.x - rx) > distance);
+            const unsigned long long m = __ballot(cond), mw = __ballot(condw);
+            if ((m | mw) == 0ull) break;
+            const unsigned gm = ((unsigned)(m >> gbase) & kField) | (((unsigned)(mw >> (gbase + W - 1)) & 1u) << W);
             const bool act = gm != 0u;
             const int i = act ? __ffs(gm) - 1 : 0;
             const float4 li = lines[a * kLineStride + i];
             // my half-plane projected onto half-plane i (the ones RVO2 leaves out, and lanes l >= i, hold an inert line)
             const float4 pr = (act && l < i) ? lp3_project(li, my) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live && l < MAXL - 1) prow[l] = pr;
+            if (live) prow[l] = pr;
             // 1-D solution on projected line l against projected lines 0 .. l-1, optimising along the normal of half-plane i
             const float4 cd = lp_line_candidate<MAXL - 2>(pr, prow, l, radius, -li.w, li.z, true);
-            if (live && l < MAXL - 1) crow[l] = cd;
+            if (live) crow[l] = cd;
             // linearProgram2 over the projected lines as a scan of the candidates (every lane of the agent, identically)
             float r2x = -li.w * radius, r2y = li.z * radius;
             bool failed = false;

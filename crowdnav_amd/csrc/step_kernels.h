@@ -1006,8 +1006,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                     if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
                 }
                 __syncthreads();
-                // (its candidate rows — 6 agents x 9 float4 per wave — live in d2, free after the pair phases: enough for one wave)
-                if (kLazy3 && P.threads == kWave && P.pairs * 4 >= (kWave / MAXL) * (MAXL - 1) * 16)
+                // (its candidate rows — 7 agents x 9 float4 per wave — live in d2, free after the pair phases: enough for one wave)
+                if (kLazy3 && P.threads == kWave && P.pairs * 4 >= (kWave / (MAXL - 1)) * (MAXL - 1) * 16)
                     lp_relaxed_lazy<MAXL>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
                                           s.todo[P.nA], P.threads);
                 else
