@@ -542,37 +542,63 @@ template <int MAXL>
 __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* proj, float4* cand, const int* count,
                                                 const float4* sol, float4* res, const int* todo, int n_todo, int threads) {
     // W = MAXL - 1 lanes per agent: lane l holds half-plane l (projections and candidates exist for l < MAXL - 1 only), and the
-    // agent's last lane also tests half-plane MAXL - 1 for violation — 7 agents per pass at 10 half-planes instead of 6 with a
+    // agent's last lane also tests half-plane MAXL - 1 for violation — 7 agents at a time at 10 half-planes instead of 6 with a
     // lane per half-plane (a step of the 20-human shard has 6.0 infeasible agents on average: a second pass for the 7th
-    // was the common case).
+    // was the common case).  A lane group whose agent is done takes the next one from the list (one wave per workgroup; with
+    // several waves each wave keeps its own chunks of G agents): the rounds of a step are then about (sum over its agents) / G,
+    // not the sum over passes of each pass's slowest agent.
     constexpr int W = MAXL - 1, G = kWave / W;
     constexpr unsigned kField = (1u << W) - 1u;
     const int wl = threadIdx.x & (kWave - 1);
     const int g = wl / W, l = wl - g * W;
     const int gbase = g * W;
     const int waves = (threads + kWave - 1) / kWave;
+    float4* const crow = cand + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * W;
     for (int chunk = threadIdx.x / kWave; chunk * G < n_todo; chunk += waves) {
-        const bool live = g < G && chunk * G + g < n_todo;
-        const int a = live ? todo[chunk * G + g] : 0;
-        const float4 r0 = res[a];
-        const int n = live ? count[a] : 0;
-        const int begin = __float_as_int(r0.z);
-        const bool need = live && begin < n;
-        const float radius = sol[a].z;
-        const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool tail = l == W - 1 && W < n;  // this lane also watches half-plane W
-        const float4 last = tail ? lines[a * kLineStride + W] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4* const prow = proj + a * kLineStride;
-        float4* const crow = cand + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * W;
-        float rx = r0.x, ry = r0.y, distance = 0.0f;
-        int icur = need ? begin : n;
+        const int hand_end = waves == 1 ? n_todo : (chunk * G + G < n_todo ? chunk * G + G : n_todo);  // agents this wave works off
+        int next = chunk * G + G;                                                                     // ... the next one to hand out
+        // per-agent state of the lane's group
+        bool live = false, need = false, tail = false;
+        int a = 0, n = 0, icur = 0;
+        float radius = 0.0f, rx = 0.0f, ry = 0.0f, r0z = 0.0f, distance = 0.0f;
+        float4 my = make_float4(0.f, 0.f, 0.f, 0.f), last = my;
+        float4* prow = proj;
+        const auto take = [&](int idx) {
+            live = g < G && idx < hand_end;
+            a = live ? todo[idx] : 0;
+            const float4 r0 = res[a];
+            n = live ? count[a] : 0;
+            const int begin = __float_as_int(r0.z);
+            need = live && begin < n;
+            radius = sol[a].z;
+            my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tail = l == W - 1 && W < n;  // this lane also watches half-plane W
+            last = tail ? lines[a * kLineStride + W] : make_float4(0.f, 0.f, 0.f, 0.f);
+            prow = proj + a * kLineStride;
+            rx = r0.x, ry = r0.y, r0z = r0.z, distance = 0.0f;
+            icur = need ? begin : n;
+        };
+        take(chunk * G + g);
         while (true) {
             const bool cond = l >= icur && l < n && (my.z * (my.y - ry) - my.w * (my.x - rx) > distance);
             const bool condw = tail && W >= icur && (last.z * (last.y - ry) - last.w * (last.x - rx) > distance);
             const unsigned long long m = __ballot(cond), mw = __ballot(condw);
-            if ((m | mw) == 0ull) break;
             const unsigned gm = ((unsigned)(m >> gbase) & kField) | (((unsigned)(mw >> (gbase + W - 1)) & 1u) << W);
             const bool act = gm != 0u;
+            if (live && !act) {  // this group's agent has no violated half-plane left
+                if (need && l == 0) res[a] = make_float4(rx, ry, r0z, 0.0f);
+                live = false;
+            }
+            if (next < hand_end) {  // free groups take the next agents of the list, in group order
+                const unsigned long long idle = __ballot(l == 0 && g < G && !act);
+                if (idle != 0ull) {
+                    const int idx = next + __popcll(idle & ((1ull << gbase) - 1ull));
+                    if (!act) take(idx);
+                    next += __popcll(idle);
+                    continue;
+                }
+            }
+            if ((m | mw) == 0ull) break;
             const int i = act ? __ffs(gm) - 1 : 0;
             const float4 li = lines[a * kLineStride + i];
             // my half-plane projected onto half-plane i (the ones RVO2 leaves out, and lanes l >= i, hold an inert line)
@@ -603,7 +629,7 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
                 icur = i + 1;
             }
         }
-        if (need && l == 0) res[a] = make_float4(rx, ry, r0.z, 0.0f);
+        if (waves == 1) break;
     }
 }
 
