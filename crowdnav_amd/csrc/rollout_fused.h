@@ -67,6 +67,15 @@ __device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max
     start = make_float4(sx, sy, 0.0f, 0.0f);
 }
 
+// The fused kernel is ONE wave per workgroup: LDS instructions of a wave execute in order, so what the phases need between a
+// lane's write and another lane's read is only that the compiler keeps the accesses in program order — not s_barrier with
+// its s_waitcnt lgkmcnt(0) in front (the LDS queue drained five times per step).  -DCN_EXP_FUSED_BARRIER restores __syncthreads.
+#ifdef CN_EXP_FUSED_BARRIER
+#define CN_FUSED_SYNC() __syncthreads()
+#else
+#define CN_FUSED_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 template <bool HEADLINE>
 __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                               RolloutView R, int n_steps, const double* ext_action) {
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     }
     unsigned int transitions = 0;
     for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
-    __syncthreads();  // pinfo, rview
+    CN_FUSED_SYNC();  // pinfo, rview
     // this pair lane's row: the kin slots of its agent's candidates (8 bits each).  A pair that does not exist (robot
     // invisible to the humans, env beyond the batch, fewer than 5 candidates) points at slot nA = (+inf, +inf): its squared
     // distance is +inf without a select, so the pair phase below has no data-dependent control flow at all.
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     const double c_ddist = in_vgpr(P.discomfort_dist), c_dfactor = in_vgpr(P.discomfort_factor);
     const double c_hsafety = in_vgpr(P.human_safety);
     stage_agent(P, s, L, r, c_hsafety);
-    __syncthreads();
+    CN_FUSED_SYNC();
 
 #ifdef CN_PHASE_TIMING
     PhaseClock clock = {};
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 s.res[L.lane] = start4;
             }
         }
-        __syncthreads();
+        CN_FUSED_SYNC();
         CN_TICK(clk, 2);
 
         // ---- candidates: lane = (agent, half-plane)
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             const float4* lq = s.lines + q * kLineStride;
             s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
         }
-        __syncthreads();
+        CN_FUSED_SYNC();
 
         // ---- solve: scan, then the candidate-form fallback for the infeasible agents
         float rx = 0.0f, ry = 0.0f;
@@ -245,15 +254,15 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 const float4 li = la[i], lj = la[m - base];
                 const float radius = s.sol[a].z;
                 if (item) s.proj[a * kLineStride + m] = lp3_project(li, lj);
-                __syncthreads();
+                CN_FUSED_SYNC();
                 if (item) {
                     const float4* pa = s.proj + a * kLineStride + base;
                     s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, radius, -li.w, li.z, true);
                 }
-                __syncthreads();
+                CN_FUSED_SYNC();
             } else {
                 if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
-                __syncthreads();
+                CN_FUSED_SYNC();
                 const int items = n_todo * kPairs;
                 for (int p = L.lane; p < items; p += kWave) {  // projections: lane = (agent, i, j)
                     const int t = p / kPairs, m = p - t * kPairs;
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                     const float4* la = s.lines + a * kLineStride;
                     s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
                 }
-                __syncthreads();
+                CN_FUSED_SYNC();
                 for (int p = L.lane; p < items; p += kWave) {  // their candidates: lane = (agent, i, k)
                     const int t = p / kPairs, m = p - t * kPairs;
                     const int a = s.todo[t];
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                     const float4* pa = s.proj + a * kLineStride + base;
                     s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
                 }
-                __syncthreads();
+                CN_FUSED_SYNC();
             }
             if (need)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             const double d = norm2(human ? cx : endx - r.gx, human ? cy : endy - r.gy);
             s.closest[L.lane] = human ? d - r.rad - s.rad[L.ebase] : d;
         }
-        __syncthreads();
+        CN_FUSED_SYNC();
         CN_TICK(clk, 5);
 
         // ---- reduce (every lane of the env, identically), integrate, episode bookkeeping, stage the next step
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             }
         }
         stage_agent(P, s, L, r, c_hsafety);
-        __syncthreads();
+        CN_FUSED_SYNC();
         CN_TICK(clk, 7);
     }
 #ifdef CN_PHASE_TIMING
