@@ -198,6 +198,19 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     return s;
 }
 
+// Workgroup barrier of the step / rollout kernels.  A workgroup of ONE wave (P.threads == 64: a compile-time fact in the
+// 20-human shard's instantiation, a uniform branch elsewhere) needs no s_barrier: a wave's LDS instructions execute in order,
+// so between one lane's write and another lane's read only the compiler has to keep program order — and the s_waitcnt
+// lgkmcnt(0) in front of every s_barrier (the LDS queue drained a dozen times per step) goes away.
+__device__ __forceinline__ void block_sync(const Params& P) {
+    if (P.threads == kWave) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
+__device__ __forceinline__ int block_sync_or(const Params& P, int v) {
+    if (P.threads == kWave) return __ballot(v != 0) != 0ull ? 1 : 0;
+    return __syncthreads_or(v);
+}
+
 // ---------------------------------------------------------------------------------------------- lanes
 struct Lane {
     int lane, env, a, ebase;  // ebase = lane of this env's robot
@@ -350,11 +363,11 @@ __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, c
             list[0].set = t == 0 ? amask : (amask & ~1ull);
             *cnt = 1;
         }
-        __syncthreads();
+        block_sync(P);
         for (int r = 0;; ++r) {
             const int c = agent ? *cnt : 0;
             const bool live = agent && r < c;
-            if (!__syncthreads_or(live ? 1 : 0)) break;
+            if (!block_sync_or(P, live ? 1 : 0)) break;
             KdNode nd = KdNode{0u, 0u, 0ull, 0ull, 0ull};
             bool member = false;
             uint32_t* acc = k.bb + ((size_t)el * k.mn + r) * 4;
@@ -366,7 +379,7 @@ __device__ __forceinline__ void kd_build_trees(const Params& P, const Smem& s, c
                     atomicMin(acc + 2, ky), atomicMax(acc + 3, ky);
                 }
             }
-            __syncthreads();
+            block_sync(P);
             bool lower = false;
             if (live) {
                 const float min_x = kd_unkey(acc[0]), max_x = kd_unkey(acc[1]), min_y = kd_unkey(acc[2]), max_y = kd_unkey(acc[3]);
@@ -577,7 +590,7 @@ __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, 
     const KdSmem k = kd_view(P, s);
     const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
     if (L.lane < P.nA && k.tie[L.lane] != 0) kd_visit_order(P, s, L, kd_gen);
-    __syncthreads();
+    block_sync(P);
     int* kept = reinterpret_cast<int*>(s.proj);
     for (int p = L.lane; p < P.pairs; p += P.threads) {
         const int info = s.pinfo[p];
@@ -606,10 +619,10 @@ __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, 
             }
         }
     }
-    __syncthreads();
+    block_sync(P);
     if (two_sweeps) {
         pair_sweep2<false>(P, s);
-        __syncthreads();
+        block_sync(P);
     }
 }
 
@@ -707,7 +720,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             reinterpret_cast<int*>(k.dnext)[L.lane] = 0;  // slots below 10 claimed by this agent's candidates (two-sweep pair phase)
         }
     }
-    __syncthreads();
+    block_sync(P);
     // simulators of more than 10 agents: this step's kd-tree(s) and every simulator's permutation (kd_order.h); the visiting
     // order itself is only worked out further down if a simulator turns out to have an exact distance tie
     int kd_gen = 0;  // the generation of node lists that holds this step's tree
@@ -716,7 +729,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         CN_TICK(clk, 0);
         if (P.E == 1 && P.threads == kWave) {
             kd_gen = kd_build_trees_wave(P, s, L, g_last);
-            __syncthreads();  // (one wave: orders the builder's LDS records before the simulator lanes read them)
+            block_sync(P);  // (one wave: orders the builder's LDS records before the simulator lanes read them)
         } else {
             kd_gen = g_last ^ 1;
             kd_build_trees(P, s, L, kd_gen);
@@ -735,7 +748,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         const float dx = me.x - ot.x, dy = me.y - ot.y;
         s.d2[p] = ((info >> 24) & 1) ? dx * dx + dy * dy : std::numeric_limits<float>::infinity();
     }
-    __syncthreads();
+    block_sync(P);
     CN_TICK(clk, 1);
 
     // pairs-2: neighbour slot = stable rank by (distSq, visit order) among the in-range candidates, which
@@ -782,7 +795,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 if (KD) atomicAdd(claimed + (info & 0xff), 1);  // (LDS, no return value)
             }
         }
-        __syncthreads();
+        block_sync(P);
         if (KD)
             pair_sweep2<true>(P, s);
         else
@@ -813,11 +826,11 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 make_half_plane(P.orca, me.x, me.y, me.z, me.w, ot.x, ot.y, ot.z, ot.w, rsum);
         }
     }
-    __syncthreads();
+    block_sync(P);
     if (KD) {
         const KdSmem k = kd_view(P, s);
         const bool my_tie = L.lane < P.nA && k.tie[L.lane] != 0;
-        if (__syncthreads_or(my_tie ? 1 : 0)) kd_resolve_ties(P, s, L, kd_gen, two_sweeps ? 1 : 0);
+        if (block_sync_or(P, my_tie ? 1 : 0)) kd_resolve_ties(P, s, L, kd_gen, two_sweeps ? 1 : 0);
     }
     CN_TICK(clk, 2);
 
@@ -835,7 +848,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
             }
         }
-        __syncthreads();
+        block_sync(P);
         float rx = 0.0f, ry = 0.0f;
         int n = 0, fail = 0;
         if (solve) {
@@ -849,13 +862,13 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 #ifdef CN_PHASE_TIMING
         if (clk) clk->acc[9] += __popcll(__ballot(need));
 #endif
-        if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+        if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
             if (L.lane < kWave) {
                 const unsigned long long nm = __ballot(need);
                 if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
                 if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
             }
-            __syncthreads();
+            block_sync(P);
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int items = s.todo[P.nA] * kPairs;
             for (int p = L.lane; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
@@ -865,7 +878,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 const float4* la = s.lines + a * kLineStride;
                 s.proj[a * kLineStride + m] = lp3_project(la[i], la[j]);
             }
-            __syncthreads();
+            block_sync(P);
             for (int p = L.lane; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
                 const int t = p / kPairs, m = p - t * kPairs;
                 const int a = s.todo[t];
@@ -874,7 +887,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 const float4* pa = s.proj + a * kLineStride + base;
                 s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
             }
-            __syncthreads();
+            block_sync(P);
             if (need)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
                          fail, max_speed, rx, ry);
@@ -893,7 +906,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
             }
         }
-        __syncthreads();
+        block_sync(P);
         float rx = 0.0f, ry = 0.0f;
         int n = 0, fail = 0;
         if (solve) {
@@ -907,7 +920,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 #ifdef CN_PHASE_TIMING
         if (clk) clk->acc[9] += __popcll(__ballot(need));
 #endif
-        if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+        if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
             if (L.lane < kWave) {
                 const unsigned long long nm = __ballot(need);
                 if (need) {
@@ -916,9 +929,9 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 }
                 if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
             }
-            __syncthreads();
+            block_sync(P);
             lp_relaxed_lazy<MAXL>(s.lines, s.proj, s.cand3, s.count, s.sol, s.res, s.todo, s.todo[P.nA], P.threads);
-            __syncthreads();
+            block_sync(P);
             if (need) {
                 const float4 got = s.res[L.lane];
                 rx = got.x, ry = got.y;
@@ -927,7 +940,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         out_vx = rx, out_vy = ry;
     } else if (kCoop) {
         lp_planar_coop<MAXL>(s.lines, s.count, s.sol, s.res, P.nA);
-        __syncthreads();
+        block_sync(P);
         if (solve) {
             const int n = s.count[L.lane];
             const float4 got = s.res[L.lane];
@@ -956,7 +969,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         if (clk) clk->acc[9] += __popcll(__ballot(need));  // agents in the fallback
 #endif
         if (kCand3) {
-            if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+            if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
                 int my_t = 0;
                 if (L.lane < kWave) {
                     const unsigned long long nm = __ballot(need);
@@ -964,7 +977,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                     if (need) s.todo[my_t] = L.lane;
                     if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
                 }
-                __syncthreads();
+                block_sync(P);
                 constexpr int kPairs = MAXL * (MAXL - 1) / 2;
                 static_assert(MAXL != 10 || kPairs == kLp3Pairs10, "proj_bytes() sizes the chunk buffers");
                 float4* const projc = s.proj;                          // [kLp3Agents][kPairs] projected half-planes
@@ -980,7 +993,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                         const float4* la = s.lines + a * kLineStride;
                         projc[p] = lp3_project(la[i], la[j]);
                     }
-                    __syncthreads();
+                    block_sync(P);
                     for (int p = L.lane; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
                         const int t = p / kPairs, m = p - t * kPairs;
                         const int a = s.todo[t0 + t];
@@ -989,14 +1002,14 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                         const float4* pa = projc + t * kPairs + base;
                         candc[p] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
                     }
-                    __syncthreads();
+                    block_sync(P);
                     if (need && my_t >= t0 && my_t < t0 + nt)
                         lp3_scan_n<MAXL>(mine, projc + (my_t - t0) * kPairs, candc + (my_t - t0) * kPairs, n, fail, max_speed, rx, ry);
-                    __syncthreads();  // the next chunk overwrites the buffers
+                    block_sync(P);  // the next chunk overwrites the buffers
                 }
             }
         } else if (kCoop3 || kLazy3) {
-            if (__syncthreads_or(need ? 1 : 0)) {  // some agent of this workgroup was infeasible
+            if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible
                 if (L.lane < kWave) {  // agent lanes live in wave 0: compact the infeasible ones
                     const unsigned long long nm = __ballot(need);
                     if (need) {
@@ -1005,14 +1018,14 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                     }
                     if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
                 }
-                __syncthreads();
+                block_sync(P);
                 // (its candidate rows — 7 agents x 9 float4 per wave — live in d2, free after the pair phases: enough for one wave)
                 if (kLazy3 && P.threads == kWave && P.pairs * 4 >= (kWave / (MAXL - 1)) * (MAXL - 1) * 16)
                     lp_relaxed_lazy<MAXL>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
                                           s.todo[P.nA], P.threads);
                 else
                     lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
-                __syncthreads();
+                block_sync(P);
                 if (need) {
                     const float4 got = s.res[L.lane];
                     rx = got.x, ry = got.y;
@@ -1068,7 +1081,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
         }
         s.act[L.lane] = make_double2(new_vx, new_vy);
     }
-    __syncthreads();
+    block_sync(P);
     CN_TICK(clk, 4);
 
     // One float64 distance per agent lane, computed branch-free so that humans and the robot share the
@@ -1103,7 +1116,7 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
             goal_dist = d;
         }
     }
-    __syncthreads();
+    block_sync(P);
     CN_TICK(clk, 5);
 
     res.done = 0;
@@ -1597,7 +1610,7 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
 #pragma unroll
         for (int f = 0; f < F; ++f) scratch[el * F + f] = acc[f];
     }
-    __syncthreads();
+    block_sync(P);
     const int f0 = want ? 0 : F - 1;  // without a summary only the transitions travel
     if (tid >= f0 && tid < F) {  // the workgroup's envs in env order
         double t = 0.0;
@@ -1606,7 +1619,7 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
         agent_store(S.wg_partial + (size_t)blockIdx.x * F + tid, t);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's payload has left before the ticket is taken
-    __syncthreads();
+    block_sync(P);
     int* const flag = reinterpret_cast<int*>(scratch + P.E * F);
     const int n_wg = (int)gridDim.x;
     const int g = blockIdx.x % kEpilogueGroups;
@@ -1614,7 +1627,7 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
     if (tid == 0)
         flag[0] = __hip_atomic_fetch_add(&S.tickets[g * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
                   (unsigned)(members - 1);
-    __syncthreads();
+    block_sync(P);
     if (!flag[0]) return;
     // last arrival of group g: the group's sums, members in index order (lane l: members l, l + 64, ..; lanes by a fixed tree)
     if (tid < kWave) {
@@ -1640,7 +1653,7 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
         flag[1] = __hip_atomic_fetch_add(&S.tickets[kEpilogueGroups * kTicketStride], 1u, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(groups - 1);
     }
-    __syncthreads();
+    block_sync(P);
     if (!flag[1]) return;
     // last arrival of all: results out, counters back to zero for the next launch (ordered by the kernel boundary)
     if (tid >= f0 && tid < F) {
