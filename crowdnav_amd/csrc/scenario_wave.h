@@ -15,6 +15,11 @@
 
 namespace cn {
 
+// A generator workgroup is ONE wave: its LDS instructions execute in order, so the phases below only need the compiler to keep
+// program order between one lane's write and another lane's read — not s_barrier with the LDS queue drained in front of it
+// (8 per 624-word block of the generator).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 struct WaveRng {
     uint32_t* key;   // [624] generator state (LDS)
     uint32_t* prev;  // [2][624] the states one and two blocks earlier, or NULL (kept only when the stream is handed on)
@@ -32,7 +37,7 @@ struct WaveRng {
         }
         produced = 0;
         cursor = 0;
-        __syncthreads();
+        wave_sync();
     }
 
     __device__ static uint32_t twist(uint32_t a, uint32_t b) {
@@ -55,7 +60,7 @@ struct WaveRng {
                 prev[624 + i] = prev[i];
                 prev[i] = key[i];
             }
-            __syncthreads();
+            wave_sync();
         }
         for (int ph = 0; ph < 3; ++ph) {
             const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454);
@@ -69,19 +74,19 @@ struct WaveRng {
                     v[k] = key[im] ^ twist(key[i], key[i + 1]);
                 }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = lo + lane + 64 * k;
                 if (i < hi) key[i] = v[k];
             }
-            __syncthreads();
+            wave_sync();
         }
         if (lane == 0) key[623] = key[396] ^ twist(key[623], key[0]);
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < 624; i += 64) out[(produced + i) % kWindow] = temper(key[i]);
         produced += 624;
-        __syncthreads();
+        wave_sync();
     }
 
     // make stream words [cursor, cursor + n) readable (n <= 384)
@@ -143,7 +148,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
         if (vel) vel[base] = make_double2(0.0, 0.0);
         rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
     }
-    __syncthreads();
+    wave_sync();
     for (int i = 1; i < A; ++i) {
         double radius = c.human_radius, v_pref = c.human_v_pref;
         if (c.randomize) {
@@ -230,11 +235,11 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
                     }
                     rng.cursor += 4u * 64;
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
         if (lane == 0) s.prad[i] = radius;
-        __syncthreads();
+        wave_sync();
         if (lane == 0) {
             pos[base + i] = s.ppos[i];
             goal[base + i] = s.pgoal[i];
@@ -242,7 +247,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
             rv[base + i] = make_double2(radius, v_pref);
         }
     }
-    __syncthreads();
+    wave_sync();
     if (mt_key_out) rng.persist(mt_key_out, mt_stride, mt_pos_out, lane);
     return (uint64_t)(rng.cursor / 2);
 }
