@@ -476,8 +476,8 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     const float* m = om + ((size_t)b * C.H + h) * (extra > 0 ? extra : 0);
     const int n_om = om_cols ? extra : (extra < 3 ? extra : 3);
     for (int k = 0; k < n_om; ++k) x[((13 + k) >> 2) * 64 + ((13 + k) & 3) * 16] = m[k];
-    if (om_cols)
-        for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+    // (features in_dim .. 4 ks_x - 1 are never written by anyone: X is zero from its allocation — 7 of 20 floats per row at 13
+    // inputs, and the kernel is bound by its HBM writes)
 }
 
 // ------------------------------------------------------------------------------------ replay-memory side
