@@ -315,14 +315,17 @@ class Explorer(object):
             eng = self._rl_engine(B, human_num, rule)
             eng.sarl_set_weights(policy.model.state_dict())
             eng.reset(offset + start + c0 + np.arange(B))
-            traj = torch.zeros(B, max_steps, human_num, D, dtype=torch.float32, device=eng.device)
-            rew = torch.zeros(max_steps, B, dtype=torch.float64, device=eng.device)
-            inf = torch.zeros(max_steps, B, dtype=torch.uint8, device=eng.device)
-            dmn = torch.zeros(max_steps, B, dtype=torch.float64, device=eng.device)
-            act = torch.zeros(max_steps, B, dtype=torch.int32, device=eng.device)
-            alive = torch.ones(B, dtype=torch.uint8, device=eng.device)
-            done = torch.zeros(B, dtype=torch.uint8, device=eng.device)
-            action = torch.zeros(B, 2, dtype=torch.float64, device=eng.device)
+            # the histories live as long as the engine (one allocation + fill per shape, not five per sampled episode); every row
+            # that is read below has been written by this call's steps, except traj's row T, which only feeds a value that
+            # torch.where discards (stale rows are finite)
+            hkey = (id(eng), B, max_steps, human_num, D)
+            if getattr(self, '_rl_hist', (None,))[0] != hkey:
+                z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
+                self._rl_hist = (hkey, z((B, max_steps, human_num, D), torch.float32), z((max_steps, B), torch.float64),
+                                 z((max_steps, B), torch.uint8), z((max_steps, B), torch.float64), z((max_steps, B), torch.int32),
+                                 z((B,), torch.uint8), z((B,), torch.uint8), z((B, 2), torch.float64))
+            _, traj, rew, inf, dmn, act, alive, done, action = self._rl_hist
+            alive.fill_(1)
             T = 0
             # Per step: the engine's kernels and ONE torch kernel — every result lands in its row of the histories (the dozen
             # torch copies / compares per step this loop used to issue cost as much host time as the step costs device time:

@@ -307,7 +307,10 @@ def _sarl_set_weights(self, state_dict):
     tensors = [state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in order]
     ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     check(self._lib.cn_sarl_set_weights(self._h, ptrs))
-    self.sync()  # the temporaries above must outlive the repack kernels
+    # the tensors above (temporaries when the model lives elsewhere or in another dtype) must outlive the repack kernels: kept
+    # until the next call — by then those kernels are long behind on the same stream; no synchronize per call (the RL phase
+    # uploads weights once per sampled episode)
+    self._sarl_weights_keepalive = tensors
 
 
 def _sarl_select(self, want_values=True, best=None, action=None):
