@@ -8,12 +8,13 @@
 // Kernels (launched back to back on the engine's stream by cn_sarl_select):
 //   orca_kernel            (step_kernels.h) the humans' next velocities — computed ONCE per env: they do not
 //                          depend on the candidate action
-//   sarl_lookahead_kernel  lane = env: next human observable states (float64) and, with_om, their occupancy maps
-//   sarl_reward_kernel     lane = (env, action): float64 reward of onestep_lookahead(action)
+//   sarl_lookahead_kernel  lane = (env, human): next human observable states (float64) and their occupancy maps — only with_om
+//                          or under LSTM-RL's re-ordering; otherwise the feature kernel derives the next states itself
 //   sarl_feature_kernel    lane = (env, action, human): float32 rotated 13-vector (+48 map values) -> X
 //   sarl_mlp_kernel        workgroup = 16 (env, action) groups x H humans: the whole value network on FP32 MFMA
 //                          (v_mfma_f32_16x16x4_f32: exact f32, k-ordered fma chain), activations in LDS
-//   sarl_select_kernel     lane = env: value = reward + gamma^(dt v_pref) * V, first strict maximum
+//   sarl_select_kernel     wave = env: float64 reward of onestep_lookahead(action) (sarl_reward_of) + gamma^(dt v_pref) * V for
+//                          every action, first strict maximum
 //
 // Row order inside an MLP tile is HUMAN-MAJOR: row = h * 16 + g (g = group within the tile).  A 16-row MFMA
 // tile then holds human h of 16 different groups, so the per-group reductions of the network (mean over
@@ -280,12 +281,11 @@ __global__ void sarl_lookahead_kernel(SarlCfg C, const double2* pos, const doubl
 }
 
 // Reward of onestep_lookahead(action) for every (env, action) (crowd_sim.py:331-389, update = False).
-__global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* goal,
-                                   const double2* rv, const double* gtime, const double* theta,
-                                   const double* actions /*[K][2]*/, double* reward /*[B][K]*/) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C.B * C.n_actions) return;
-    const int b = idx / C.n_actions, a = idx - b * C.n_actions;
+// (a device function: sarl_select_kernel evaluates it where it combines reward and value — one kernel and one stream boundary
+// less per decision, which is 10 % of a single-env decision)
+__device__ inline double sarl_reward_of(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
+                                        const double2* rv, const double* gtime, const double* theta,
+                                        const double* actions /*[K][2]*/, int b, int a) {
     const int A = C.H + 1;
     const size_t g0 = (size_t)b * A;
     double ax = actions[2 * a], ay = actions[2 * a + 1];
@@ -329,8 +329,7 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
         } else {
             r = 0.0;
         }
-        reward[idx] = r;
-        return;
+        return r;
     }
     for (int i = 1; i < A; ++i) {
         const double2 hp = pos[g0 + i], hv = vel[g0 + i];
@@ -374,7 +373,7 @@ __global__ void sarl_reward_kernel(SarlCfg C, const double2* pos, const double2*
     } else {
         r = 0.0;
     }
-    reward[idx] = r;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------ features
@@ -427,11 +426,12 @@ __global__ void sarl_om_columns_kernel(SarlCfg C, int in_dim, int ks_x, const fl
 // store instruction writes 16 consecutive words per (tile, h).
 __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
                                     const double2* rv, const double* theta, const double* actions,
-                                    const double* next_obs, const float* om, float* X, size_t n_tiles,
+                                    double* next_obs, const float* om, float* X, size_t n_tiles,
                                     int* hcount /*[n_tiles * 16] humans present per group*/,
                                     int om_cols = 1 /* 0: the consumer reads the occupancy maps from `om` itself (they do
                                     not depend on the action: written into X they are 81 copies, 48 of every 61 floats);
-                                    only k-steps 0..3 — the 13 rotated features and map values 0..2 — are written */) {
+                                    only k-steps 0..3 — the 13 rotated features and map values 0..2 — are written */,
+                                    const double2* vel = nullptr, const float* orca_vel = nullptr /* not null: no lookahead kernel ran */) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_tiles * C.H * kSarlGroups) return;
     const int g = (int)(idx % kSarlGroups);
@@ -466,7 +466,24 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
     const float vx = (float)ax, vy = (float)ay;
     const float radius = (float)rv[g0].x, v_pref = (float)rv[g0].y;
     const float gx = (float)goal[g0].x, gy = (float)goal[g0].y;
-    const double* o = next_obs + ((size_t)b * C.H + h) * 5;
+    // the human's next observable state (get_next_observable_state, agent.py:63-74): from sarl_lookahead_kernel when it ran
+    // (occupancy maps, LSTM-RL's re-ordering); otherwise computed here — the same float64 expressions — and written out by the
+    // lanes of the env's first action (cn_sarl_export, the step's observation)
+    double o[5];
+    if (orca_vel != nullptr) {
+        const size_t gj = g0 + 1 + h;
+        const double vxn = C.const_vel ? vel[gj].x : (double)orca_vel[2 * gj], vyn = C.const_vel ? vel[gj].y : (double)orca_vel[2 * gj + 1];
+        o[0] = pos[gj].x + vxn * C.dt, o[1] = pos[gj].y + vyn * C.dt, o[2] = vxn, o[3] = vyn, o[4] = rv[gj].x;
+        if (a == 0) {
+            double* dst = next_obs + ((size_t)b * C.H + h) * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) dst[k] = o[k];
+        }
+    } else {
+        const double* src = next_obs + ((size_t)b * C.H + h) * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) o[k] = src[k];
+    }
     const float px1 = (float)o[0], py1 = (float)o[1], vx1 = (float)o[2], vy1 = (float)o[3], radius1 = (float)o[4];
     float f[13];
     rotate_row(px, py, vx, vy, radius, gx, gy, v_pref, theta_f, C.unicycle, px1, py1, vx1, vy1, radius1, f);
@@ -1535,9 +1552,9 @@ __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
 // ------------------------------------------------------------------------------------ action selection
 // value = reward + pow(gamma, time_step * v_pref) * V (multi_human_rl.py:52); the first strict maximum wins (:54);
 // a robot already at its goal stops (:22-23, policy.py:43-49).  best = -1 encodes that stop action.
-__global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2* goal, const double2* rv,
-                                   const double* actions, const double* reward, const float* V, double* values,
-                                   int* best, double* action_out) {
+__global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* goal, const double2* rv,
+                                   const double* gtime, const double* theta, const double* actions, double* reward,
+                                   const float* V, double* values, int* best, double* action_out) {
     // one wave per env: lanes stride over the actions, then a butterfly keeps the largest value, lowest index on ties
     // (= the first strict maximum of the reference's loop; NaN and -inf never win: `value > max_value` is false)
     const int b = blockIdx.x * (blockDim.x / kWaveSize) + (threadIdx.x / kWaveSize);
@@ -1546,7 +1563,9 @@ __global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2*
     double bv = -__builtin_inf();
     int bi = -1;
     for (int a = lane; a < C.n_actions; a += kWaveSize) {
-        const double v = reward[(size_t)b * C.n_actions + a] + C.gamma_bar * (double)V[(size_t)b * C.n_actions + a];
+        const double r = sarl_reward_of(C, pos, vel, goal, rv, gtime, theta, actions, b, a);  // onestep_lookahead's reward
+        reward[(size_t)b * C.n_actions + a] = r;                                              // (kept for cn_sarl_export)
+        const double v = r + C.gamma_bar * (double)V[(size_t)b * C.n_actions + a];
         if (values) values[(size_t)b * C.n_actions + a] = v;
         if (v > bv) {
             bv = v;
