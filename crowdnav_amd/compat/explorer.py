@@ -312,6 +312,18 @@ class Explorer(object):
         n_steps, actions_taken = 0, []
         for c0 in range(0, k, self.max_envs):
             B = min(self.max_envs, k - c0)
+            prof = getattr(self, 'rl_profile', None)  # dict: seconds per part of a sampling call (synchronising: debugging only)
+            if prof is not None:
+                import time
+                torch.cuda.synchronize()
+                tp = [time.perf_counter()]
+
+                def lap(name):
+                    torch.cuda.synchronize()
+                    tp.append(time.perf_counter())
+                    prof[name] = prof.get(name, 0.0) + tp[-1] - tp[-2]
+            else:
+                lap = lambda name: None  # noqa: E731
             eng = self._rl_engine(B, human_num, rule)
             eng.sarl_set_weights(policy.model.state_dict())
             eng.reset(offset + start + c0 + np.arange(B))
@@ -327,19 +339,22 @@ class Explorer(object):
             _, traj, rew, inf, dmn, act, alive, done, action = self._rl_hist
             alive.fill_(1)
             T = 0
+            lap('weights + reset')
             # Per step: the engine's kernels and ONE torch kernel — every result lands in its row of the histories (the dozen
             # torch copies / compares per step this loop used to issue cost as much host time as the step costs device time:
             # 158 us per step at one env, BASELINE configs[4]'s sampling)
+            step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
+            done_b, eps = done.view(torch.bool), float(policy.epsilon)
             for t in range(max_steps):
-                sel = eng.sarl_select(want_values=False, best=act[t], action=action)
-                eng.sarl_explore(sel, policy.epsilon, mask=alive, want_explored=False)
-                eng.sarl_transform(out=traj[:, t], env_stride=max_steps * human_num * D)
-                eng.step_into(action, rew[t], done, inf[t], dmn[t])
-                alive.masked_fill_(done.view(torch.bool), 0)
+                step(t, eps)
+                alive.masked_fill_(done_b, 0)
                 T = t + 1
                 if t % 8 == 7 and not bool(alive.any().item()):
                     break
             eng.sync()
+            lap('steps')
+            if prof is not None:
+                prof['n_steps_issued'] = prof.get('n_steps_issued', 0) + T
             R, I, Dm = rew[:T].cpu().numpy(), inf[:T].cpu().numpy(), dmn[:T].cpu().numpy()
             Ac = act[:T].cpu().numpy()
             terminal = I >= _lib.REACH_GOAL
@@ -369,6 +384,7 @@ class Explorer(object):
                 r = rew[it, bt]
                 values = torch.where(is_last, r, r + gamma_bar * v_next).float()
                 self._push_all(states, values)
+            lap('read-back + TD targets + push')
             for b in range(B):
                 n = int(Tb[b])
                 outcome.append(int(last[b]))

@@ -377,6 +377,33 @@ def _sarl_transform(self, out=None, env_stride=0, sort_humans=None):
     return out
 
 
+def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
+    """The train-phase decision + step of every env as ONE Python call per step: step(t, epsilon) runs
+    cn_sarl_select -> cn_sarl_explore (mask = alive) -> cn_sarl_transform -> cn_step with row t of the caller's histories
+    (traj [B, T, H, D] float32; rew / dmin [T, B] float64; info [T, B] uint8; act [T, B] int32: the chosen action index) as
+    outputs, addresses precomputed — the four wrappers above cost ~45 us of Python per step between them (tensor views,
+    pointer objects, checks), as much as the step costs the device at one env."""
+    B, T, H, D = traj.shape
+    assert traj.dtype == torch.float32 and traj.is_contiguous() and act.dtype == torch.int32 and act.is_contiguous()
+    for t_, dt in ((rew, torch.float64), (dmin, torch.float64), (info, torch.uint8)):
+        assert t_.dtype == dt and t_.is_contiguous() and tuple(t_.shape) == (T, B)
+    assert alive.dtype == torch.uint8 and done.dtype == torch.uint8 and action.dtype == torch.float64 and action.is_contiguous()
+    lib, h, V = self._lib, self._h, C.c_void_p
+    p_traj, p_rew, p_inf, p_dmn, p_act = traj.data_ptr(), rew.data_ptr(), info.data_ptr(), dmin.data_ptr(), act.data_ptr()
+    p_alive, p_done, p_action = V(alive.data_ptr()), V(done.data_ptr()), V(action.data_ptr())
+    sort = int(self.sarl['model'] == 'lstm_rl')
+    stride = T * H * D
+
+    def step(t, epsilon):
+        best = V(p_act + 4 * B * t)
+        check(lib.cn_sarl_select(h, None, best, p_action))
+        check(lib.cn_sarl_explore(h, epsilon, p_alive, best, p_action, None))
+        check(lib.cn_sarl_transform(h, V(p_traj + 4 * H * D * t), stride, sort))
+        check(lib.cn_step(h, p_action, 1, V(p_rew + 8 * B * t), p_done, V(p_inf + B * t), V(p_dmn + 8 * B * t), None, None, None))
+    return step
+
+
+BatchedCrowdSim.sarl_sampler = _sarl_sampler
 BatchedCrowdSim.sarl_configure = _sarl_configure
 BatchedCrowdSim.sarl_set_weights = _sarl_set_weights
 BatchedCrowdSim.sarl_select = _sarl_select
