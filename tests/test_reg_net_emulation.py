@@ -231,3 +231,105 @@ def test_register_network_layout_plain():
 
 def test_register_network_layout_with_occupancy_maps():
     _check(61, 1)
+
+
+# ---- lstm_reg_kernel: the gate layer's packing and the cell update in the accumulator layout ---------------------------------
+# Output tile mt holds gates i, f, g, o (torch order) of units 4 mt .. 4 mt + 3: accumulator register kk of lane group lg =
+# gate kk of unit 4 mt + lg, so the new hidden state of a tile is, lane for lane, the B operand of k-step XKS + mt of the next
+# human's gate layer; the head reads joint = [self (6) | h_n (50)] through the k order of its first layer.
+HID, KSH = 50, 13
+
+
+def pack_gates(Wih, Whh, bih, bhh, xks):
+    K = Wih.shape[1]
+    KS = xks + KSH
+    S = 1 + cdiv(KS, 4)
+    stream = np.zeros((KSH * S, 64, 4), np.float32)
+    for mt in range(KSH):
+        for j in range(S):
+            quad = stream[mt * S + j]
+            for lane in range(64):
+                lg, m = lane >> 4, lane & 15
+                for kk in range(4):
+                    if j == 0:
+                        u = 4 * mt + lg
+                        quad[lane, kk] = bih[kk * HID + u] + bhh[kk * HID + u] if u < HID else 0.0
+                    else:
+                        ks, u = 4 * (j - 1) + kk, 4 * mt + (m >> 2)
+                        n = (m & 3) * HID + u
+                        if u < HID and ks < KS:
+                            if ks < xks:
+                                quad[lane, kk] = Wih[n, 4 * ks + lg] if 4 * ks + lg < K else 0.0
+                            else:
+                                c = 4 * (ks - xks) + lg
+                                quad[lane, kk] = Whh[n, c] if c < HID else 0.0
+    return stream, S
+
+
+def test_lstm_gate_layer_layout_and_head_k_order():
+    rng = np.random.default_rng(3)
+    T, D, xks = 4, 13, 4
+    Wih = (rng.standard_normal((4 * HID, D)) / np.sqrt(D)).astype(np.float32)
+    Whh = (rng.standard_normal((4 * HID, HID)) / np.sqrt(HID)).astype(np.float32)
+    bih, bhh = (0.1 * rng.standard_normal((2, 4 * HID))).astype(np.float32)
+    W0 = (rng.standard_normal((150, 6 + HID)) / np.sqrt(56)).astype(np.float32)
+    b0 = (0.1 * rng.standard_normal(150)).astype(np.float32)
+    x = rng.standard_normal((16, T, D)).astype(np.float32)  # [group][human = LSTM step][feature]
+    x[:, 1:, :6] = x[:, :1, :6]
+    X = np.zeros((T, xks, 64), np.float32)
+    for t in range(T):
+        for n in range(D):
+            X[t, n >> 2, (n & 3) * 16:(n & 3) * 16 + 16] = x[:, t, n]
+    stream, S = pack_gates(Wih, Whh, bih, bhh, xks)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+    h = [np.zeros(64, np.float32) for _ in range(KSH)]
+    c = [np.zeros(64, np.float32) for _ in range(KSH)]
+    for t in range(T):
+        hn = []
+        for mt in range(KSH):
+            acc = stream[mt * S].copy()
+            for ks in range(xks + KSH):
+                a = stream[mt * S + 1 + ks // 4][:, ks % 4]
+                acc = mfma(a, X[t][ks] if ks < xks else h[ks - xks], acc)
+            cn = sig(acc[:, 1]) * c[mt] + sig(acc[:, 0]) * np.tanh(acc[:, 2].astype(np.float64))
+            c[mt] = cn.astype(np.float32)
+            hn.append((sig(acc[:, 3]) * np.tanh(cn)).astype(np.float32))
+        h = hn
+    # numpy LSTM (torch.nn.LSTM's equations, gate order i, f, g, o)
+    hr, cr = np.zeros((16, HID)), np.zeros((16, HID))
+    for t in range(T):
+        g = x[:, t].astype(np.float64) @ Wih.T + bih + hr @ Whh.T + bhh
+        i, f, gg, o = (g[:, k * HID:(k + 1) * HID] for k in range(4))
+        cr = sig(f) * cr + sig(i) * np.tanh(gg)
+        hr = sig(o) * np.tanh(cr)
+    lane = np.arange(64)
+    for j in range(KSH):
+        u = 4 * j + (lane >> 4)
+        want = np.where(u < HID, hr[lane & 15, np.minimum(u, HID - 1)], 0.0)
+        assert np.abs(h[j] - want).max() < 2e-6, (j, np.abs(h[j] - want).max())
+    # head layer 0 on joint = [self | h_n]: k-steps 0..12 = h's registers, 13 = X k-step 0 of the first row, 14 = its k-step 1
+    def kcol_head(ks, lg):
+        if ks < KSH:
+            return 6 + 4 * ks + lg if 4 * ks + lg < HID else -1
+        return lg if ks == 13 else (4 + lg if lg < 2 else -1)
+    inp = lambda ks: h[ks] if ks < KSH else (X[0][0] if ks == 13 else X[0][1])
+    y = np.zeros((16, 160))
+    for mt in range(10):
+        acc = np.zeros((64, 4), np.float32)
+        for l_ in range(64):
+            for kk in range(4):
+                f = 16 * mt + 4 * kk + (l_ >> 4)
+                acc[l_, kk] = b0[f] if f < 150 else 0.0
+        for ks in range(15):
+            a = np.zeros(64, np.float32)
+            for l_ in range(64):
+                lg, m = l_ >> 4, l_ & 15
+                n, col = 16 * mt + 4 * (m & 3) + (m >> 2), kcol_head(ks, lg)
+                a[l_] = W0[n, col] if (n < 150 and col >= 0) else 0.0
+            acc = mfma(a, inp(ks), acc)
+        for l_ in range(64):
+            for kk in range(4):
+                y[l_ & 15, 16 * mt + 4 * kk + (l_ >> 4)] = acc[l_, kk]
+    joint = np.concatenate([x[:, 0, :6].astype(np.float64), hr], axis=1)
+    want = joint @ W0.T + b0
+    assert np.abs(y[:, :150] - want).max() < 2e-5, np.abs(y[:, :150] - want).max()
