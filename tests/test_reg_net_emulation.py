@@ -333,3 +333,43 @@ def test_lstm_gate_layer_layout_and_head_k_order():
     joint = np.concatenate([x[:, 0, :6].astype(np.float64), hr], axis=1)
     want = joint @ W0.T + b0
     assert np.abs(y[:, :150] - want).max() < 2e-5, np.abs(y[:, :150] - want).max()
+
+
+def test_hoisted_occupancy_map_term_layout():
+    """kRegSarlPre: mlp1.0's accumulators start from b + W[:, 13:61] om, computed once per (env, human) and stored in the
+    accumulator's own order (sarl_om_term_kernel: term[row][16 mt + 4 lg + kk] = feature 16 mt + 4 kk + lg); 4 k-steps of the 13
+    rotated features follow.  Must equal the 61-input layer."""
+    rng = np.random.default_rng(5)
+    W = (rng.standard_normal((150, 61)) / np.sqrt(61)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(150)).astype(np.float32)
+    x = rng.standard_normal((16, 61)).astype(np.float32)  # one human of 16 groups (here: 16 different envs)
+    term = np.zeros((16, 160), np.float32)                # [row][slot]
+    for slot in range(160):
+        mt, lg, kk = slot >> 4, (slot >> 2) & 3, slot & 3
+        f = 16 * mt + 4 * kk + lg
+        if f < 150:
+            v = np.float32(b[f])
+            for k in range(48):
+                v = np.float32(np.float32(W[f, 13 + k] * x[:, 13 + k]) + v)  # fma chain, bias first (one rounding more than fma: 1e-6)
+            term[:, slot] = v
+    X = np.zeros((4, 64), np.float32)
+    for n in range(13):
+        X[n >> 2, (n & 3) * 16:(n & 3) * 16 + 16] = x[:, n]
+    lane = np.arange(64)
+    got = np.zeros((16, 160))
+    for mt in range(10):
+        acc = np.zeros((64, 4), np.float32)
+        for kk in range(4):
+            acc[:, kk] = term[lane & 15, mt * 16 + (lane >> 4) * 4 + kk]  # one 16-byte load per lane
+        for ks in range(4):
+            a = np.zeros(64, np.float32)
+            for l_ in range(64):
+                lg, m = l_ >> 4, l_ & 15
+                n, col = 16 * mt + 4 * (m & 3) + (m >> 2), 4 * ks + lg
+                a[l_] = W[n, col] if (n < 150 and col < 13) else 0.0
+            acc = mfma(a, X[ks], acc)
+        for l_ in range(64):
+            for kk in range(4):
+                got[l_ & 15, 16 * mt + 4 * kk + (l_ >> 4)] = acc[l_, kk]
+    want = x.astype(np.float64) @ W.T.astype(np.float64) + b
+    assert np.abs(got[:, :150] - want).max() < 1e-5, np.abs(got[:, :150] - want).max()
