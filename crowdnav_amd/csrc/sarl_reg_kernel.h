@@ -27,7 +27,8 @@
 
 namespace cn {
 
-constexpr int kRegDepth = 4;   // weight quads in flight per wave
+constexpr int kRegDepth = 4;   // weight quads in flight per wave (RegStreamT<6> in the 5-human SARL kernels: round 3, below)
+constexpr int kRegPad = 12;    // a stream is a whole number of 4- AND 6-quad groups: one packing serves both depths
 constexpr int kRegHumans = 5;  // N tiles per wave, at most
 constexpr int kRegWaves = 4;   // waves per workgroup = SIMDs per CU
 
@@ -122,9 +123,10 @@ __host__ __device__ constexpr int reg_qbase(int l, int xks) {
     for (int i = 0; i < l; ++i) q += reg_layer_quads(i, xks);
     return q;
 }
-// the stream is padded to a multiple of kRegDepth so that quad I always lives in register slot I % kRegDepth
+// the stream is padded to a multiple of the queue depth (of every depth in use: kRegPad) so that quad I always lives in
+// register slot I % depth
 __host__ __device__ constexpr int reg_total_quads(int xks) {
-    return reg_cdiv(reg_qbase(reg_layers(xks), xks), kRegDepth) * kRegDepth;
+    return reg_cdiv(reg_qbase(reg_layers(xks), xks), kRegPad) * kRegPad;
 }
 // position of item j (0 = bias if the layer has one, then the weight quads) of output tile mt inside its layer
 __host__ __device__ constexpr int reg_qpos(int l, int xks, int mt, int j) {
@@ -224,19 +226,27 @@ typedef const f32x4 __attribute__((address_space(1))) * gf32x4_p;
 // scratch in the first build) or rebuilt as 64-bit vector adds whose destination the register allocator, out of VGPRs, put
 // on top of loads still in flight (s_waitcnt vmcnt(0): the whole prefetch queue drained, several times per tile).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct RegStream {
+// DEPTH quads in flight.  4 everywhere but in the 5-human SARL kernels, which have the registers for 6 (round 3: the one-N-tile
+// layers — attention.0's global half, the value head — consume a quad every 128 cycles, and 4 in flight cover 512 cycles of L2
+// latency: cn_sarl_select 1.868 -> 1.838 ms, with occupancy maps 1.922 -> 1.907, 8 no better than 6).
+template <int DEPTH>
+struct RegStreamT {
+    static constexpr int kDepth = DEPTH;
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t voff;         // lane * 16
-    f32x4 q[kRegDepth];    // quads I .. I + kRegDepth - 1 of the running position (quad J in slot J % kRegDepth)
+    uint32_t voff;     // lane * 16
+    f32x4 q[DEPTH];    // quads I .. I + DEPTH - 1 of the running position (quad J in slot J % DEPTH)
 };
-__device__ __forceinline__ f32x4 reg_quad(const RegStream& s, int J) {
+typedef RegStreamT<kRegDepth> RegStream;
+template <class WS>
+__device__ __forceinline__ f32x4 reg_quad(const WS& s, int J) {
     // 4 quads share one scalar offset (the other 2 address bits go into the instruction's 12-bit immediate)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff + (J & 3) * 1024, (J >> 2) * 4096, 0));
 }
-template <int QT>
-__device__ __forceinline__ f32x4 reg_take(RegStream& s, int I) {
-    const f32x4 v = s.q[I % kRegDepth];
-    s.q[I % kRegDepth] = reg_quad(s, (I + kRegDepth) % QT);
+template <int QT, class WS>
+__device__ __forceinline__ f32x4 reg_take(WS& s, int I) {
+    static_assert(QT % WS::kDepth == 0, "slot I % depth must survive the wrap of the stream");
+    const f32x4 v = s.q[I % WS::kDepth];
+    s.q[I % WS::kDepth] = reg_quad(s, (I + WS::kDepth) % QT);
     return v;
 }
 
@@ -252,8 +262,8 @@ __device__ __forceinline__ f32x4 reg_relu(f32x4 v) {
 
 // emit(nt, mt, act(W x + b)) for NT N tiles and every output tile mt; in(nt, ks) = the B operand of k-step ks; init(mt) =
 // accumulator start when the layer has no bias quad
-template <int XKS, int L, int NT, bool RELU, class In, class Init, class Emit>
-__device__ __forceinline__ void reg_dense(RegStream& ws, In in, Init init, Emit emit) {
+template <int XKS, int L, int NT, bool RELU, class WS, class In, class Init, class Emit>
+__device__ __forceinline__ void reg_dense(WS& ws, In in, Init init, Emit emit) {
     constexpr RegShape S = reg_shape(L, XKS);
     constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
     static_assert(!S.paired, "use reg_dense1");
@@ -317,8 +327,8 @@ __device__ __forceinline__ float reg_relu1(float x) {
 // AGPR array is accumulated in VGPRs, rectified there and moved with one v_accvgpr_write (2 per value; read - max - write on
 // an AGPR accumulator would be 3).  The ReLU of tile mt - 1 follows the first MFMAs of tile mt, so that it never waits for
 // the matrix pipe to drain.
-template <int XKS, int L, int NT, bool AG, class In, class Init, int MT = reg_shape(L, XKS).mt>
-__device__ __forceinline__ void reg_dense_arr(RegStream& ws, In in, Init init, f32x4 (&out)[NT][MT]) {
+template <int XKS, int L, int NT, bool AG, class WS, class In, class Init, int MT = reg_shape(L, XKS).mt>
+__device__ __forceinline__ void reg_dense_arr(WS& ws, In in, Init init, f32x4 (&out)[NT][MT]) {
     constexpr RegShape S = reg_shape(L, XKS);
     constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
     static_assert(!S.paired && MT == S.mt && S.ks >= 4, "use reg_dense1");
@@ -365,8 +375,8 @@ __device__ __forceinline__ void reg_dense_arr(RegStream& ws, In in, Init init, f
 
 // one N tile: output tiles two at a time (their MFMAs alternate: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles,
 // an independent one after 32)
-template <int XKS, int L, bool RELU, class In, int MT = reg_shape(L, XKS).mt>
-__device__ __forceinline__ void reg_dense1(RegStream& ws, In in, f32x4 (&out)[MT]) {
+template <int XKS, int L, bool RELU, class WS, class In, int MT = reg_shape(L, XKS).mt>
+__device__ __forceinline__ void reg_dense1(WS& ws, In in, f32x4 (&out)[MT]) {
     constexpr RegShape S = reg_shape(L, XKS);
     constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
     static_assert(S.paired && S.bias && MT == S.mt, "use reg_dense");
@@ -436,11 +446,11 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
     constexpr int QT = reg_total_quads(KEY);
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
-    RegStream ws;
+    RegStreamT<(NT == kRegHumans ? 6 : kRegDepth)> ws;
     ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, QT * 1024, 0x00020000);  // raw, 32-bit elements
     ws.voff = (uint32_t)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < kRegDepth; ++i) ws.q[i] = reg_quad(ws, i);
+    for (int i = 0; i < ws.kDepth; ++i) ws.q[i] = reg_quad(ws, i);
     if (wid >= n_tiles) return;
     const gfloat_p Xg = as_global(X) + lane;
     float x[NT][XKS];
