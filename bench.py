@@ -24,6 +24,12 @@ is timed separately as `boundary_ms` (and `value_incl_boundary` charges it to th
 actually limits this kernel, only when the committed PMC profile is of the same launch shape) and, at N=1, `cpu_baseline`
 (the CPU oracle timed on this host's cores on a bounded sample of the same workload; + the unmodified reference Python
 loop as timed in the build container) and `secondary` (BASELINE configs[2] and configs[3] measured in the same run).
+
+Two environment switches exist so that the N > 1 code path can be EXECUTED on a one-GPU box (tests/test_bench_multirank.py):
+CROWDNAV_AMD_BENCH_BACKEND=gloo (torch.distributed backend of the ranks; RCCL refuses two ranks on one device, gloo moves
+the few collectives of a run through the host) and CROWDNAV_AMD_BENCH_SHARE_GPU=1 (every rank uses device 0).  Numbers
+measured that way time two processes sharing one GPU and say nothing about scaling; the line says so (`config.backend`,
+`config.shared_gpu`).
 """
 import argparse
 import contextlib
@@ -42,6 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
+REFERENCE_PYTHON_PROFILE = os.path.join(ROOT, 'profiles', 'r03_reference_python.json')
 
 
 def algorithmic_bytes_per_env_step(H):
@@ -76,10 +83,15 @@ def pmc_issue(rec, envs, steps_per_launch, launch_seconds):
     rate, their shares are reported so the reader can discount it."""
     if rec is None or 'sq_insts_valu' not in rec:
         return None
+    src = pmc_provenance()
+    if src is None or src['stale']:
+        return None  # the kernels changed after the counters were collected: no fraction rather than a stale one
     achieved = rec['sq_insts_valu'] / launch_seconds
     out = {'bound': 'valu-issue', 'achieved': achieved / 1e9, 'peak': VALU_ISSUE_PEAK / 1e9,
            'unit': 'G wave-instructions/s', 'frac': achieved / VALU_ISSUE_PEAK,
-           'valu_per_env_step': rec['sq_insts_valu'] / (envs * steps_per_launch)}
+           'valu_per_env_step': rec['sq_insts_valu'] / (envs * steps_per_launch),
+           'counters_from': src, 'note': 'SQ_INSTS_VALU is NOT measured in this run: committed rocprofv3 PMC pass of the same '
+                                         'launch shape (counters_from) over the launch time of this run'}
     for k in ('f64_share', 'trans_share', 'lane_occupancy'):
         if k in rec:
             out[k] = rec[k]
@@ -101,23 +113,104 @@ def no_gc():
         gc.enable()
 
 
+class Comm:
+    """The few collectives of a run (never on the step path): barrier, all-reduce of a handful of float64 scalars, all-gather
+    of small Python objects.  backend 'nccl' = RCCL on device tensors; 'gloo' (CROWDNAV_AMD_BENCH_BACKEND, the one-GPU
+    execution of this path) stages the scalars through the host."""
+
+    def __init__(self, world, rank, backend):
+        self.world, self.rank, self.backend = world, rank, backend
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def all_reduce(self, values, op='sum'):
+        """list of floats -> list of floats, reduced over the ranks"""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(values, dtype=torch.float64, device='cpu' if self.backend == 'gloo' else 'cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu().tolist()]
+
+    def all_gather(self, obj):
+        import torch.distributed as dist
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+
+def pmc_provenance():
+    """Where issue_roofline's instruction counts come from: the committed PMC profile and the commit that last touched it,
+    and whether the kernel sources (crowdnav_amd/csrc) were committed AFTER it — then the counts describe an older kernel
+    and the caller drops the field instead of printing a stale fraction.  Outside a git checkout (the GPU box's snapshot
+    has no .git) the file's own `csrc_sha` stamp (written by scripts/pmc_to_traffic.py) is compared with the sha256 of the
+    sources."""
+    rel = os.path.relpath(PMC_PROFILE, ROOT)
+    info = {'file': rel, 'stale': False}
+    try:
+        doc = json.load(open(PMC_PROFILE))
+    except (OSError, ValueError):
+        return None
+    stamp = doc.get('csrc_sha')
+    if stamp:
+        info['csrc_sha_profiled'] = stamp
+        info['stale'] = stamp != csrc_sha()
+        return info
+    try:
+        def last(*paths):
+            r = subprocess.run(['git', '-C', ROOT, 'log', '-1', '--format=%H %ct', '--'] + list(paths), capture_output=True,
+                               text=True, timeout=10)
+            h, t = r.stdout.split()
+            return h, int(t)
+        (hp, tp), (hc, tc) = last(rel), last(*['crowdnav_amd/csrc/' + n for n in ROLLOUT_SOURCES])
+        info['profile_commit'], info['csrc_commit'] = hp[:12], hc[:12]
+        info['stale'] = tc > tp
+    except Exception:  # no git, no history: cannot tell
+        info['stale'] = None
+    return info
+
+
+# the sources of the rollout kernels (what roofline.traffic / issue_roofline describe); the value-network kernels live elsewhere
+ROLLOUT_SOURCES = ('kd_order.h', 'orca_device.h', 'rollout_fused.h', 'scenario_device.h', 'scenario_wave.h', 'step_kernels.h')
+
+
+def csrc_sha():
+    """sha256 over the rollout kernels' sources, in name order: identifies the kernels a PMC profile was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'crowdnav_amd', 'csrc')
+    for n in ROLLOUT_SOURCES:
+        if os.path.exists(os.path.join(d, n)):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def sarl_flop(B, H, om):
     """algorithmic flops of one batched value-network decision: per (env, action) tile of H humans"""
     return 2 * (81 * H * (62050 + (7200 if om else 0)) + 81 * 33500) * B
 
 
-def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
+def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank, comm=None):
     """BASELINE configs[2]: B envs x H humans, SARL value-network rollout (random-init weights), greedy phase.
     A step = cn_sarl_select (81 lookaheads + value network per env) + cn_rollout_step (transition, bookkeeping, seeded
     auto-reset).  HIP events bracket every cn_sarl_select (the MFMA roofline is the value network's flops over THAT time)
     and every whole step."""
     import numpy as np
     import torch
-    import torch.distributed as dist
     import crowdnav_amd
     from crowdnav_amd import distributed as cd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
     from crowdnav_amd.sarl_rollout import SarlRollout
+    comm = comm or Comm(world, rank, 'nccl')
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
                                        robot_visible=1, device=local_rank)
     torch.manual_seed(0)
@@ -135,9 +228,7 @@ def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
         for e in e3:
             e.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
+    comm.barrier()
     before = int(ro.transitions.item())
     with no_gc():
         t0 = time.perf_counter()
@@ -149,25 +240,23 @@ def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
             e2.record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
+    comm.barrier()
     transitions = int(ro.transitions.item()) - before
-    tot = torch.tensor([float(transitions)], dtype=torch.float64, device='cuda')
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:  # real per-rank counts over the slowest rank's time
-        dist.all_reduce(tot)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    per_rank = comm.all_gather({'rank': rank, 'transitions': transitions, 'seconds': elapsed})
+    tot = sum(r['transitions'] for r in per_rank)  # real per-rank counts over the slowest rank's time
+    tmax = max(r['seconds'] for r in per_rank)
     flop = sarl_flop(B, H, om)
     select_s = sum(a.elapsed_time(b) for a, b, _ in ev) / 1e3 / steps
     step_s = sum(a.elapsed_time(c) for a, _, c in ev) / 1e3 / steps
     name = 'om-sarl' if om else 'sarl'
     out = {
         'metric': 'env-steps/sec, %d envs x %d humans, %s value-net rollout (BASELINE configs[2])' % (B, H, name),
-        'value': float(tot.item()) / float(tmax.item()), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps,
-        'warmup': warm, 'ms_per_step': float(tmax.item()) * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak',
+        'value': tot / tmax, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warm, 'ms_per_step': tmax * 1e3 / steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32 (FP32 MFMA value network, f64 lookahead rewards)', 'data': 'synthetic',
         'config': {'workload': '%d envs x %d humans, 81 actions, %s, random-init weights' % (B, H, name),
-                   'preroll_steps': preroll},
+                   'preroll_steps': preroll, 'backend': comm.backend if world > 1 else None},
+        'ranks': per_rank,
         'roofline': {'bound': 'mfma', 'achieved': flop / select_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
                      'frac': flop / select_s / 1e12 / 157.3, 'traffic': None,
                      'kernel': 'cn_sarl_select (orca + lookahead + reward + feature + value-network + select kernels; the '
@@ -190,9 +279,11 @@ def measure_sarl(B, H, om, steps, warm, preroll, world, rank, local_rank):
     return out
 
 
-def bench_sarl(args, world, rank, local_rank):
+def bench_sarl(args, world, rank, local_rank, comm):
     out = measure_sarl(args.envs, args.humans, args.workload == 'om-sarl', min(args.steps, 200), min(args.warmup, 20),
-                       min(args.preroll, 60), world, rank, local_rank)
+                       min(args.preroll, 60), world, rank, local_rank, comm)
+    if os.environ.get('CROWDNAV_AMD_BENCH_SHARE_GPU') == '1':
+        out['config']['shared_gpu'] = True
     if rank == 0:
         print(json.dumps(out), flush=True)
 
@@ -343,7 +434,7 @@ def cpu_baseline(envs, humans, target_seconds=8.0):
     # north_star: "next to the reference Python-RVO2 CPU path": the unmodified reference loop cannot run on the GPU box
     # (/root/reference does not travel); its timing in the build container is committed by oracle/time_reference_python.py
     ref_py = None
-    ref_path = os.path.join(ROOT, 'profiles', 'r03_reference_python.json')
+    ref_path = REFERENCE_PYTHON_PROFILE
     if os.path.exists(ref_path):
         r = json.load(open(ref_path))
         ref_py = {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'],
@@ -419,26 +510,41 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
 
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('CROWDNAV_AMD_BENCH_BACKEND', 'nccl')
+    share_gpu = os.environ.get('CROWDNAV_AMD_BENCH_SHARE_GPU') == '1'
+    if backend not in ('nccl', 'gloo'):
+        raise SystemExit('CROWDNAV_AMD_BENCH_BACKEND must be nccl or gloo')
+    if world > 1:
+        # dmabuf IPC: the only mode this pool's host driver supports (task environment note: "without it RCCL ... fails
+        # with hipIpcGetMemHandle: invalid argument").  The HSA runtime reads it when it initialises, i.e. before the first
+        # HIP call below — never overriding a value the box exports.
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
     import torch
     import torch.distributed as dist
     import crowdnav_amd
     from crowdnav_amd import distributed as cd
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
+    if share_gpu:
+        local_rank = 0  # every rank on device 0: executes the N > 1 path on a one-GPU box (not a scaling measurement)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit('rank %d needs GPU %d but only %d are visible' % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
+    comm = Comm(world, rank, backend)
 
     B, H = args.envs, args.humans
     if args.workload != 'orca':
-        bench_sarl(args, world, rank, local_rank)
+        bench_sarl(args, world, rank, local_rank, comm)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -454,34 +560,39 @@ def main():
 
     # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
     # inside the timed region costs more host time than a 20-step launch's enqueue
-    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ((args.steps + args.chunk - 1) // args.chunk) + 1)]
+    # One event in front of the first timed launch and one behind EVERY launch: launch k is timed from the event behind launch
+    # k - 1 to its own (the stream has nothing else in between), and the last of them doubles as the "stream has drained" flag
+    # the host spins on — n + 1 event records in the timed region instead of 2 n + 1 (each is a packet the command processor
+    # handles between the kernels).
+    n_launches = (args.steps + args.chunk - 1) // args.chunk
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 2)]
     for ev in pool:
         ev.record()
 
     def run(n_steps, events=None):
         left = n_steps
+        if events is not None:
+            pool[0].record()
         while left > 0:
             n = min(args.chunk, left)
-            if events is not None:
-                e0, e1 = pool[2 * len(events)], pool[2 * len(events) + 1]
-                e0.record()
             eng.rollout(n)
             if events is not None:
-                e1.record()
-                events.append((e0, e1, n))
+                k = len(events)
+                pool[k + 1].record()
+                events.append((pool[k], pool[k + 1], n))
             left -= n
 
-    def drain():
-        pool[-1].record()
-        while not pool[-1].query():  # spin until the stream has drained: a blocking synchronize alone wakes up late
+    def drain(last=None):
+        if last is None:
+            last = pool[-1]
+            last.record()
+        while not last.query():  # spin until the stream has drained: a blocking synchronize alone wakes up late
             pass
         torch.cuda.synchronize()
 
     def fence():
         drain()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        comm.barrier()
 
     def shard_boundary():
         """What a run does ONCE, when it ends (explorer.py:74): single GPU - nothing, the last launch has written the
@@ -503,10 +614,9 @@ def main():
     with no_gc():
         t0 = time.perf_counter()
         run(args.steps, events)
-        drain()  # this rank's K steps are done (synchronize) ...
+        drain(events[-1][1])  # this rank's K steps are done (synchronize) ...
         elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()  # ... and every rank's, before anything else is launched
+    comm.barrier()  # ... and every rank's, before anything else is launched
     tb = time.perf_counter()
     summary = shard_boundary()
     drain()
@@ -516,14 +626,10 @@ def main():
     transitions = int(bufs['transitions'].item()) - before
     # an env whose 48-deep scenario ring ran dry inside one launch pauses until the next launch; count what ran
     paused_env_steps = B * args.steps - transitions
-    t = torch.tensor([elapsed, boundary], dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's K steps; the slowest rank's boundary
-    elapsed, boundary = float(t[0].item()), float(t[1].item())
-    n = torch.tensor([transitions, own_episodes], dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(n)  # transitions of every shard (they differ by the few ring-dry pauses)
-    total, episodes = int(n[0].item()), int(n[1].item())
+    per_rank = comm.all_gather({'rank': rank, 'transitions': transitions, 'seconds': elapsed, 'boundary_seconds': boundary})
+    # the slowest rank's K steps, the slowest rank's boundary; transitions of every shard (they differ by the few ring-dry pauses)
+    elapsed, boundary = comm.all_reduce([elapsed, boundary], op='max')
+    total, episodes = (int(v) for v in comm.all_reduce([transitions, own_episodes]))
 
     kernel_s = sum(e0.elapsed_time(e1) for e0, e1, _ in events) / 1e3
     launches = len(events)
@@ -533,6 +639,8 @@ def main():
     achieved = algorithmic_bytes_per_env_step(H) * B * args.steps / kernel_s / 1e9
     prof = pmc_profile(B, H, steps_per_launch, args.circle_radius) if len(shapes) == 1 else None
     s = [float(v) for v in summary.cpu().tolist()]
+    src = pmc_provenance() if prof is not None else None
+    fresh = src is not None and not src['stale']  # the PMC record describes the kernels of this tree
     out = {
         'metric': 'env-steps/sec (whole node), %d envs x %d humans, ORCA step' % (B, H),
         'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
@@ -547,9 +655,13 @@ def main():
                    'scenario_fill': 'asynchronous (side streams, per-slot ready flags)' if args.async_fill else 'before each launch',
                    'preroll_steps': args.preroll,
                    'parallelism': 'env-axis shards x%d, no collective on the step path; one all-gather of episode records '
-                                  'when a run ends (boundary_ms)' % world},
+                                  'when a run ends (boundary_ms)' % world,
+                   'backend': backend if world > 1 else None, 'shared_gpu': share_gpu},
+        'ranks': per_rank,
+        'summary': s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof),
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof) if fresh else None,
+                     'traffic_from': src if fresh else None,
                      'kernel': 'cn::rollout_fused_kernel (one cn_rollout call incl. its in-kernel statistics epilogue; + '
                                'cn::ring_fill_kernel when the scenario ring needs topping up)' if H <= 5 else
                                'cn::rollout_kernel<10> (+ cn::ring_fill_wave_kernel)',

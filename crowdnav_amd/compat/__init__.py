@@ -12,6 +12,8 @@ from .types import (ActionRot, ActionXY, Collision, Danger, FullState, JointStat
 
 _register_trainable()
 
+from .reference import install  # noqa: E402  (run the reference's own train.py / test.py on these classes)
+
 
 def register():
     """gym.make('CrowdSim-v0') -> crowdnav_amd.compat.CrowdSim (reference: crowd_sim/__init__.py:3-6)."""
@@ -19,6 +21,6 @@ def register():
     gym_register(id='CrowdSim-v0', entry_point='crowdnav_amd.compat:CrowdSim')
 
 
-__all__ = ['CrowdSim', 'Explorer', 'Robot', 'Human', 'ORCA', 'SARL', 'CADRL', 'LstmRL', 'ValueNetwork', 'build_action_space', 'Policy', 'policy_factory', 'default_env_config',
+__all__ = ['install', 'CrowdSim', 'Explorer', 'Robot', 'Human', 'ORCA', 'SARL', 'CADRL', 'LstmRL', 'ValueNetwork', 'build_action_space', 'Policy', 'policy_factory', 'default_env_config',
            'register', 'ActionXY', 'ActionRot', 'ObservableState', 'FullState', 'JointState', 'Timeout',
            'ReachGoal', 'Danger', 'Collision', 'Nothing']

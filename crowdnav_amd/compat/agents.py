@@ -6,7 +6,7 @@ import logging
 import numpy as np
 
 from .policy import policy_factory
-from .types import ActionXY, FullState, JointState, ObservableState
+from .types import ActionRot, ActionXY, FullState, JointState, ObservableState
 
 
 class Agent(object):
@@ -38,8 +38,23 @@ class Agent(object):
         if v_pref is not None:
             self.v_pref = v_pref
 
+    def sample_random_attributes(self):
+        """agent.py:39-45 on the HOST numpy stream (a device reset draws them on the env's own seeded stream instead,
+        scenario_device.h, in the same order)."""
+        self.v_pref = np.random.uniform(0.5, 1.5)
+        self.radius = np.random.uniform(0.3, 0.5)
+
     def get_observable_state(self):
         return ObservableState(self.px, self.py, self.vx, self.vy, self.radius)
+
+    def get_next_observable_state(self, action):
+        """agent.py:63-74: where this agent would be after `action` (what onestep_lookahead reports for the humans)."""
+        self.check_validity(action)
+        nx, ny = self.compute_position(action, self.time_step)
+        if self.kinematics == 'holonomic':
+            return ObservableState(nx, ny, action.vx, action.vy, self.radius)
+        heading = self.theta + action.r
+        return ObservableState(nx, ny, action.v * np.cos(heading), action.v * np.sin(heading), self.radius)
 
     def get_full_state(self):
         return FullState(self.px, self.py, self.vx, self.vy, self.radius, self.gx, self.gy, self.v_pref, self.theta)
@@ -47,11 +62,23 @@ class Agent(object):
     def get_position(self):
         return self.px, self.py
 
+    def set_position(self, position):
+        self.px, self.py = position[0], position[1]
+
     def get_goal_position(self):
         return self.gx, self.gy
 
     def get_velocity(self):
         return self.vx, self.vy
+
+    def set_velocity(self, velocity):
+        self.vx, self.vy = velocity[0], velocity[1]
+
+    def act(self, ob):
+        raise NotImplementedError  # abstract in the reference too (agent.py:95-101)
+
+    def check_validity(self, action):
+        assert isinstance(action, ActionXY if self.kinematics == 'holonomic' else ActionRot)
 
     def compute_position(self, action, delta_t):
         if self.kinematics == 'holonomic':

@@ -27,17 +27,7 @@ class CADRL(SARL):
         self.with_om = False
 
     def configure(self, config):
-        self.gamma = config.getfloat('rl', 'gamma')
-        self.kinematics = config.get('action_space', 'kinematics')
-        self.sampling = config.get('action_space', 'sampling')
-        self.speed_samples = config.getint('action_space', 'speed_samples')
-        self.rotation_samples = config.getint('action_space', 'rotation_samples')
-        self.query_env = config.getboolean('action_space', 'query_env')
-        self.cell_num = config.getint('om', 'cell_num')
-        self.cell_size = config.getfloat('om', 'cell_size')
-        self.om_channel_size = config.getint('om', 'om_channel_size')
-        if self.kinematics not in ('holonomic', 'unicycle'):
-            raise NotImplementedError('kinematics %r' % self.kinematics)
+        self.set_common_parameters(config)
         mlp_dims = [int(x) for x in config.get('cadrl', 'mlp_dims').split(', ')]
         self.model = ValueNetwork(self.joint_state_dim, mlp_dims)
         self.net_cfg = dict(gamma=self.gamma, mlp3_dims=mlp_dims, model='cadrl')

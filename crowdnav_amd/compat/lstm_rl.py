@@ -56,17 +56,7 @@ class LstmRL(SARL):
         self.name = 'LSTM-RL'
 
     def configure(self, config):
-        self.gamma = config.getfloat('rl', 'gamma')
-        self.kinematics = config.get('action_space', 'kinematics')
-        self.sampling = config.get('action_space', 'sampling')
-        self.speed_samples = config.getint('action_space', 'speed_samples')
-        self.rotation_samples = config.getint('action_space', 'rotation_samples')
-        self.query_env = config.getboolean('action_space', 'query_env')
-        self.cell_num = config.getint('om', 'cell_num')
-        self.cell_size = config.getfloat('om', 'cell_size')
-        self.om_channel_size = config.getint('om', 'om_channel_size')
-        if self.kinematics not in ('holonomic', 'unicycle'):
-            raise NotImplementedError('kinematics %r' % self.kinematics)
+        self.set_common_parameters(config)
         pairwise = config.getboolean('lstm_rl', 'with_interaction_module')
         mlp_dims = [int(x) for x in config.get('lstm_rl', 'mlp2_dims').split(', ')]
         hidden = config.getint('lstm_rl', 'global_state_dim')

@@ -32,6 +32,13 @@ class Policy(object):
     def predict(self, state):
         raise NotImplementedError
 
+    @staticmethod
+    def reach_destination(state):
+        """policy.py:40-49: CURRENT position against the goal, norm of (dy, dx) in that order (SURVEY.md App. B #8)."""
+        import numpy as np
+        s = state.self_state
+        return bool(np.linalg.norm((s.py - s.gy, s.px - s.gx)) < s.radius)
+
 
 class ORCA(Policy):
     """Same attributes as the reference's ORCA (orca.py:55-67); the solve itself runs in libcrowdnav_amd."""

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .policy import Policy
-from .types import ActionRot, ActionXY
+from .types import ActionRot, ActionXY, FullState, ObservableState
 
 
 def mlp(input_dim, mlp_dims, last_relu=False):
@@ -107,22 +107,24 @@ class SARL(Policy):
         self.joint_state_dim = 13
         self.net_cfg = None
 
-    def configure(self, config):
+    def set_common_parameters(self, config):
+        """[rl], [action_space], [om] of policy.config (cadrl.py:64-73) — shared by the three value-network policies."""
         self.gamma = config.getfloat('rl', 'gamma')
-        self.kinematics = config.get('action_space', 'kinematics')
-        self.sampling = config.get('action_space', 'sampling')
-        self.speed_samples = config.getint('action_space', 'speed_samples')
-        self.rotation_samples = config.getint('action_space', 'rotation_samples')
-        self.query_env = config.getboolean('action_space', 'query_env')
+        for key, get in (('kinematics', config.get), ('sampling', config.get), ('speed_samples', config.getint),
+                         ('rotation_samples', config.getint), ('query_env', config.getboolean)):
+            setattr(self, key, get('action_space', key))
         self.cell_num = config.getint('om', 'cell_num')
         self.cell_size = config.getfloat('om', 'cell_size')
         self.om_channel_size = config.getint('om', 'om_channel_size')
+        if self.kinematics not in ('holonomic', 'unicycle'):
+            raise NotImplementedError('kinematics %r' % self.kinematics)
+
+    def configure(self, config):
+        self.set_common_parameters(config)
         dims = {k: [int(x) for x in config.get('sarl', k).split(', ')]
                 for k in ('mlp1_dims', 'mlp2_dims', 'mlp3_dims', 'attention_dims')}
         self.with_om = config.getboolean('sarl', 'with_om')
         with_global_state = config.getboolean('sarl', 'with_global_state')
-        if self.kinematics not in ('holonomic', 'unicycle'):
-            raise NotImplementedError('kinematics %r' % self.kinematics)
         self.model = ValueNetwork(self.input_dim(), self.self_state_dim, dims['mlp1_dims'], dims['mlp2_dims'],
                                   dims['mlp3_dims'], dims['attention_dims'], with_global_state, self.cell_size,
                                   self.cell_num)
@@ -183,10 +185,45 @@ class SARL(Policy):
             self.last_state = self.transform(state)
         return action
 
-    @staticmethod
-    def reach_destination(state):
-        s = state.self_state
-        return np.linalg.norm((s.py - s.gy, s.px - s.gx)) < s.radius
+    # ---- host-side mirrors of the reference's helper methods.  The device path does not call them (cn_sarl_select computes
+    # the same quantities for the whole batch); they exist so that code written against the reference's classes finds them.
+    def propagate(self, state, action):
+        """CADRL.propagate (cadrl.py:104-129): constant-velocity step of an observed human / kinematic step of the robot."""
+        dt = self.time_step
+        if isinstance(state, ObservableState):
+            return ObservableState(state.px + action.vx * dt, state.py + action.vy * dt, action.vx, action.vy, state.radius)
+        if not isinstance(state, FullState):
+            raise ValueError('Type error')
+        if self.kinematics == 'holonomic':
+            vx, vy, theta = action.vx, action.vy, state.theta
+        else:
+            theta = state.theta + action.r
+            vx, vy = action.v * np.cos(theta), action.v * np.sin(theta)
+        return FullState(state.px + vx * dt, state.py + vy * dt, vx, vy, state.radius, state.gx, state.gy, state.v_pref, theta)
+
+    def rotate(self, state):
+        """CADRL.rotate (cadrl.py:187-222) on a batch of 14-float joint rows."""
+        return rotate(state, self.kinematics)
+
+    def build_occupancy_maps(self, human_states):
+        """MultiHumanRL.build_occupancy_maps (multi_human_rl.py:109-163): tensor [H, cell_num^2 * om_channel_size]."""
+        return occupancy_maps(human_states, self.cell_num, self.cell_size, self.om_channel_size)
+
+    def compute_reward(self, nav, humans):
+        """MultiHumanRL.compute_reward (multi_human_rl.py:65-88): the reward model of query_env = false, with the reference's
+        literal constants (-0.25, 1, 0.2, 0.5) and its distance at the robot's NEXT position against the humans' next ones."""
+        dmin = float('inf')
+        for human in humans:
+            gap = np.linalg.norm((nav.px - human.px, nav.py - human.py)) - nav.radius - human.radius
+            if gap < 0:
+                return -0.25
+            dmin = min(dmin, gap)
+        if np.linalg.norm((nav.px - nav.gx, nav.py - nav.gy)) < nav.radius:
+            return 1
+        return (dmin - 0.2) * 0.5 * self.time_step if dmin < 0.2 else 0
+
+
+MultiHumanRL = SARL  # the reference's common base of SARL and LSTM-RL (multi_human_rl.py:8); here SARL carries that logic
 
 
 def default_policy_config(overrides=None):

@@ -28,8 +28,8 @@ class ReplayMemory(Dataset):
     def is_full(self):
         return len(self.memory) == self.capacity
 
-    def __getitem__(self, index):
-        return self.memory[index]
+    def __getitem__(self, item):
+        return self.memory[item]
 
     def __len__(self):
         return len(self.memory)

@@ -11,187 +11,18 @@
 //
 // Built with -ffp-contract=off: float32 ORCA and float64 env arithmetic must round exactly like the CPU
 // reference; the only fused operation is the explicit fma in norm2().
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <dlfcn.h>
-#include <new>
-#include <type_traits>
-#include <utility>
-#include <vector>
-
-#include "../../include/crowdnav_amd.h"
-#include "step_kernels.h"
+#include "engine_host.h"
 #include "rollout_fused.h"
 #include "records_kernels.h"
-#include "sarl_kernels.h"
-#include "sarl_reg_kernel.h"
 
-// ------------------------------------------------------------------------------------------------ C ABI
+thread_local char cn_g_err[512] = "";
 
-namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define CN_HIP(call)                                                                              \
-    do {                                                                                          \
-        hipError_t err__ = (call);                                                                \
-        if (err__ != hipSuccess)                                                                  \
-            return fail(CN_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, \
-                        __LINE__);                                                                \
-    } while (0)
-
-}  // namespace
-
-struct cn_engine {
-    cn_config cfg;
-    cn::Params P;
-    cn::ScenarioCfg C;
-    cn::StateView S;
-    hipStream_t stream;
-    cn_rollout_io io_host;   // last cn_rollout_io uploaded to io_dev
-    cn_rollout_io* io_dev;   // device copy the rollout kernels read through
-    cn::StateView* S_dev;    // device copy of S (the fused rollout kernel re-reads state pointers instead of holding them)
-    // CN_FLAG_ASYNC_SCENARIO_FILL: fill kernels go round-robin over side streams (a launch stuck on a hard scenario must
-    // not hold back the next one) and start once the previous transition kernel has written its episode counters
-    static constexpr int kFillStreams = 8;
-    bool async_fill;
-    hipStream_t fill_streams[kFillStreams];
-    hipEvent_t rollout_done;
-    int next_fill_stream;
-    bool io_valid;
-    int steps_since_fill;    // transitions launched since the scenario ring was last topped up; < 0 = never filled
-    struct cn_sarl* sarl;    // SARL decision state (sarl_abi.inc), NULL until cn_sarl_configure
-    double* discount;
-    int discount_len;
-    uint32_t* probe_key;
-    double* summary_scratch;  // records_summary_kernel: per-workgroup partials + ticket counter
-    int maxl;          // half-planes held in VGPRs by the solve phase: 5 or 10
-    bool mt_in_lds;    // lane-per-scenario generators keep their MT19937 state in LDS instead of HBM
-    bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
-    size_t smem;       // dynamic LDS bytes per workgroup
-    // Device memory comes from a few large slabs, not one hipMalloc per buffer: an engine has ~60 device buffers, most of them a
-    // few KiB; one 32 MiB slab (plus one per buffer larger than that) is 2-4 mappings to create and - each hipFree being a device
-    // synchronisation - 2-4 to tear down, and cn_sarl_configure can roll a failed configuration back to a mark.
-    struct Slab {
-        char* base;
-        size_t size, used;
-    };
-    std::vector<Slab> slabs;
-    struct AllocMark {
-        size_t n_slabs, used;
-    };
-    AllocMark alloc_mark() const { return {slabs.size(), slabs.empty() ? 0 : slabs.back().used}; }
-    void alloc_rollback(AllocMark m) {  // frees everything allocated since alloc_mark()
-        while (slabs.size() > m.n_slabs) {
-            (void)hipFree(slabs.back().base);
-            slabs.pop_back();
-        }
-        if (!slabs.empty()) slabs.back().used = m.used;
-    }
-};
-
-namespace {
-
-constexpr size_t kSlabBytes = (size_t)32 << 20, kSlabAlign = 4096;
-
-template <typename T>
-int dev_alloc(cn_engine* e, T** out, size_t n) {
-    const size_t bytes = (n * sizeof(T) + kSlabAlign - 1) / kSlabAlign * kSlabAlign;
-    if (e->slabs.empty() || e->slabs.back().used + bytes > e->slabs.back().size) {
-        const size_t size = bytes > kSlabBytes ? (bytes + ((size_t)2 << 20) - 1) >> 21 << 21 : kSlabBytes;
-        void* p = nullptr;
-        CN_HIP(hipMalloc(&p, size));
-        e->slabs.push_back({static_cast<char*>(p), size, 0});
-    }
-    cn_engine::Slab& sl = e->slabs.back();
-    void* p = sl.base + sl.used;
-    sl.used += bytes;
-    CN_HIP(hipMemset(p, 0, bytes));
-    *out = static_cast<T*>(p);
-    return CN_OK;
-}
-
-int bind(cn_engine* e) {
-    if (!e) return fail(CN_ERR_INVALID, "engine is NULL");
-    CN_HIP(hipSetDevice(e->cfg.device));
-    return CN_OK;
-}
-
-inline int grid_envs(const cn_engine* e) { return (e->P.B + e->P.E - 1) / e->P.E; }
-
-// launch a kernel template instantiated for the engine's half-plane capacity (and with / without the kd-tree bookkeeping of
-// simulators with more than 10 agents)
-#define CN_LAUNCH_MAXL(e, kernel, grid, ...)                                                                        \
-    do {                                                                                                            \
-        const dim3 g__(grid), b__((e)->P.threads);                                                                  \
-        if ((e)->maxl == 5 && !(e)->P.kd)                                                                           \
-            hipLaunchKernelGGL((cn::kernel<5, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);               \
-        else if ((e)->maxl == 5)                                                                                    \
-            hipLaunchKernelGGL((cn::kernel<5, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);                \
-        else if (!(e)->P.kd)                                                                                        \
-            hipLaunchKernelGGL((cn::kernel<10, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);              \
-        else                                                                                                        \
-            hipLaunchKernelGGL((cn::kernel<10, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__);               \
-    } while (0)
-
-// ... and for the robot kinematics (the unicycle code only exists in the <.., true, ..> instantiations).  K: the kernel
-// template takes <MAXL, UNI, KD> (step_kernel) — rollout_kernel has HEADLINE in between, see CN_LAUNCH_ROLLOUT
-#define CN_LAUNCH_MAXL_UNI(e, kernel, grid, ...)                                                                    \
-    do {                                                                                                            \
-        const dim3 g__(grid), b__((e)->P.threads);                                                                  \
-        const int v__ = ((e)->maxl == 5 ? 0 : 4) | ((e)->P.robot_unicycle ? 2 : 0) | ((e)->P.kd ? 1 : 0);           \
-        switch (v__) {                                                                                              \
-            case 0: hipLaunchKernelGGL((cn::kernel<5, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-            case 1: hipLaunchKernelGGL((cn::kernel<5, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
-            case 2: hipLaunchKernelGGL((cn::kernel<5, true, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
-            case 3: hipLaunchKernelGGL((cn::kernel<5, true, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;    \
-            case 4: hipLaunchKernelGGL((cn::kernel<10, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break; \
-            case 5: hipLaunchKernelGGL((cn::kernel<10, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-            case 6: hipLaunchKernelGGL((cn::kernel<10, true, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-            default: hipLaunchKernelGGL((cn::kernel<10, true, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-        }                                                                                                           \
-    } while (0)
-
-#define CN_LAUNCH_ROLLOUT(e, grid, ...)                                                                             \
-    do {                                                                                                            \
-        const dim3 g__(grid), b__((e)->P.threads);                                                                  \
-        const int v__ = ((e)->maxl == 5 ? 0 : 4) | ((e)->P.robot_unicycle ? 2 : 0) | ((e)->P.kd ? 1 : 0);           \
-        switch (v__) {                                                                                              \
-            case 0: hipLaunchKernelGGL((cn::rollout_kernel<5, false, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-            case 1: hipLaunchKernelGGL((cn::rollout_kernel<5, false, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
-            case 2: hipLaunchKernelGGL((cn::rollout_kernel<5, true, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;   \
-            case 3: hipLaunchKernelGGL((cn::rollout_kernel<5, true, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;    \
-            case 4: hipLaunchKernelGGL((cn::rollout_kernel<10, false, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break; \
-            case 5: hipLaunchKernelGGL((cn::rollout_kernel<10, false, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-            case 6: hipLaunchKernelGGL((cn::rollout_kernel<10, true, false, false>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-            default: hipLaunchKernelGGL((cn::rollout_kernel<10, true, false, true>), g__, b__, (e)->smem, (e)->stream, __VA_ARGS__); break;  \
-        }                                                                                                           \
-    } while (0)
-
-int env_int(const char* name, int fallback) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : fallback;
-}
-inline int grid_lanes(const cn_engine* e) { return (e->P.B + cn::kWave - 1) / cn::kWave; }
-
-}  // namespace
+// every agent's ORCA velocity on the engine's stream (cn_orca; the first kernel of cn_sarl_select in sarl_abi.hip)
+void cn_launch_orca(cn_engine* e, float* out_vel) { CN_LAUNCH_MAXL(e, orca_kernel, grid_envs(e), e->P, e->S, out_vel); }
 
 extern "C" {
 
-const char* cn_last_error(void) { return g_err; }
+const char* cn_last_error(void) { return cn_g_err; }
 int cn_abi_version(void) { return 5; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
@@ -356,8 +187,6 @@ int cn_create(const cn_config* c, cn_engine** out) {
     return rc;
 }
 
-static void sarl_release(cn_engine* e);
-
 int cn_destroy(cn_engine* e) {
     if (!e) return CN_OK;
     (void)hipSetDevice(e->cfg.device);
@@ -368,9 +197,9 @@ int cn_destroy(cn_engine* e) {
             (void)hipStreamDestroy(e->fill_streams[i]);
         }
     if (e->rollout_done) (void)hipEventDestroy(e->rollout_done);
-    e->alloc_rollback({0, 0});
+    e->alloc_rollback(cn_engine::AllocMark{});
     if (e->discount) (void)hipFree(e->discount);
-    sarl_release(e);
+    cn_sarl_release(e);
     delete e;
     return CN_OK;
 }
@@ -545,7 +374,7 @@ int cn_orca(cn_engine* e, float* out_vel) {
     int rc = bind(e);
     if (rc) return rc;
     if (!out_vel) return fail(CN_ERR_INVALID, "cn_orca: out_vel is NULL");
-    CN_LAUNCH_MAXL(e, orca_kernel, grid_envs(e), e->P, e->S, out_vel);
+    cn_launch_orca(e, out_vel);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -684,6 +513,9 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     static const bool use_fused = env_int("CROWDNAV_AMD_FUSED", 1) != 0;
     static const bool use_geom20 = env_int("CROWDNAV_AMD_GEOM20", 1) != 0;  // the compile-time geometry of configs[3]'s shard
     const bool headline = P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 && P.threads == 64;
+    // (small crowds the fused kernel does not take — unicycle robot, asynchronous fill, several waves per workgroup — run the
+    // generic rollout_kernel<5, ..>; its own compile-time-geometry instantiation for configs[1] went when the fused kernel
+    // became the headline path)
     // (the fused kernel reads the launch-time fill level only: never with the asynchronous fill, whose slots are published
     // one by one — CROWDNAV_AMD_WAVE_SCENARIOS=1 can switch that on for a small crowd)
     if (use_fused && !e->async_fill && e->maxl == 5 && !P.robot_unicycle && P.NC <= cn::kFusedMaxNC && P.pairs <= cn::kWave &&
@@ -694,9 +526,6 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
         else
             hipLaunchKernelGGL((cn::rollout_fused_kernel<false>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
                                (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
-    } else if (e->maxl == 5 && !P.robot_unicycle && headline) {
-        hipLaunchKernelGGL((cn::rollout_kernel<5, false, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
-                           (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else if (use_geom20 && e->maxl == 10 && !P.robot_unicycle && P.A == 21 && P.NC == 20 && P.E == 1 && P.threads == 64 &&
                P.orca.max_neighbors == 10 && P.kd) {
         hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
@@ -811,8 +640,6 @@ int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out) {
 
 }  // extern "C"
 
-#include "sarl_abi.inc"
-
 #ifdef CN_PHASE_TIMING
 // profiling builds only (scripts/phase_probe.py): accumulated shader-clock cycles per rollout phase, [8] = waves
 extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
@@ -820,14 +647,6 @@ extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
     if (reset) {
         unsigned long long zero[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_phase_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-extern "C" int cn_debug_sarl_cycles(unsigned long long* out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cn::cn_sarl_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long zero[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_sarl_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;
 }

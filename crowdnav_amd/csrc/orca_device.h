@@ -22,6 +22,18 @@ constexpr int kMaxNb = 10;     // RVO2 maxNeighbors supported (the reference har
 constexpr int kLineStride = kMaxNb + 1;  // float4 slots per agent in LDS (+1 pad: conflict-free b128 reads)
 constexpr float kRvoEps = 0.00001f;
 
+// "Barrier" of a ONE-wave workgroup (the fused rollout, the 20-human shard's rollout, a scenario generator wave): a wave's
+// LDS instructions execute in order, so between one lane's write and another lane's read no s_barrier — and none of the
+// s_waitcnt lgkmcnt(0) hipcc puts in front of one — is needed; what IS needed is that the COMPILER keeps the accesses in
+// program order.  wave_barrier alone is a scheduling barrier with no memory semantics (IntrNoMem): the two wavefront-scope
+// fences make it a release / acquire pair at IR level, so no LDS access may be moved or forwarded across it whatever the
+// optimiser can prove about per-thread aliasing; at wavefront scope they emit no instruction on gfx9.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct OrcaParams {
     float neighbor_dist;
     float inv_time_horizon;  // 1.0f / timeHorizon

@@ -73,7 +73,7 @@ __device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max
 #ifdef CN_EXP_FUSED_BARRIER
 #define CN_FUSED_SYNC() __syncthreads()
 #else
-#define CN_FUSED_SYNC() __builtin_amdgcn_wave_barrier()
+#define CN_FUSED_SYNC() wave_lds_sync()
 #endif
 
 template <bool HEADLINE>

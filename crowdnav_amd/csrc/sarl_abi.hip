@@ -1,4 +1,9 @@
-// C ABI of the SARL robot decision (declared in include/crowdnav_amd.h); included at the end of crowdnav_amd.hip.
+// C ABI of the SARL robot decision (declared in include/crowdnav_amd.h): cn_sarl_* and the value-network kernels, a
+// translation unit of its own (engine_host.h has what it shares with crowdnav_amd.hip).
+#define CN_SARL_TU  // step_kernels.h: the ORCA / step kernels and the engine types, not the rollout and scenario kernels
+#include "engine_host.h"
+#include "sarl_kernels.h"
+#include "sarl_reg_kernel.h"
 
 struct cn_sarl {
     cn_sarl_config cfg;
@@ -19,8 +24,6 @@ struct cn_sarl {
     size_t lds_bytes;
     bool weights_set;
     bool chunked;       // sarl_mlp_chunked_kernel: the humans do not fit one tile's LDS
-    bool legacy_mlp;    // CROWDNAV_AMD_SARL_V1=1: the one-tile-per-workgroup kernel of round 1 (A/B)
-    bool pipe_mlp;      // the value head of tile t - 1 on the waves idle during tile t (sarl_mlp_pipe_kernel); CROWDNAV_AMD_SARL_PIPE=0: off
     bool reg_mlp;       // sarl_reg_kernel: activations in registers (shipped widths, 5 humans, more than 512 tiles); CROWDNAV_AMD_SARL_REG=0 / 2: never / always
     int reg_xks;        // its network key: k-steps of the SARL input, 4 (13 features) or 16 (+ 48 occupancy-map features); kRegCadrl
     float* reg_stream;  // its weight stream: reg_total_quads(reg_xks) quads of 256 floats
@@ -34,7 +37,7 @@ struct cn_sarl {
     int n_cus;
 };
 
-static void sarl_release(cn_engine* e) {
+void cn_sarl_release(cn_engine* e) {
     delete e->sarl;  // device buffers are owned by the engine's slabs
     e->sarl = nullptr;
 }
@@ -122,8 +125,6 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
     s->cfg = *c;
     s->weights_set = false;
     s->chunked = false;
-    s->legacy_mlp = env_int("CROWDNAV_AMD_SARL_V1", 0) != 0;
-    s->pipe_mlp = env_int("CROWDNAV_AMD_SARL_PIPE", 1) != 0;
     s->reg_mlp = false, s->reg_xks = 0, s->reg_stream = s->reg_stream2 = s->reg_stream3 = s->reg_scratch = s->om_w = s->om_term = nullptr;
     s->chunk_nt = s->n_chunks = s->cadrl_nt = s->cadrl_chunks = 0;
     {
@@ -211,15 +212,11 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->chunked = H > cn::kSarlMaxHumans;  // cadrl_mlp_chunked_kernel streams the humans in chunks of 5
         if (s->chunked) s->lds_bytes = cn::cadrl_mlp_chunked_lds_bytes(net);
     } else {
-        s->lds_bytes = cn::sarl_mlp_lds_bytes(net);
-        s->chunked = H > cn::kSarlMaxHumans || s->lds_bytes > 160 * 1024;  // 6+ humans at the shipped widths
+        // one tile's activations + the side chain's pong buffer (sarl_mlp_pipe_kernel) in LDS, or the humans stream through
+        // in chunks (6+ humans at the shipped widths)
+        s->lds_bytes = cn::sarl_mlp_lds_bytes(net) + cn::sarl_mlp_pipe_extra_lds_bytes(net);
+        s->chunked = H > cn::kSarlMaxHumans || s->lds_bytes > 160 * 1024;
         if (s->chunked) s->lds_bytes = cn::sarl_mlp_chunked_lds_bytes(net);
-        if (!s->chunked && !s->legacy_mlp && s->pipe_mlp) {  // + the side chain's pong buffer, if one tile still fits
-            if (s->lds_bytes + cn::sarl_mlp_pipe_extra_lds_bytes(net) <= 160 * 1024)
-                s->lds_bytes += cn::sarl_mlp_pipe_extra_lds_bytes(net);
-            else
-                s->pipe_mlp = false;
-        }
     }
     // The register-resident kernel is compiled for the shipped network (policy.config [sarl]) on 1..5 humans.  It is a THROUGHPUT
     // kernel: one wave carries a tile through the whole network in ~86 us, 1024 of them at a time; the LDS kernel puts a whole
@@ -227,19 +224,17 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
     // train.py) the LDS kernel finishes first.  CROWDNAV_AMD_SARL_REG: 0 never, 1 (default) by size, 2 always.
     const int reg_mode = env_int("CROWDNAV_AMD_SARL_REG", 1);
     const size_t tiles_here = ((size_t)C.B * C.n_actions + cn::kSarlGroups - 1) / cn::kSarlGroups;
-    if (!cadrl && !lstm && !s->legacy_mlp && H >= 1 && H <= cn::kRegHumans && c->with_global_state && (in_dim == 13 || in_dim == 61) &&
+    if (!cadrl && !lstm && H >= 1 && H <= cn::kRegHumans && c->with_global_state && (in_dim == 13 || in_dim == 61) &&
         m1a == 150 && m1b == 100 && m2a == 100 && m2b == 50 && a0 == 100 && a1 == 100 && j0 == 150 && j1 == 100 && j2 == 100 &&
         (reg_mode == 2 || (reg_mode == 1 && tiles_here > 512))) {
-        // 61 inputs: the occupancy-map half of mlp1.0 is hoisted out of the action loop (CROWDNAV_AMD_SARL_OM_HOIST=0: all 16
-        // k-steps inside the kernel, the maps read directly)
-        // (the un-hoisted kernel is kept for 5 humans only: the A/B of DESIGN section 3)
-        s->reg_mlp = true, s->reg_xks = in_dim == 13 ? 4 : (H != 5 || env_int("CROWDNAV_AMD_SARL_OM_HOIST", 1)) ? cn::kRegSarlPre : 16;
+        // 61 inputs: the occupancy-map half of mlp1.0 is hoisted out of the action loop (sarl_om_term_kernel, kRegSarlPre)
+        s->reg_mlp = true, s->reg_xks = in_dim == 13 ? 4 : cn::kRegSarlPre;
         if ((rc = dev_alloc(e, &s->reg_stream, (size_t)cn::reg_total_quads(s->reg_xks) * 256))) return rc;
         if (s->reg_xks == cn::kRegSarlPre &&
             ((rc = dev_alloc(e, &s->om_w, (size_t)160 * 49)) || (rc = dev_alloc(e, &s->om_term, (size_t)C.B * H * 160))))
             return rc;
     }
-    if (!cadrl && !lstm && !s->legacy_mlp && H > cn::kRegHumans && c->with_global_state && (in_dim == 13 || in_dim == 61) && m1a == 150 &&
+    if (!cadrl && !lstm && H > cn::kRegHumans && c->with_global_state && (in_dim == 13 || in_dim == 61) && m1a == 150 &&
         m1b == 100 && m2a == 100 && m2b == 50 && a0 == 100 && a1 == 100 && j0 == 150 && j1 == 100 && j2 == 100 &&
         (reg_mode == 2 || (reg_mode == 1 && tiles_here > 512))) {  // sarl_reg_chunk_kernel: chunks of 3 or 4 humans
         s->n_chunks = (H + 3) / 4, s->chunk_nt = (H + s->n_chunks - 1) / s->n_chunks;
@@ -254,13 +249,13 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
             ((rc = dev_alloc(e, &s->om_w, (size_t)160 * 49)) || (rc = dev_alloc(e, &s->om_term, (size_t)C.B * H * 160))))
             return rc;
     }
-    if (cadrl && !s->legacy_mlp && H >= 1 && in_dim == 13 && j0 == 150 && j1 == 100 && j2 == 100 &&
+    if (cadrl && H >= 1 && in_dim == 13 && j0 == 150 && j1 == 100 && j2 == 100 &&
         (reg_mode == 2 || (reg_mode == 1 && tiles_here > 512))) {  // cadrl_reg_kernel: [cadrl] mlp_dims = 150, 100, 100, 1
         s->reg_mlp = true, s->reg_xks = cn::kRegCadrl;
         s->cadrl_chunks = (H + cn::kRegHumans - 1) / cn::kRegHumans, s->cadrl_nt = (H + s->cadrl_chunks - 1) / s->cadrl_chunks;
         if ((rc = dev_alloc(e, &s->reg_stream, (size_t)cn::reg_total_quads(s->reg_xks) * 256))) return rc;
     }
-    if (lstm && !pairwise && !s->legacy_mlp && hid == cn::kRegLstmHid && (in_dim == 13 || in_dim == 61) && j0 == 150 && j1 == 100 &&
+    if (lstm && !pairwise && hid == cn::kRegLstmHid && (in_dim == 13 || in_dim == 61) && j0 == 150 && j1 == 100 &&
         j2 == 100 && (reg_mode == 2 || (reg_mode == 1 && tiles_here > 512))) {  // lstm_reg_kernel: any number of humans
         s->reg_mlp = true, s->reg_xks = cn::kRegLstmGates + (in_dim == 13 ? 4 : 16);
         if ((rc = dev_alloc(e, &s->reg_stream, (size_t)cn::reg_total_quads(s->reg_xks) * 256)) ||
@@ -280,7 +275,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         (rc = dev_alloc(e, &s->X, s->n_tiles * H * net.ks_x * 64)) ||
         (rc = dev_alloc(e, &s->hcount, s->n_tiles * cn::kSarlGroups)))
         return rc;
-    if (e->cfg.scenario_rule == CN_MIXED && (s->chunked || s->legacy_mlp))
+    if (e->cfg.scenario_rule == CN_MIXED && s->chunked)
         return fail(CN_ERR_UNSUPPORTED,
                     "value networks under the mixed rule run the one-tile kernels (they mask an episode's absent humans): "
                     "num_humans must be 5 (the rule never draws more)");
@@ -434,7 +429,7 @@ int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array) {
 // The register-resident kernel for 61 inputs (13 rotated features + 48 map cells) reads the occupancy maps from
 // `om` itself; X then holds k-steps 0..3 only (sarl_reg_kernel.h).
 static bool sarl_om_direct(const cn_sarl* s) {
-    return s->reg_mlp && (s->reg_xks == 16 || s->reg_xks == cn::kRegSarlPre || s->reg_xks == cn::kRegChunkAPre) && s->net.in_dim == 61;
+    return s->reg_mlp && (s->reg_xks == cn::kRegSarlPre || s->reg_xks == cn::kRegChunkAPre) && s->net.in_dim == 61;
 }
 
 int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) {
@@ -446,7 +441,7 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
     const cn::SarlCfg& C = s->C;
     const int H = C.H;
     // humans' next velocities, once per env (query_env = false: they keep their current ones, no ORCA pass)
-    if (!C.const_vel) CN_LAUNCH_MAXL(e, orca_kernel, grid_envs(e), e->P, e->S, s->orca_vel);
+    if (!C.const_vel) cn_launch_orca(e, s->orca_vel);
     // the humans' next observable states: their own kernel only where something is built on them per (env, human) — occupancy
     // maps, LSTM-RL's re-ordering; otherwise the feature kernel derives them itself.  The reward of every (env, action) is
     // evaluated inside sarl_select_kernel.  (Each small kernel less is ~7 us of a 70 us single-env decision.)
@@ -470,14 +465,9 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
         else if (s->cfg.model == CN_MODEL_LSTM_RL)                                                                   \
             hipLaunchKernelGGL(cn::lstm_mlp_kernel<HH>, grid, block, s->lds_bytes, e->stream, s->net, s->X, s->V, ng,   \
                                s->hcount);                                                                          \
-        else if (s->legacy_mlp)                                                                                      \
-            hipLaunchKernelGGL(cn::sarl_mlp_kernel_v1<HH>, grid, block, s->lds_bytes, e->stream, s->net, s->X, s->V, ng); \
-        else if (s->pipe_mlp)                                                                                        \
+        else                                                                                                         \
             hipLaunchKernelGGL(cn::sarl_mlp_pipe_kernel<HH>, pgrid, block, s->lds_bytes, e->stream, s->ref, s->X, s->V, \
                                ng, (int)s->n_tiles, s->hcount);                                                      \
-        else                                                                                                         \
-            hipLaunchKernelGGL(cn::sarl_mlp_kernel<HH>, pgrid, block, s->lds_bytes, e->stream, s->ref, s->X, s->V, ng,  \
-                               (int)s->n_tiles, s->hcount);                                                          \
         break;
     if (s->reg_mlp) {
         const unsigned wgs = (unsigned)((s->n_tiles + cn::kRegWaves - 1) / cn::kRegWaves);
@@ -527,9 +517,6 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
         else if (s->reg_xks == 4) CN_SARL_REG((cn::sarl_reg_kernel<4, NT>), om_direct, C.n_actions); \
         else CN_SARL_REG((cn::sarl_reg_kernel<4, NT, true>), om_direct, C.n_actions);             \
         break;
-        if (!reg_cadrl && s->reg_xks == 16)
-            CN_SARL_REG((cn::sarl_reg_kernel<16, 5>), om_direct, C.n_actions);
-        else
         switch (NTK) {
             CN_SARL_REG_NT(1)
             CN_SARL_REG_NT(2)
@@ -621,3 +608,15 @@ int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes) {
 }
 
 }  // extern "C"
+
+#ifdef CN_PHASE_TIMING
+// profiling builds only (scripts/sarl_phase_probe.py)
+extern "C" int cn_debug_sarl_cycles(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cn::cn_sarl_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_sarl_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -35,7 +35,7 @@ namespace cn {
 // CN_PHASE_TIMING (profiling builds only): per-layer shader-clock ticks of sarl_mlp_kernel as wave 0 sees them
 // (barrier to barrier), summed over tiles into cn_sarl_cycles[k]; [15] = tiles.  scripts/sarl_phase_probe.py
 #ifdef CN_PHASE_TIMING
-__device__ unsigned long long cn_sarl_cycles[16];
+static __device__ unsigned long long cn_sarl_cycles[16];
 #define CN_SARL_CLOCK_BEGIN() unsigned long long sclk_last_ = __builtin_readcyclecounter(), sclk_acc_[15] = {}
 #define CN_SARL_TICK(k)                                                  \
     do {                                                                 \
@@ -603,11 +603,7 @@ __global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_k
 // Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS traffic, not for its global loads — so
 // the B fragments of the NEXT layer, requested before the barrier (dense_prefetch), stay in flight across it
 // (__syncthreads() drains vmcnt as well and would expose one L2 round trip per layer: 11 per tile).
-#ifndef CN_EXP_NO_BARRIER
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#else
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#endif
 
 // Weights are read through GLOBAL-address-space pointers: a generic pointer whose provenance the compiler cannot see (the
 // persistent kernel rebuilds them from an arena base) turns into flat_load, which counts on lgkmcnt as well as vmcnt — and
@@ -674,24 +670,12 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) ah[j][rt] = afrag[(rt * ks_in + j) * 64];
         for (int k0 = 0; k0 < P.kpad; k0 += kSarlKChunk) {
-#ifndef CN_EXP_NO_B
 #pragma unroll
             for (int j = 0; j < kSarlKChunk; ++j) bnxt[j] = wfrag[(k0 + kSarlKChunk + j) * 64];
-#else
-#pragma unroll
-            for (int j = 0; j < kSarlKChunk; ++j) bnxt[j] = bcur[j] + 1.0f;
-#endif
-#ifndef CN_EXP_NO_A
 #pragma unroll
             for (int j = kHead; j < kSarlKChunk; ++j)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) ar[j - kHead][rt] = afrag[(rt * ks_in + k0 + j) * 64];
-#else
-#pragma unroll
-            for (int j = kHead; j < kSarlKChunk; ++j)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) ar[j - kHead][rt] = ah[0][rt] + (float)(k0 + j);
-#endif
             __builtin_amdgcn_sched_barrier(0);  // requests first
 #pragma unroll
             for (int j = 0; j < kHead; ++j)
@@ -699,12 +683,10 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j][rt], bcur[j], acc[rt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef CN_EXP_NO_A
 #pragma unroll
             for (int j = 0; j < kHead; ++j)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) ah[j][rt] = afrag[(rt * ks_in + k0 + kSarlKChunk + j) * 64];
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = kHead; j < kSarlKChunk; ++j)
@@ -724,11 +706,7 @@ __device__ __forceinline__ void dense_mfma(const PackedLinear& P, const float* i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
             }
-#ifndef CN_EXP_NO_EPILOGUE
             *reinterpret_cast<f32x4*>(out + rt * ks_out * 64 + frag_off) = v;
-#else
-            if (v[0] == 123.456f) *reinterpret_cast<f32x4*>(out + rt * ks_out * 64 + frag_off) = v;
-#endif
         }
     }
 }
@@ -769,147 +747,9 @@ __device__ __forceinline__ void zero_lds(float* lds, size_t words, int tid) {
 // per launch instead of once per tile (every k-padding word the MFMA loops read is either written by the producing layer —
 // whole column tiles — or zeroed explicitly below); layers are separated by lds_barrier, and every layer's first B
 // fragments are requested BEFORE the barrier that precedes it (dense_prefetch), while the previous layer's epilogue and the
-// barrier wait are still in progress.
-template <int H>
-__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel(SarlNetRef net, const float* X, float* V, int n_groups,
-                                                                int n_tiles, const int* hcount) {
-    extern __shared__ float lds[];
-    float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
-    float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2
-    float* bufC = bufB + H * net.ks_b * 64;       // [H][ks_c][64]  mlp2 output (per-human feature)
-    float* gbuf = bufC + H * net.ks_c * 64;       // [ks_b][64]     mean over humans of h2
-    float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]     joint state / mlp3 ping
-    float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term / mlp3 pong
-    float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights, final value
-    float* vbuf = sbuf + H * net.ks_s * 64;       // [kSarlThreads] partial sums of the single-output layers
-    int* hc = reinterpret_cast<int*>(vbuf + kSarlThreads);  // [16] humans present per group (H unless the `mixed` rule)
-
-    int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    zero_lds(lds, (size_t)(vbuf - lds), tid);
-    const int nf = net.nf;
-    const int x_words = H * net.ks_x * 64;
-    float* xs = bufB;
-    BFrag pre = dense_prefetch(layer_of(net, kL_mlp1_0), wave, lane);
-    lds_barrier();
-    CN_SARL_CLOCK_BEGIN();
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        // Everything that depends only on the lane or on the descriptors is loop-invariant, and the compiler would hoist
-        // it: a dozen layers' worth of fragment addresses in VGPRs and pointers in SGPRs, live across the whole tile loop
-        // (128 VGPRs + scratch instead of 70).  Laundering the three ids and the arena base makes it recompute them where
-        // they are used — a few integer operations per layer.
-        asm volatile("" : "+v"(tid), "+v"(lane));
-        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        SarlNetRef nn = net;
-        asm volatile("" : "+s"(nn.base));
-        const SarlNetRef* n = &nn;
-        // stage X: a straight coalesced copy (the feature kernel wrote fragment order)
-        const float* xg = X + (size_t)tile * x_words;
-        for (int i = tid; i < x_words; i += kSarlThreads) xs[i] = xg[i];
-        if (tid < kSarlGroups) hc[tid] = hcount[(size_t)tile * kSarlGroups + tid];
-        // k padding of the joint state (features 6 + nf .. of mlp3.0's k loop): the previous tile left mlp3.2's output there
-        for (int i = tid; i < kSarlGroups * (layer_of(*n, kL_mlp3_0).kpad * 4 - 6 - nf); i += kSarlThreads) {
-            const int g = i & 15, n = 6 + nf + (i >> 4);
-            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = 0.0f;
-        }
-        __syncthreads();  // X came from global memory: this one waits for it (and for the prefetch, an L2 hit by now)
-        CN_SARL_TICK(0);
-        // self_state = state[:, 0, :6] (sarl.py:36): features 0..5 of human 0's row of each group
-        if (tid < kSarlGroups * 6) {
-            const int g = tid & 15, n = tid >> 4;
-            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];
-        }
-        dense_mfma<H, true>(layer_of(*n, kL_mlp1_0), xs, n->ks_x, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
-        pre = dense_prefetch(layer_of(*n, kL_mlp1_2), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(1);
-        dense_mfma<H, true>(layer_of(*n, kL_mlp1_2), bufA, n->ks_a, bufB, n->ks_b, true, nullptr, wave, lane, &pre);  // h2
-        pre = dense_prefetch(layer_of(*n, kL_mlp2_0), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(2);
-        // global state: mean over the humans of a group (sarl.py:42) — elementwise over fragment offsets
-        if (n->with_global) {
-            for (int i = tid; i < n->ks_b * 64; i += kSarlThreads) {
-                const int cnt = hc[i & 15];
-                float sum = 0.0f;
-#pragma unroll
-                for (int h = 0; h < H; ++h) sum += h < cnt ? bufB[h * n->ks_b * 64 + i] : 0.0f;
-                gbuf[i] = sum / (float)cnt;
-            }
-        }
-        dense_mfma<H, true>(layer_of(*n, kL_mlp2_0), bufB, n->ks_b, bufA, n->ks_a, true, nullptr, wave, lane, &pre);
-        pre = dense_prefetch(layer_of(*n, kL_mlp2_2), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(3);
-        dense_mfma<H, true>(layer_of(*n, kL_mlp2_2), bufA, n->ks_a, bufC, n->ks_c, false, nullptr, wave, lane, &pre);  // features
-        // attention layer 0 on [h2 | global]: the global half is the same for every human of a group, so it is
-        // one 16-row product (kbuf) added to every row tile's accumulator at the matching group row
-        if (n->with_global) dense_mfma<1>(layer_of(*n, kL_att0_global), gbuf, n->ks_b, kbuf, n->ks_a, false, nullptr, wave, lane);
-        pre = dense_prefetch(layer_of(*n, kL_att0_local), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(4);
-        dense_mfma<H, true>(layer_of(*n, kL_att0_local), bufB, n->ks_b, bufA, n->ks_a, true, n->with_global ? kbuf : nullptr,
-                            wave, lane, &pre);
-        pre = dense_prefetch(layer_of(*n, kL_att_2), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(5);
-        dense_mfma<H, true>(layer_of(*n, kL_att_2), bufA, n->ks_a, bufB, n->ks_b, true, nullptr, wave, lane, &pre);
-        lds_barrier();
-        CN_SARL_TICK(6);
-        dense_vec1<H>(layer_of(*n, kL_att_4), bufB, n->ks_b, sbuf, n->ks_s, vbuf, tid);  // score (h, g) at h*ks_s*64 + g
-        pre = dense_prefetch(layer_of(*n, kL_mlp3_0), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(7);
-        // masked softmax without max subtraction (sarl.py:52-53)
-        if (tid < kSarlGroups) {
-            float e[H], total = 0.0f;
-            const int cnt = hc[tid];
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const float sc = sbuf[h * n->ks_s * 64 + tid];
-                e[h] = h < cnt ? expf(sc) * (sc != 0.0f ? 1.0f : 0.0f) : 0.0f;  // an absent human carries no weight
-                total += e[h];
-            }
-#pragma unroll
-            for (int h = 0; h < H; ++h) sbuf[h * n->ks_s * 64 + tid] = e[h] / total;
-        }
-        lds_barrier();
-        CN_SARL_TICK(8);
-        // weighted feature sum (sarl.py:60) -> joint state features 6 ..
-        for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
-            const int g = i & 15, c = i >> 4;
-            const int src = (c >> 2) * 64 + (c & 3) * 16 + g;
-            float sum = 0.0f;
-#pragma unroll
-            for (int h = 0; h < H; ++h) sum += sbuf[h * n->ks_s * 64 + g] * bufC[h * n->ks_c * 64 + src];
-            const int n = 6 + c;
-            jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = sum;
-        }
-        lds_barrier();
-        CN_SARL_TICK(9);
-        dense_mfma<1, true>(layer_of(*n, kL_mlp3_0), jbuf, n->ks_a, kbuf, n->ks_a, true, nullptr, wave, lane, &pre);
-        pre = dense_prefetch(layer_of(*n, kL_mlp3_2), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(10);
-        dense_mfma<1, true>(layer_of(*n, kL_mlp3_2), kbuf, n->ks_a, jbuf, n->ks_a, true, nullptr, wave, lane, &pre);
-        pre = dense_prefetch(layer_of(*n, kL_mlp3_4), wave, lane);
-        lds_barrier();
-        CN_SARL_TICK(11);
-        dense_mfma<1, true>(layer_of(*n, kL_mlp3_4), jbuf, n->ks_a, kbuf, n->ks_a, true, nullptr, wave, lane, &pre);
-        lds_barrier();
-        CN_SARL_TICK(12);
-        dense_vec1<1>(layer_of(*n, kL_mlp3_6), kbuf, n->ks_a, sbuf, n->ks_s, vbuf, tid);
-        pre = dense_prefetch(layer_of(*n, kL_mlp1_0), wave, lane);  // the next tile's first layer
-        lds_barrier();
-        CN_SARL_TICK(13);
-        if (tid < kSarlGroups) {
-            const size_t G = (size_t)tile * kSarlGroups + tid;
-            if (G < (size_t)n_groups) V[G] = sbuf[tid];
-        }
-        // sbuf / vbuf are next written after the next tile's first barriers: no extra barrier needed here
-    }
-    CN_SARL_CLOCK_END_N((n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
-}
-
+// barrier wait are still in progress.  (The plain form of this kernel — every wave on every layer, the value head in line:
+// what profiles/r02_sarl_ablation.txt measured — and the one-tile-per-workgroup kernel of round 1 were removed in round 4;
+// no default route reached them.)
 // The value head of tile t - 1 (mlp3: three 16-row layers + the single-output layer, 13 k of a tile's 84 k ticks when run
 // on its own: 16 rows cannot fill the workgroup) runs on the waves that idle during tile t's 7-column-tile layers:
 //   slot of tile t            main waves 0..6 (0..9)      side waves
@@ -1057,118 +897,6 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_pipe_kernel(SarlNetRef 
     }
 }
 __host__ inline size_t sarl_mlp_pipe_extra_lds_bytes(const SarlNet& net) { return sizeof(float) * 64 * (size_t)net.ks_a; }
-
-template <int H>
-__global__ __launch_bounds__(kSarlThreads) void sarl_mlp_kernel_v1(SarlNet net, const float* X, float* V, int n_groups) {
-    extern __shared__ float lds[];
-    float* bufA = lds;                            // [H][ks_a][64]  wide hidden layers
-    float* bufB = bufA + H * net.ks_a * 64;       // [H][ks_b][64]  X staging, then mlp1 output (h2), then attention.2
-    float* bufC = bufB + H * net.ks_b * 64;       // [H][ks_c][64]  mlp2 output (per-human feature)
-    float* gbuf = bufC + H * net.ks_c * 64;       // [ks_b][64]     mean over humans of h2
-    float* jbuf = gbuf + net.ks_b * 64;           // [ks_a][64]     joint state / mlp3 ping
-    float* kbuf = jbuf + net.ks_a * 64;           // [ks_a][64]     global attention term / mlp3 pong
-    float* sbuf = kbuf + net.ks_a * 64;           // [H][ks_s][64]  attention scores -> weights, final value
-    float* vbuf = sbuf + H * net.ks_s * 64;       // [kSarlThreads] partial sums of the single-output layers
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const size_t tile = blockIdx.x;
-    CN_SARL_CLOCK_BEGIN();
-    zero_lds(lds, (size_t)(vbuf - lds), tid);
-    __syncthreads();
-
-    // stage X: a straight coalesced copy (the feature kernel wrote fragment order); X is staged with ks_x k-steps
-    float* xs = bufB;
-    const float* xg = X + tile * H * net.ks_x * 64;
-    for (int i = tid; i < H * net.ks_x * 64; i += kSarlThreads) xs[i] = xg[i];
-    // k padding of the joint-state buffer (features 6 + nf .. ks*4) must be finite zeros
-    for (int i = tid; i < net.ks_a * 64; i += kSarlThreads) jbuf[i] = 0.0f;
-    __syncthreads();
-    CN_SARL_TICK(0);
-    // self_state = state[:, 0, :6] (sarl.py:36): features 0..5 of human 0's row of each group
-    if (tid < kSarlGroups * 6) {
-        const int g = tid & 15, n = tid >> 4;
-        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = xs[(n >> 2) * 64 + (n & 3) * 16 + g];
-    }
-
-    dense_mfma<H>(net.L[kL_mlp1_0], xs, net.ks_x, bufA, net.ks_a, true, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(1);
-    dense_mfma<H>(net.L[kL_mlp1_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);  // h2
-    __syncthreads();
-    CN_SARL_TICK(2);
-    // global state: mean over the humans of a group (sarl.py:42) — elementwise over fragment offsets
-    if (net.with_global) {
-        for (int i = tid; i < net.ks_b * 64; i += kSarlThreads) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int h = 0; h < H; ++h) sum += bufB[h * net.ks_b * 64 + i];
-            gbuf[i] = sum / (float)H;
-        }
-    }
-    dense_mfma<H>(net.L[kL_mlp2_0], bufB, net.ks_b, bufA, net.ks_a, true, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(3);
-    dense_mfma<H>(net.L[kL_mlp2_2], bufA, net.ks_a, bufC, net.ks_c, false, nullptr, wave, lane);  // features
-    // attention layer 0 on [h2 | global]: the global half is the same for every human of a group, so it is
-    // one 16-row product (kbuf) added to every row tile's accumulator at the matching group row
-    if (net.with_global) dense_mfma<1>(net.L[kL_att0_global], gbuf, net.ks_b, kbuf, net.ks_a, false, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(4);
-    dense_mfma<H>(net.L[kL_att0_local], bufB, net.ks_b, bufA, net.ks_a, true, net.with_global ? kbuf : nullptr, wave,
-                  lane);
-    __syncthreads();
-    CN_SARL_TICK(5);
-    dense_mfma<H>(net.L[kL_att_2], bufA, net.ks_a, bufB, net.ks_b, true, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(6);
-    dense_vec1<H>(net.L[kL_att_4], bufB, net.ks_b, sbuf, net.ks_s, vbuf, tid);  // score (h, g) at h*ks_s*64 + g
-    __syncthreads();
-    CN_SARL_TICK(7);
-    // masked softmax without max subtraction (sarl.py:52-53)
-    if (tid < kSarlGroups) {
-        float e[H], total = 0.0f;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float sc = sbuf[h * net.ks_s * 64 + tid];
-            e[h] = expf(sc) * (sc != 0.0f ? 1.0f : 0.0f);
-            total += e[h];
-        }
-#pragma unroll
-        for (int h = 0; h < H; ++h) sbuf[h * net.ks_s * 64 + tid] = e[h] / total;
-    }
-    __syncthreads();
-    CN_SARL_TICK(8);
-    // weighted feature sum (sarl.py:60) -> joint state features 6 ..
-    const int nf = net.L[kL_mlp2_2].N;
-    for (int i = tid; i < kSarlGroups * nf; i += kSarlThreads) {
-        const int g = i & 15, c = i >> 4;
-        const int src = (c >> 2) * 64 + (c & 3) * 16 + g;
-        float sum = 0.0f;
-#pragma unroll
-        for (int h = 0; h < H; ++h) sum += sbuf[h * net.ks_s * 64 + g] * bufC[h * net.ks_c * 64 + src];
-        const int n = 6 + c;
-        jbuf[(n >> 2) * 64 + (n & 3) * 16 + g] = sum;
-    }
-    __syncthreads();
-    CN_SARL_TICK(9);
-    dense_mfma<1>(net.L[kL_mlp3_0], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(10);
-    dense_mfma<1>(net.L[kL_mlp3_2], kbuf, net.ks_a, jbuf, net.ks_a, true, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(11);
-    dense_mfma<1>(net.L[kL_mlp3_4], jbuf, net.ks_a, kbuf, net.ks_a, true, nullptr, wave, lane);
-    __syncthreads();
-    CN_SARL_TICK(12);
-    dense_vec1<1>(net.L[kL_mlp3_6], kbuf, net.ks_a, sbuf, net.ks_s, vbuf, tid);
-    __syncthreads();
-    CN_SARL_TICK(13);
-    if (tid < kSarlGroups) {
-        const size_t G = tile * kSarlGroups + tid;
-        if (G < (size_t)n_groups) V[G] = sbuf[tid];
-    }
-    CN_SARL_CLOCK_END();
-}
 
 // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row, then the minimum over the humans
 // of a group (cadrl.py:162-163).  Layers live in L[kL_mlp3_0 .. kL_mlp3_6]; buffers as in the SARL kernel.

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "orca_device.h"
 #include "scenario_device.h"
 
 namespace cn {
@@ -18,7 +19,7 @@ namespace cn {
 // A generator workgroup is ONE wave: its LDS instructions execute in order, so the phases below only need the compiler to keep
 // program order between one lane's write and another lane's read — not s_barrier with the LDS queue drained in front of it
 // (8 per 624-word block of the generator).
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void wave_sync() { wave_lds_sync(); }
 
 struct WaveRng {
     uint32_t* key;   // [624] generator state (LDS)

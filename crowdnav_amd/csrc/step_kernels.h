@@ -203,7 +203,7 @@ __device__ __forceinline__ Smem carve(const Params& P) {
 // so between one lane's write and another lane's read only the compiler has to keep program order — and the s_waitcnt
 // lgkmcnt(0) in front of every s_barrier (the LDS queue drained a dozen times per step) goes away.
 __device__ __forceinline__ void block_sync(const Params& P) {
-    if (P.threads == kWave) __builtin_amdgcn_wave_barrier();
+    if (P.threads == kWave) wave_lds_sync();
     else __syncthreads();
 }
 __device__ __forceinline__ int block_sync_or(const Params& P, int v) {
@@ -632,7 +632,7 @@ __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, 
 // CN_PHASE_TIMING (compile time, profiling builds only): per-phase shader-clock accumulation inside the fused rollout
 // (scripts/phase_probe.py).  Off in the product build: PhaseClock is empty and CN_TICK expands to nothing.
 #ifdef CN_PHASE_TIMING
-__device__ unsigned long long cn_phase_cycles[16];
+static __device__ unsigned long long cn_phase_cycles[16];  // (static: step_kernels.h is part of both translation units)
 struct PhaseClock {
     unsigned long long last, acc[10];
 };
@@ -1243,6 +1243,9 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
     }
 }
 
+// Everything below — scenario generation, rollout bookkeeping, the rollout kernels — belongs to the env translation unit
+// (crowdnav_amd.hip).  sarl_abi.hip includes this header for orca_kernel / step_kernel's types only and defines CN_SARL_TU.
+#ifndef CN_SARL_TU
 // The 624-word MT19937 state of the scenario a lane is generating lives in LDS, word-major ([624][64 lanes]:
 // conflict-free, ~30 cycles per draw instead of a dependent L2 round trip).  One 64-lane workgroup takes
 // 624 * 64 * 4 = 159 744 B, i.e. one generator wave per CU — what makes the reference's heavy-tailed rejection
@@ -1618,6 +1621,9 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
             if ((int)blockIdx.x * P.E + el < P.B) t += scratch[el * F + tid];
         agent_store(S.wg_partial + (size_t)blockIdx.x * F + tid, t);
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "rollout_epilogue orders its payload stores before the ticket with s_waitcnt vmcnt(0): on gfx9 (gfx950) vmcnt counts stores; gfx10+ counts them in vscnt - use release / acquire atomics there"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's payload has left before the ticket is taken
     block_sync(P);
     int* const flag = reinterpret_cast<int*>(scratch + P.E * F);
@@ -1824,5 +1830,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
     }
     rollout_epilogue(P, S, *R.io, L, robot, transitions, ep_count, reinterpret_cast<double*>(s.lines));
 }
+
+#endif  // CN_SARL_TU
 
 }  // namespace cn

@@ -7,7 +7,9 @@ shard boundary (end of Explorer.run_k_episodes, crowd_nav/utils/explorer.py:74-9
 A record block is what cn_rollout_records packs per env (include/crowdnav_amd.h): float64 [1 + 6 K] =
 (episodes finished, K x RECORD_FIELDS).  Record j is RING SLOT j of the env's record ring: its j-th finished episode while
 the env has finished at most record_capacity episodes; once the ring has wrapped, the most recent episode whose ordinal
-is congruent to j.  episodes_in_global_order therefore refuses wrapped blocks (size the rings for the run).
+is congruent to j.  episodes_in_global_order therefore refuses wrapped rings — an env that finished more episodes than
+its ring's record_capacity (NOT more than the K <= record_capacity records a block carries: that is a truncated view of
+valid slots) — so size the rings for the run.
 pack_blocks is its host-side restatement (CPU tests, and the reference for the GPU test of the kernel)."""
 import torch
 import torch.distributed as dist
@@ -54,19 +56,30 @@ def gather_blocks(blocks, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return blocks
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == 'gloo' and blocks.is_cuda:
+        # gloo (CPU tests, and bench.py's one-GPU execution of the N > 1 path) moves the blocks through the host
+        host = blocks.detach().cpu().contiguous()
+        out = torch.empty((world * host.shape[0], host.shape[1]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(blocks.device)
     out = torch.empty((world * blocks.shape[0], blocks.shape[1]), dtype=blocks.dtype, device=blocks.device)
     dist.all_gather_into_tensor(out, blocks.contiguous(), group=group)
     return out
 
 
-def episodes_in_global_order(records, counts, total_envs, finished=None):
-    """Flatten gathered records to a list ordered by global episode id c = g + j * total_envs.  finished (optional): the
-    unclamped episode counts, blocks[:, 0]; an env that finished more episodes than its ring holds has overwritten slots,
-    and slot j is then not episode j (include/crowdnav_amd.h: record_capacity) — refused."""
+def episodes_in_global_order(records, counts, total_envs, finished, record_capacity=None):
+    """Flatten gathered records to a list ordered by global episode id c = g + j * total_envs.
+    finished: the unclamped episode counts (blocks[:, 0]); record_capacity: slots of an env's record ring (default: the K
+    records a block carries).  An env that finished more episodes than its RING holds has overwritten slots, and slot j is
+    then not episode j (include/crowdnav_amd.h: record_capacity) — refused.  A block that carries fewer records than the
+    ring holds (K < record_capacity) is not a wrap: its slots are valid, the list is merely truncated to K per env."""
     K = records.shape[1]
-    if finished is not None and bool((finished.to(torch.int64) > counts).any()):
-        raise ValueError('record rings have wrapped (an env finished more episodes than its %d record slots): slot j is no '
-                         'longer episode j; use a larger record_capacity' % int(counts.max()))
+    cap = K if record_capacity is None else int(record_capacity)
+    over = finished.to(torch.int64) > cap
+    if bool(over.any()):
+        raise ValueError('record rings have wrapped: %d env(s) finished more episodes (up to %d) than their %d record slots, '
+                         'slot j is no longer episode j; use a larger record_capacity'
+                         % (int(over.sum()), int(finished.max()), cap))
     rows = []
     for j in range(K):
         have = counts > j
@@ -76,3 +89,9 @@ def episodes_in_global_order(records, counts, total_envs, finished=None):
     vals = torch.cat([r[1] for r in rows])
     order = torch.argsort(ids)
     return ids[order], vals[order]
+
+
+def episodes_from_blocks(blocks, total_envs, record_capacity=None):
+    """gathered [n, 1 + 6 K] blocks -> (global episode ids, records) in global episode order; refuses wrapped rings."""
+    records, counts = split_blocks(blocks, record_capacity)
+    return episodes_in_global_order(records, counts, total_envs, blocks[:, 0], record_capacity)

@@ -69,7 +69,8 @@ class BatchedCrowdSim(object):
     def use_current_stream(self):
         """Launch on torch's current HIP stream so torch ops and torch.cuda.Event order with the engine."""
         with torch.cuda.device(self.device):
-            check(self._lib.cn_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            self._stream = torch.cuda.current_stream()
+            check(self._lib.cn_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
 
     def sync(self):
         check(self._lib.cn_sync(self._h))
@@ -308,8 +309,12 @@ def _sarl_set_weights(self, state_dict):
     ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     check(self._lib.cn_sarl_set_weights(self._h, ptrs))
     # the tensors above (temporaries when the model lives elsewhere or in another dtype) must outlive the repack kernels: kept
-    # until the next call — by then those kernels are long behind on the same stream; no synchronize per call (the RL phase
-    # uploads weights once per sampled episode)
+    # until the next call — by then those kernels are long behind on the engine's stream; no synchronize per call (the RL phase
+    # uploads weights once per sampled episode).  The caching allocator is told that the engine's stream reads them: were
+    # the caller inside another torch.cuda.stream(...) context, a freed temporary could otherwise be handed out again on THAT
+    # stream while the repack kernels, on the stream captured at construction / use_current_stream(), still read it.
+    for t in tensors:
+        t.record_stream(self._stream)
     self._sarl_weights_keepalive = tensors
 
 
@@ -384,10 +389,16 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     outputs, addresses precomputed — the four wrappers above cost ~45 us of Python per step between them (tensor views,
     pointer objects, checks), as much as the step costs the device at one env."""
     B, T, H, D = traj.shape
-    assert traj.dtype == torch.float32 and traj.is_contiguous() and act.dtype == torch.int32 and act.is_contiguous()
-    for t_, dt in ((rew, torch.float64), (dmin, torch.float64), (info, torch.uint8)):
-        assert t_.dtype == dt and t_.is_contiguous() and tuple(t_.shape) == (T, B)
-    assert alive.dtype == torch.uint8 and done.dtype == torch.uint8 and action.dtype == torch.float64 and action.is_contiguous()
+    if B != self.B or H != self.H:
+        raise ValueError('traj is [%d, T, %d, D]; the engine holds %d envs x %d humans' % (B, H, self.B, self.H))
+    specs = ((traj, torch.float32, (B, T, H, D)), (act, torch.int32, (T, B)), (rew, torch.float64, (T, B)),
+             (dmin, torch.float64, (T, B)), (info, torch.uint8, (T, B)), (alive, torch.uint8, (B,)), (done, torch.uint8, (B,)),
+             (action, torch.float64, (B, 2)))
+    for t_, dt, shape in specs:  # raw addresses go to the C ABI below: every tensor on the engine's device, dense, as declared
+        if t_.device != self.device or t_.dtype != dt or tuple(t_.shape) != shape or not t_.is_contiguous():
+            raise ValueError('sarl_sampler: expected a contiguous %s %s tensor on %s, got %s %s on %s (contiguous: %s)'
+                             % (dt, shape, self.device, t_.dtype, tuple(t_.shape), t_.device, t_.is_contiguous()))
+    keep = (self, traj, rew, info, dmin, act, alive, done, action)  # the closure owns what its addresses point into
     lib, h, V = self._lib, self._h, C.c_void_p
     p_traj, p_rew, p_inf, p_dmn, p_act = traj.data_ptr(), rew.data_ptr(), info.data_ptr(), dmin.data_ptr(), act.data_ptr()
     p_alive, p_done, p_action = V(alive.data_ptr()), V(done.data_ptr()), V(action.data_ptr())
@@ -395,6 +406,8 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     stride = T * H * D
 
     def step(t, epsilon):
+        if not keep[0]._h.value:
+            raise RuntimeError('sarl_sampler: the engine has been closed')
         best = V(p_act + 4 * B * t)
         check(lib.cn_sarl_select(h, None, best, p_action))
         check(lib.cn_sarl_explore(h, epsilon, p_alive, best, p_action, None))

@@ -52,5 +52,8 @@ doc = json.load(open(out)) if os.path.exists(out) else {'profiles': []}
 key = lambda p: (p['envs'], p['humans'], p['steps_per_launch'], p.get('circle_radius', 4.0))  # noqa: E731
 doc['profiles'] = [p for p in doc['profiles'] if key(p) != key(rec)]
 doc['profiles'].append(rec)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+doc['csrc_sha'] = bench.csrc_sha()  # the rollout kernels these counters were collected on (bench.py: pmc_provenance)
 json.dump(doc, open(out, 'w'), indent=1)
 print(json.dumps(rec, indent=1))

@@ -42,3 +42,45 @@ def test_committed_pmc_profile_is_well_formed():
 def test_algorithmic_bytes_follow_the_survey():
     import bench
     assert bench.algorithmic_bytes_per_env_step(5) == 458 and bench.algorithmic_bytes_per_env_step(20) == 1538
+
+
+def test_issue_roofline_names_its_counter_source_and_is_dropped_when_stale(tmp_path, monkeypatch):
+    """issue_roofline divides COMMITTED SQ_INSTS_VALU by this run's launch time.  The line says where the
+    counters come from, and a kernel edit without a re-profile drops the field instead of printing a stale fraction."""
+    import bench
+    prof = tmp_path / 'traffic.json'
+    rec = dict(envs=4096, humans=5, steps_per_launch=20, fetch_size_kb=100.0, write_size_kb=50.0, sq_insts_valu=4.0e7)
+    # (1) stamped profile (scripts/pmc_to_traffic.py writes csrc_sha): fresh when the stamp equals the sources' hash
+    prof.write_text(json.dumps({'csrc_sha': bench.csrc_sha(), 'profiles': [rec]}))
+    monkeypatch.setattr(bench, 'PMC_PROFILE', str(prof))
+    src = bench.pmc_provenance()
+    assert src['stale'] is False and src['csrc_sha_profiled'] == bench.csrc_sha()
+    issue = bench.pmc_issue(bench.pmc_profile(4096, 5, 20), 4096, 20, 100e-6)
+    assert issue['counters_from'] == src and 'NOT measured in this run' in issue['note']
+    # (2) the kernels changed since: no issue_roofline
+    prof.write_text(json.dumps({'csrc_sha': '0' * 16, 'profiles': [rec]}))
+    assert bench.pmc_provenance()['stale'] is True
+    assert bench.pmc_issue(bench.pmc_profile(4096, 5, 20), 4096, 20, 100e-6) is None
+    # (3) unstamped profile outside the repository: cannot tell -> stale is None or decided by git; never a crash
+    prof.write_text(json.dumps({'profiles': [rec]}))
+    assert bench.pmc_provenance()['stale'] in (None, True, False)
+
+
+def test_committed_profile_provenance_is_decidable_in_this_checkout():
+    import bench
+    if not os.path.exists(bench.PMC_PROFILE):
+        return
+    src = bench.pmc_provenance()
+    assert src is not None and src['file'].startswith('profiles/')
+    assert 'csrc_sha_profiled' in src or 'profile_commit' in src or src['stale'] is None
+
+
+def test_reference_python_baseline_is_labelled_off_host():
+    """cpu_baseline.reference_python is the unmodified reference loop timed in the BUILD container (the reference does not
+    travel to the GPU box): the embedded record must say so."""
+    import bench
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "(build container, NOT this host)" in src
+    assert os.path.exists(bench.REFERENCE_PYTHON_PROFILE)
+    r = json.load(open(bench.REFERENCE_PYTHON_PROFILE))
+    assert r['cores'] == 1 and r['value'] > 0 and 'host_cpu' in r

@@ -1,0 +1,114 @@
+"""bench.py's N > 1 path EXECUTED on a one-GPU box, before the driver's 8-GPU run is its first execution.
+
+`python bench.py --gpus 2 ...` re-executes itself as two ranks (self_launch: the command line the driver uses at N = 1; under
+torch.distributed.run the ranks arrive with RANK / WORLD_SIZE set and the same code runs).  Two switches make that possible
+where only one GPU exists: CROWDNAV_AMD_BENCH_SHARE_GPU=1 maps every rank to device 0, CROWDNAV_AMD_BENCH_BACKEND=gloo replaces
+RCCL (which refuses two ranks on one device) for the handful of collectives of a run — barriers, two small reductions, the
+ONE all-gather of record blocks at the shard boundary.  Everything else is the code the 8-GPU run executes: env-axis shards
+with global episode seeds, per-rank timing between barriers, the boundary (gather + job-wide summary kernel), one JSON line
+from rank 0.  What is asserted: the line's arithmetic (value = all ranks' transitions / the slowest rank's time), that the
+job-wide statistics equal those of ONE engine holding all 8192 envs (sharding invariance through the real script), and that a
+rank dying makes the parent exit non-zero instead of hanging in a collective.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra)
+    return env
+
+
+def _json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith('{')]
+
+
+def _run(args, timeout=420, **extra):
+    p = subprocess.run([sys.executable, BENCH] + args, env=_env(**extra), capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout[-3000:]  # rank 0 prints exactly ONE line
+    return lines[0]
+
+
+SHARED = dict(CROWDNAV_AMD_BENCH_BACKEND='gloo', CROWDNAV_AMD_BENCH_SHARE_GPU='1')
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_sharing_one_gpu_orca():
+    flags = ['--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-secondary']
+    two = _run(['--gpus', '2'] + flags, **SHARED)
+    assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['steps'] == 20 and two['warmup'] == 5
+    assert two['config']['backend'] == 'gloo' and two['config']['shared_gpu'] is True
+    ranks = sorted(two['ranks'], key=lambda r: r['rank'])
+    assert [r['rank'] for r in ranks] == [0, 1]
+    # whole-job throughput: every rank's transitions over the SLOWEST rank's time
+    total, slowest = sum(r['transitions'] for r in ranks), max(r['seconds'] for r in ranks)
+    assert two['value'] == pytest.approx(total / slowest, rel=1e-12)
+    assert two['ms_per_step'] == pytest.approx(slowest * 1e3 / 20, rel=1e-12)
+    assert 0 < total <= 2 * 4096 * 20 and all(r['transitions'] > 0.9 * 4096 * 20 for r in ranks)
+    # the one exchange of a run was executed and timed
+    assert two['boundary_ms'] > 0.0 and two['value_incl_boundary'] < two['value']
+    # sharding invariance through the real script: ONE engine with all 8192 envs (global env ids 0..8191, the same episode
+    # seeds) leaves the same job-wide statistics as the two shards' gathered record blocks
+    one = _run(['--gpus', '1', '--envs', '8192'] + flags)
+    assert one['n_gpus'] == 1 and one['boundary_ms'] == 0.0
+    assert one['episodes_finished'] == two['episodes_finished'] > 0
+    assert sum(r['transitions'] for r in one['ranks']) == total
+    s1, s2 = one['summary'], two['summary']
+    assert s1[:5] == s2[:5] and s1[7] == s2[7]                    # counts: episodes, records held, success / collision / timeout, danger steps
+    assert s1[5] == pytest.approx(s2[5], rel=1e-12) and s1[6] == pytest.approx(s2[6], rel=1e-12)  # float64 sums, other order
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_sharing_one_gpu_sarl():
+    two = _run(['--gpus', '2', '--workload', 'sarl', '--steps', '6', '--warmup', '2', '--preroll', '4'], **SHARED)
+    assert two['n_gpus'] == 2 and two['config']['backend'] == 'gloo' and two['config'].get('shared_gpu') is True
+    ranks = sorted(two['ranks'], key=lambda r: r['rank'])
+    assert [r['rank'] for r in ranks] == [0, 1]
+    total, slowest = sum(r['transitions'] for r in ranks), max(r['seconds'] for r in ranks)
+    assert two['value'] == pytest.approx(total / slowest, rel=1e-12) and total > 0
+    assert two['roofline']['bound'] == 'mfma' and 0.0 < two['roofline']['frac'] < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_a_dying_rank_ends_the_job_non_zero():
+    """SIGKILL one rank while the job runs: the parent must terminate the other rank (it would wait in a collective forever)
+    and return non-zero well inside the timeout."""
+    import psutil
+    p = subprocess.Popen([sys.executable, BENCH, '--gpus', '2', '--steps', '400000', '--warmup', '5', '--no-cpu-baseline',
+                          '--no-secondary'], env=_env(**SHARED), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        kids, t0 = [], time.time()
+        while len(kids) < 2 and time.time() - t0 < 120:
+            kids = psutil.Process(p.pid).children()
+            time.sleep(0.2)
+        assert len(kids) == 2, 'bench.py --gpus 2 did not start two ranks'
+        time.sleep(20.0)  # let them get past the imports and into the run (400 000 steps: several minutes of work)
+        assert p.poll() is None, 'job ended before a rank was killed: %s' % p.stderr.read()[-2000:]
+        kids[1].kill()
+        rc = p.wait(timeout=120)
+        assert rc != 0
+        for k in kids:
+            assert not k.is_running() or k.status() == psutil.STATUS_ZOMBIE
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+def test_bench_refuses_an_unknown_backend():
+    p = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--steps', '1'], env=_env(CROWDNAV_AMD_BENCH_BACKEND='mpi'),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and 'nccl or gloo' in p.stderr

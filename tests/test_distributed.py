@@ -35,7 +35,9 @@ def _worker(rank, world, port, B, K, ret):
     assert cd.shard(rank, world, B) == (rank * B, world * B)
     allb = cd.gather_blocks(cd.pack_blocks(_fake_bufs(rank, B, K, world)))
     allr, allc = cd.split_blocks(allb)
-    ids, vals = cd.episodes_in_global_order(allr, allc, world * B)
+    ids, vals = cd.episodes_in_global_order(allr, allc, world * B, allb[:, 0])
+    ids2, vals2 = cd.episodes_from_blocks(allb, world * B)
+    assert torch.equal(ids, ids2) and torch.equal(vals, vals2)
     ret[rank] = (allr.clone(), allc.clone(), ids.clone(), vals.clone())
     dist.barrier()
     dist.destroy_process_group()
@@ -70,6 +72,22 @@ def test_gather_is_identity_without_process_group():
     assert float(rec[0].abs().sum()) == 0.0 and float(rec[1, 1].abs().sum()) == 0.0  # nothing beyond what an env holds
     with pytest.raises(ValueError):
         cd.shard(2, 2, 4)
+
+
+def test_only_a_wrapped_ring_is_refused():
+    """an env that finished more episodes than its RING holds is refused; a block that merely carries fewer
+    records than the ring holds (K < record_capacity) is a truncated view of valid slots and is not."""
+    from crowdnav_amd import distributed as cd
+    bufs = _fake_bufs(0, 6, 3, 1)                      # ring of 3 slots, envs finished 0, 1, 2, 3, 0, 1 episodes
+    blocks = cd.pack_blocks(bufs)
+    ids, vals = cd.episodes_from_blocks(blocks, 6)     # nothing wrapped
+    assert len(ids) == int(bufs['ep_count'].sum())
+    short = cd.pack_blocks(bufs, max_records=2)        # K = 2 < capacity 3: env 3 finished 3 > K episodes
+    ids2, _ = cd.episodes_from_blocks(short, 6, record_capacity=3)
+    assert len(ids2) == int(bufs['ep_count'].clamp(max=2).sum())
+    wrapped = dict(bufs, ep_count=bufs['ep_count'] + 2)   # env 3: 5 episodes through 3 slots
+    with pytest.raises(ValueError, match='wrapped'):
+        cd.episodes_from_blocks(cd.pack_blocks(wrapped), 6)
 
 
 @pytest.mark.timeout(180)
