@@ -179,6 +179,7 @@ def pmc_provenance():
 
 
 # the sources of the rollout kernels (what roofline.traffic / issue_roofline describe); the value-network kernels live elsewhere
+RECORDS = 1  # episode records kept per env by the ORCA workload (ring capacity = records per boundary block)
 ROLLOUT_SOURCES = ('kd_order.h', 'orca_device.h', 'rollout_fused.h', 'scenario_device.h', 'scenario_wave.h', 'step_kernels.h')
 
 
@@ -554,9 +555,12 @@ def main():
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply.
     # boundary_records=1: every rollout launch leaves the shard's explorer.py:74-90 sums (bufs['summary']) and one record
     # block per env (bufs['blocks'], 56 B per env: the all-gather's input) behind — its own last workgroup, no extra kernel
-    bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=4,
+    # record_capacity = boundary_records: the shard's own in-kernel summary (single GPU) and the summary of the gathered blocks
+    # (sharded) are then the same statistic — over each env's most recent finished episode — whatever the world size
+    # (tests/test_bench_multirank.py compares the two through this script)
+    bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=RECORDS,
                              env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1],
-                             boundary_records=1)
+                             boundary_records=RECORDS)
 
     # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
     # inside the timed region costs more host time than a 20-step launch's enqueue
@@ -600,7 +604,7 @@ def main():
         summary of explorer.py:74-90 (one kernel): float64 [8] on the device"""
         if world == 1:
             return bufs['summary']
-        return eng.records_summary(cd.gather_blocks(bufs['blocks']), record_capacity=4)
+        return eng.records_summary(cd.gather_blocks(bufs['blocks']), record_capacity=RECORDS)
 
     run(args.preroll)
     gc.collect()  # (before the warm-up launches: see no_gc)

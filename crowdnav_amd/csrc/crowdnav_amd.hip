@@ -528,7 +528,8 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
                                (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else if (use_geom20 && e->maxl == 10 && !P.robot_unicycle && P.A == 21 && P.NC == 20 && P.E == 1 && P.threads == 64 &&
                P.orca.max_neighbors == 10 && P.kd) {
-        hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), e->smem, e->stream, e->P,
+        const size_t smem20 = CN_COMPACT20 != 0 ? cn::smem_bytes_compact(P.nA, P.pairs, P.A, P.E) : e->smem;
+        hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), smem20, e->stream, e->P,
                            (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else {
         CN_LAUNCH_ROLLOUT(e, grid_envs(e), e->P, (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);

@@ -550,7 +550,9 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
 //   lines [nA][kLineStride]; proj [nA][kLineStride] scratch rows; cand: (kWave / MAXL) * (MAXL - 1) float4 of scratch per WAVE
 //   (one row per agent of the pass); res [nA] in: (result, int bits: first infeasible line), out: result; todo [n_todo]: the
 //   agents that need the fallback, compacted (kWave / MAXL of them share a pass)
-template <int MAXL>
+//   GROUP_ROWS: proj holds one row of MAXL - 1 projected half-planes per lane GROUP of the wave (kWave / (MAXL - 1) rows: the
+//   compact LDS layout of the 20-human shard's kernel) instead of one row of kLineStride per agent
+template <int MAXL, bool GROUP_ROWS = false>
 __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* proj, float4* cand, const int* count,
                                                 const float4* sol, float4* res, const int* todo, int n_todo, int threads) {
     // W = MAXL - 1 lanes per agent: lane l holds half-plane l (projections and candidates exist for l < MAXL - 1 only), and the
@@ -586,7 +588,7 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
             my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
             tail = l == W - 1 && W < n;  // this lane also watches half-plane W
             last = tail ? lines[a * kLineStride + W] : make_float4(0.f, 0.f, 0.f, 0.f);
-            prow = proj + a * kLineStride;
+            prow = GROUP_ROWS ? proj + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * W : proj + a * kLineStride;
             rx = r0.x, ry = r0.y, r0z = r0.z, distance = 0.0f;
             icur = need ? begin : n;
         };

@@ -21,6 +21,11 @@ namespace cn {
 // (8 per 624-word block of the generator).
 __device__ __forceinline__ void wave_sync() { wave_lds_sync(); }
 
+// CN_GEN_PREFILTER (compile time, default on): the conservative float32 prefilter of the circle-crossing rejection loop
+#ifndef CN_GEN_PREFILTER
+#define CN_GEN_PREFILTER 1
+#endif
+
 struct WaveRng {
     uint32_t* key;   // [624] generator state (LDS)
     uint32_t* prev;  // [2][624] the states one and two blocks earlier, or NULL (kept only when the stream is handed on)
@@ -125,7 +130,20 @@ struct WaveScratch {
     double2 ppos[64];
     double2 pgoal[64];
     double prad[64];
+    float4 fpg[64];   // float32 copies (pos.x, pos.y, goal.x, goal.y) of the placed agents: the conservative prefilter
+    float fthr2[64];  // ... and, per placed agent, (min_dist - margin)^2 for the human being placed
 };
+
+// Conservative float32 prefilter of the circle-crossing rejection test (crowd_sim.py:159-175).  On the reference's own
+// geometry (20 humans on the 4 m circle) the last humans of a scenario are accepted once in 10^3..10^4 attempts: almost every
+// attempt lies DEEP inside some placed agent's exclusion disc, and deciding that does not need the float64 cos / sin and the
+// up to 38 exact float64 distance tests of the reference arithmetic.  An attempt is rejected here only if its float32
+// position is closer than min_dist - margin to a placed position or goal; the float32 position is within
+// 2e-6 (R + 2) m of the float64 one (angle: 27 of 53 random bits, rounded to 24: 5e-7 rad; cosf / sinf: 2 ulp; the sums
+// and differences: a few ulp of R + 1), and margin = 2e-5 (R + 2) m is ten times that — so every attempt rejected here is
+// rejected by the exact test, and a pass of 64 attempts without a survivor moves the cursor on exactly as the exact path
+// would.  Survivors (and the give-up rule) go through the exact path unchanged: same stream, same decisions, same bits.
+__device__ __forceinline__ float prefilter_margin(double R) { return 2.0e-5f * ((float)R + 2.0f); }
 
 // Builds agents [0, A) at pos/vel/goal/rv[base + agent] (vel may be NULL); returns np.random.random() calls consumed.
 // Must be called by all 64 lanes of a one-wave workgroup.
@@ -140,7 +158,9 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
     rng.seed(seed, lane);
     const int A = c.num_agents;
     const double R = c.circle_radius;
+    const float Rf = (float)R, margin = prefilter_margin(R);
     if (lane == 0) {
+        s.fpg[0] = make_float4(0.0f, -Rf, 0.0f, Rf);
         s.ppos[0] = make_double2(0.0, -R);
         s.pgoal[0] = make_double2(0.0, R);
         s.prad[0] = c.robot_radius;
@@ -159,12 +179,37 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
             rng.cursor += 4;
         }
         unsigned long long attempts = 0;
+        const float vpf = (float)v_pref;
         if (c.rule == 0) {
             // circle crossing: attempt = (angle, px_noise, py_noise) = 6 words; reject if within min_dist of any placed
             // agent's position or goal (crowd_sim.py:159-175)
+            if (lane < i) {  // this human's thresholds against everybody placed so far
+                const float t = (float)(radius + s.prad[lane] + c.discomfort_dist) - margin;
+                s.fthr2[lane] = t > 0.0f ? t * t : 0.0f;
+            }
+            wave_sync();
             for (;;) {
                 rng.ensure(6 * 64, lane);
                 const uint32_t at = rng.cursor + 6u * lane;
+                if (CN_GEN_PREFILTER) {
+                    const float frac = (float)(rng.word(at) >> 5) * 0x1p-27f;
+                    float sn, cs;
+                    sincosf(frac * 6.2831855f, &sn, &cs);
+                    const float fx = Rf * cs + ((float)(rng.word(at + 2) >> 5) * 0x1p-27f - 0.5f) * vpf;
+                    const float fy = Rf * sn + ((float)(rng.word(at + 4) >> 5) * 0x1p-27f - 0.5f) * vpf;
+                    bool inside = false;
+                    for (int k = 0; k < i; ++k) {
+                        const float4 q = s.fpg[k];
+                        const float t2 = s.fthr2[k];
+                        const float ax = fx - q.x, ay = fy - q.y, bx = fx - q.z, by = fy - q.w;
+                        inside = inside | (ax * ax + ay * ay < t2) | (bx * bx + by * by < t2);
+                    }
+                    if (__ballot(!inside) == 0ull && attempts + 64 < c.max_attempts) {  // 64 certain rejections
+                        attempts += 64;
+                        rng.cursor += 6u * 64;
+                        continue;
+                    }
+                }
                 const double angle = rng.random_at(at) * kPi * 2;
                 const double nx = (rng.random_at(at + 2) - 0.5) * v_pref;
                 const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
@@ -190,6 +235,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
                     if (lane == first) {
                         s.ppos[i] = make_double2(x, y);
                         s.pgoal[i] = make_double2(-x, -y);
+                        s.fpg[i] = make_float4((float)x, (float)y, (float)-x, (float)-y);
                     }
                     rng.cursor += 6u * (first + 1);
                     break;

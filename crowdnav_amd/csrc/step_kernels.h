@@ -158,7 +158,23 @@ __host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl, int A 
            (size_t)pairs * 8 + 64 + 8 + 16 + 16 + sizeof(double) * kMaxDiscount + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
 }
 
-template <int MAXL>
+// COMPACT: the LDS layout of the 20-human shard's kernel (rollout_kernel<10, false, true, true>: one env per one-wave
+// workgroup, lazy fallback, two-sweep pair phase).  18.6 KB per workgroup allowed 8 workgroups = 2 waves per SIMD whatever the
+// register count; a third resident wave needs <= 12.8 KB (160 KB in 1280-byte granules: 10 granules x 12 workgroups).  What goes:
+//   disc   2048 B  the discount table: one global load per step on the robot lane, issued a step ahead of its use
+//   proj   3696 -> 1008 B  rows of the lazy fallback belong to the 7 lane groups of a pass, not to the 21 agents (the `kept`
+//                  table of the two-sweep pair phase, 840 B, shares them as before)
+//   act     336 -> 16 B    one robot per workgroup
+//   pinfo  1680 -> 840 B   16-bit pair descriptors (the candidate slot is p - 20 q)
+constexpr int kLazyRows = (kWave / (kMaxNb - 1)) * (kMaxNb - 1);  // 63 float4: 7 groups x 9 projected half-planes
+__host__ __device__ inline size_t smem_bytes_compact(int nA, int pairs, int A, int E) {
+    size_t n = (size_t)16 * (nA + 1) + 16 * nA + 16 * E + (size_t)16 * kLineStride * nA + 16 * kLazyRows;
+    n += (size_t)nA * (16 + 16 + 8 + 8 + 4 + 4 + 4 + 4) + 4 * (nA + 1) + 16;
+    n += (size_t)pairs * 4 + (size_t)pairs * 2 + 16 + 16 + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
+    return n;
+}
+
+template <int MAXL, bool COMPACT = false>
 __device__ __forceinline__ Smem carve(const Params& P) {
     extern __shared__ double2 smem_raw[];
     Smem s;
@@ -166,9 +182,9 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     const int nA = P.nA;
     s.kin = reinterpret_cast<float4*>(p), p += 16 * (nA + 1);
     s.posd = reinterpret_cast<double2*>(p), p += 16 * nA;
-    s.act = reinterpret_cast<double2*>(p), p += 16 * nA;
+    s.act = reinterpret_cast<double2*>(p), p += 16 * (COMPACT ? P.E : nA);
     s.lines = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
-    s.proj = reinterpret_cast<float4*>(p), p += proj_bytes(nA, MAXL);
+    s.proj = reinterpret_cast<float4*>(p), p += COMPACT ? (size_t)16 * kLazyRows : proj_bytes(nA, MAXL);
     s.cand2 = s.cand3 = nullptr;
     if (MAXL == 5) {
         s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
@@ -188,10 +204,10 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.todo = reinterpret_cast<int*>(p), p += 4 * (nA + 1);
     p += (16 - (reinterpret_cast<size_t>(p) & 15)) & 15;  // rows of d2 are read as float4 when NC is a multiple of 4
     s.d2 = reinterpret_cast<float*>(p), p += 4 * P.pairs;
-    s.pinfo = reinterpret_cast<int*>(p), p += 4 * P.pairs;
+    s.pinfo = reinterpret_cast<int*>(p), p += (COMPACT ? 2 : 4) * P.pairs;
     s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
     {
-        char* q = reinterpret_cast<char*>(s.disc + kMaxDiscount);
+        char* q = reinterpret_cast<char*>(s.disc + (COMPACT ? 0 : kMaxDiscount));
         q += (16 - (reinterpret_cast<size_t>(q) & 15)) & 15;
         s.kd_off = (uint32_t)(q - reinterpret_cast<char*>(smem_raw));
     }
@@ -243,6 +259,17 @@ __device__ __forceinline__ void load_agent(const StateView& S, size_t gi, AgentR
 // ORCA.predict adds the others to its rvo2 sim: the other humans by index, then the robot if it is visible
 // (crowd_sim.py:325-327, orca.py:102-104); the robot's own sim holds every human.
 //   bits 0-7 agent lane, 8-15 lane of the candidate, 16-23 candidate slot, 24 pair exists, 25 agent is a robot
+// COMPACT: 16 bits per pair — bits 0-4 agent lane, 5-9 lane of the candidate, 10 pair exists, 11 agent is a robot; the
+// candidate slot is p - NC * agent lane.  pair_info() hands out the 32-bit form either way.
+template <bool COMPACT>
+__device__ __forceinline__ int pair_info(const Params& P, const Smem& s, int p) {
+    if (!COMPACT) return s.pinfo[p];
+    const int w = reinterpret_cast<const uint16_t*>(s.pinfo)[p];
+    const int q = w & 31;
+    return q | (((w >> 5) & 31) << 8) | ((p - q * P.NC) << 16) | (((w >> 10) & 3) << 24);
+}
+
+template <bool COMPACT = false>
 __device__ __forceinline__ void build_pairs(const Params& P, const Smem& s) {
     for (int p = threadIdx.x; p < P.pairs; p += P.threads) {
         const int q = p / P.NC;
@@ -260,7 +287,10 @@ __device__ __forceinline__ void build_pairs(const Params& P, const Smem& s) {
                 exists = exists && P.robot_visible;
             }
         }
-        s.pinfo[p] = q | ((el * P.A + j) << 8) | (c << 16) | (exists ? 1 << 24 : 0) | (a == 0 ? 1 << 25 : 0);
+        if (COMPACT)
+            reinterpret_cast<uint16_t*>(s.pinfo)[p] = (uint16_t)(q | ((el * P.A + j) << 5) | (exists ? 1 << 10 : 0) | (a == 0 ? 1 << 11 : 0));
+        else
+            s.pinfo[p] = q | ((el * P.A + j) << 8) | (c << 16) | (exists ? 1 << 24 : 0) | (a == 0 ? 1 << 25 : 0);
     }
 }
 
@@ -586,6 +616,7 @@ __device__ __forceinline__ void pair_sweep2(const Params& P, const Smem& s) {
 // their candidates again, ties by visiting order.  (Tried as a real call, __attribute__((noinline)): the mere presence of a call
 // cost the 20-human rollout 4-5 % on every step — 62.3 vs 59.4 M env-steps/s instrumented — so it is inlined, and the few
 // registers the rare path spills go to scratch.)  All threads of the workgroup (barriers inside).
+template <bool COMPACT = false>
 __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, const Lane& L, int kd_gen, int two_sweeps) {
     const KdSmem k = kd_view(P, s);
     const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
@@ -593,7 +624,7 @@ __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, 
     block_sync(P);
     int* kept = reinterpret_cast<int*>(s.proj);
     for (int p = L.lane; p < P.pairs; p += P.threads) {
-        const int info = s.pinfo[p];
+        const int info = pair_info<COMPACT>(P, s, p);
         const int q = info & 0xff, c = (info >> 16) & 0xff, ol = (info >> 8) & 0xff;
         if (k.tie[q] == 0) continue;
         const int qb = q / P.A * P.A;
@@ -604,7 +635,7 @@ __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, 
         int rank = 0;
         for (int kk = 0; kk < P.NC; ++kk) {
             const float v = row[kk];
-            const int visit = vq[((s.pinfo[p - c + kk] >> 8) & 0xff) - qb];
+            const int visit = vq[((pair_info<COMPACT>(P, s, p - c + kk) >> 8) & 0xff) - qb];
             rank += (v < range_sq ? 1 : 0) & ((v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (visit < my_visit ? 1 : 0)));
         }
         if (mine < range_sq && rank < P.orca.max_neighbors) {
@@ -679,7 +710,7 @@ struct PhaseClock {};
 
 // KD (compile time): the instantiation carries the kd-tree bookkeeping of simulators with more than 10 agents (kd_order.h);
 // crowds of at most 9 humans run the one without it.
-template <int MAXL, bool KD>
+template <int MAXL, bool KD, bool COMPACT = false>
 __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, const Lane& L, const AgentRegs& r,
                                             float robot_max_speed, bool solve, float& out_vx, float& out_vy,
                                             PhaseClock* clk = nullptr) {
@@ -742,7 +773,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
 
     // pairs-1: squared distances, self.pos - other.pos (Appendix A.2)
     for (int p = L.lane; p < P.pairs; p += P.threads) {
-        const int info = s.pinfo[p];
+        const int info = pair_info<COMPACT>(P, s, p);
         const float4 me = s.kin[info & 0xff];
         const float4 ot = s.kin[(info >> 8) & 0xff];
         const float dx = me.x - ot.x, dy = me.y - ot.y;
@@ -772,7 +803,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         int* kept = reinterpret_cast<int*>(s.proj);
         int* const claimed = KD ? reinterpret_cast<int*>(kd_view(P, s).dnext) : nullptr;
         for (int p = L.lane; p < P.pairs; p += P.threads) {
-            const int info = s.pinfo[p];
+            const int info = pair_info<COMPACT>(P, s, p);
             const int c = (info >> 16) & 0xff;
             const float mine = s.d2[p];
             const float4* row4 = reinterpret_cast<const float4*>(s.d2 + (p - c));
@@ -802,7 +833,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             pair_sweep2<false>(P, s);
     } else
     for (int p = L.lane; p < P.pairs; p += P.threads) {
-        const int info = s.pinfo[p];
+        const int info = pair_info<COMPACT>(P, s, p);
         const int q = info & 0xff, c = (info >> 16) & 0xff;
         const float mine = s.d2[p];
         const float* row = s.d2 + (p - c);
@@ -830,7 +861,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     if (KD) {
         const KdSmem k = kd_view(P, s);
         const bool my_tie = L.lane < P.nA && k.tie[L.lane] != 0;
-        if (block_sync_or(P, my_tie ? 1 : 0)) kd_resolve_ties(P, s, L, kd_gen, two_sweeps ? 1 : 0);
+        if (block_sync_or(P, my_tie ? 1 : 0)) kd_resolve_ties<COMPACT>(P, s, L, kd_gen, two_sweeps ? 1 : 0);
     }
     CN_TICK(clk, 2);
 
@@ -1021,8 +1052,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 block_sync(P);
                 // (its candidate rows — 7 agents x 9 float4 per wave — live in d2, free after the pair phases: enough for one wave)
                 if (kLazy3 && P.threads == kWave && P.pairs * 4 >= (kWave / (MAXL - 1)) * (MAXL - 1) * 16)
-                    lp_relaxed_lazy<MAXL>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
-                                          s.todo[P.nA], P.threads);
+                    lp_relaxed_lazy<MAXL, COMPACT>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
+                                                   s.todo[P.nA], P.threads);
                 else
                     lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
                 block_sync(P);
@@ -1055,14 +1086,14 @@ __device__ __forceinline__ double python_fmod(double x, double y) {  // python's
 
 // UNI (compile time): the robot may be a unicycle.  The holonomic instantiation carries none of that code — it sits
 // inside the fused rollout loop, where 20 extra VGPRs and a few dead branches cost 7 % (712 -> 665 M env-steps/s).
-template <int MAXL, bool UNI, bool KD>
+template <int MAXL, bool UNI, bool KD, bool COMPACT = false>
 __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
                                           double& gtime, float robot_max_speed, const double* ext_action,
                                           int update, StepResult& res, double& new_vx, double& new_vy,
                                           double* theta_io = nullptr, PhaseClock* clk = nullptr) {
     (void)clk;
     float ovx, ovy;
-    orca_phases<MAXL, KD>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
+    orca_phases<MAXL, KD, COMPACT>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
     new_vx = ovx;
     new_vy = ovy;
     // unicycle robot (ActionRot v, r): the collision test uses v (cos, sin)(r + theta) (crowd_sim.py:339-341), the
@@ -1682,8 +1713,16 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
 #ifndef CN_MAXL10_WAVES
 #define CN_MAXL10_WAVES 1
 #endif
+// CN_COMPACT20 (compile time, default on): the 20-human shard's kernel uses the compact LDS layout (carve<.., COMPACT>)
+#ifndef CN_COMPACT20
+#define CN_COMPACT20 1
+#endif
+// CN_GEOM20_WAVES: resident waves per SIMD the shard's kernel (HEADLINE instantiation of rollout_kernel<10>) is compiled for
+#ifndef CN_GEOM20_WAVES
+#define CN_GEOM20_WAVES 1
+#endif
 template <int MAXL, bool UNI, bool HEADLINE = false, bool KD = false>
-__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
+__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVES : CN_MAXL10_WAVES) : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                             RolloutView R, int n_steps, const double* ext_action) {
     // The ~20 state pointers are needed before and after the step loop and when an episode ends, never inside a step: they
     // are re-read from the engine's device copy of the StateView there (scalar loads) instead of holding 40 SGPRs — spilled
@@ -1710,7 +1749,8 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         pin(P.dt), pin(P.time_limit), pin(P.success_reward), pin(P.collision_penalty), pin(P.discomfort_dist);
         pin(P.discomfort_factor), pin(P.human_safety);
     }
-    const Smem s = carve<MAXL>(P);
+    constexpr bool COMPACT = HEADLINE && MAXL == 10 && CN_COMPACT20 != 0;  // the shard kernel's LDS layout (carve)
+    const Smem s = carve<MAXL, COMPACT>(P);
     const Lane L = lane_of(P);
     AgentRegs r = {};
     float robot_max_speed = 0.0f;
@@ -1725,7 +1765,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         if (KD) kd_load(P, S, s, L);
         if (robot) theta = S.theta[L.env];
     }
-    build_pairs(P, s);
+    build_pairs<COMPACT>(P, s);
     if (robot) {
         const StateView S = *Sd;
         const cn_rollout_io io = *R.io;
@@ -1752,8 +1792,10 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         theta = 1.5707963267948966;
     }
     unsigned int transitions = 0;
-    for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
+    if (!COMPACT)
+        for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
     __syncthreads();
+    const int disc_len = R.discount_len < kMaxDiscount ? R.discount_len : kMaxDiscount;
 
 #ifdef CN_PHASE_TIMING
     PhaseClock clock = {};
@@ -1770,14 +1812,18 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? CN_MAXL10_WAVES : 1)) void
         asm volatile("" : "+v"(Ls.lane), "+v"(Ls.a), "+v"(Ls.ebase));
         Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env is running
 
+        // COMPACT: no LDS copy of the discount table — this step's factor is requested here, a whole transition before its use
+        double disc_now = 0.0;
+        if (COMPACT && robot && cur_steps < disc_len) disc_now = R.discount[cur_steps];
+
         StepResult res;
         double nvx, nvy;
-        step_core<MAXL, UNI, KD>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
+        step_core<MAXL, UNI, KD, COMPACT>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
 
         if (robot && state == kRunning) {
             int next_flag = 1;
             ++transitions;
-            const double disc = cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0;
+            const double disc = COMPACT ? disc_now : (cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0);
             cur_return = cur_return + disc * res.reward;  // python sum(): left to right
             ++cur_steps;
             if (res.info == CN_DANGER) {

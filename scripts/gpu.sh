@@ -1,5 +1,5 @@
 # The ONE GPU-box runner: `gpurun -- 'bash scripts/gpu.sh <stage> [<stage> ...]'`.  Stages write under gpurun_out/<tag>/
-# (tag = $CN_TAG, default r03); summaries that matter are copied into profiles/ by hand.  Experiment builds live under
+# (tag = $CN_TAG, default r04); summaries that matter are copied into profiles/ by hand.  Experiment builds live under
 # build/exp/ (make -C crowdnav_amd/csrc exp NAME=.. DEFS=..) and are selected with CROWDNAV_AMD_LIB.
 #   tests [pytest args]   pytest -m gpu (whole suite, or the files given in $CN_TESTS)
 #   smoke                 __graft_entry__.smoke()
@@ -10,10 +10,10 @@
 #   sarl                  cn_sarl_select timing (scripts/sarl_bench.py) for the in-tree library and build/exp/lib_ab_sarl*.so
 #   trace                 rocprofv3 --kernel-trace --stats of both bench shapes and the SARL decision
 #   pmc                   separate rocprofv3 --pmc passes: FETCH / WRITE / SQ for the fused kernel (both shapes), rollout_kernel<10>,
-#                         sarl_reg_kernel<4> and <16> (MFMA busy) -> r03_traffic.json
+#                         sarl_reg_kernel<4> and <16> (MFMA busy) -> ${TAG}_traffic.json
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp
 shopt -s nullglob
-REPO=$GRAFT_REPO_ROOT; TAG=${CN_TAG:-r03}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; cd $REPO
+REPO=$GRAFT_REPO_ROOT; TAG=${CN_TAG:-r04}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; cd $REPO
 line() { timeout 20 python scripts/bench_line.py "$1"; }
 bench() { # name, [VAR=val ...] -- args
   name=$1; shift; envs=(); while [ "$1" != "--" ] && [ $# -gt 0 ]; do envs+=("$1"); shift; done; shift
@@ -94,12 +94,22 @@ pmc)
     prof pmc_${v}_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${v}_fetch -o p -- python $REPO/scripts/sarl_bench.py --iters 3 $a
     prof pmc_${v}_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${v}_write -o p -- python $REPO/scripts/sarl_bench.py --iters 3 $a
   done
-  rm -f $OUT/r03_traffic.json
-  P="python scripts/pmc_to_traffic.py $OUT/r03_traffic.json"
+  rm -f $OUT/${TAG}_traffic.json
+  P="python scripts/pmc_to_traffic.py $OUT/${TAG}_traffic.json"
   $P 4096 5 1000 rollout_fused_kernel tail $OUT/pmc_default_fetch $OUT/pmc_default_write $OUT/pmc_default_sq1 $OUT/pmc_default_sq2 > /dev/null
   $P 4096 5 20 rollout_fused_kernel 2 $OUT/pmc_driver_fetch $OUT/pmc_driver_write $OUT/pmc_driver_sq1 $OUT/pmc_driver_sq2 > /dev/null
   CN_PMC_RADIUS=12 $P 4096 20 500 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 > /dev/null
   python scripts/prof_summary.py $OUT/pmc_sarl_mfma | tail -n 4; python scripts/prof_summary.py $OUT/pmc_om_sarl_mfma | tail -n 4
-  head -c 1500 $OUT/r03_traffic.json ;;
+  head -c 1500 $OUT/${TAG}_traffic.json ;;
+h20ab)
+  # the 20-human shard's kernel and the scenario generator: every build/exp/lib_ab_*.so against the in-tree library
+  [ -x $REPO/build/exp/lds_granule ] && $REPO/build/exp/lds_granule | tee $OUT/lds_granule.txt
+  for lib in "" $REPO/build/exp/lib_ab_*.so; do
+    n=$(basename "${lib:-intree}" .so)
+    bench h20_${n}_r12 CROWDNAV_AMD_LIB=$lib -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1500 --warmup 500 --chunk 500
+    bench h20_${n}_r4_async CROWDNAV_AMD_LIB=$lib -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 2000 --warmup 500 --chunk 1000 --preroll 100 --seed-base 1000 --seed-mod 1024 --async-fill
+    ( export CROWDNAV_AMD_LIB=$lib; timeout 120 python scripts/reset_probe.py 22 2>&1 | grep "reset ms" | sed "s/^/$n: /" | tee -a $OUT/reset_probe.txt )
+  done
+  for envs in ${CN_H20_ENVS:-}; do bench h20_intree_r12_envs$envs -- --no-cpu-baseline --humans 20 --circle-radius 12 --envs $envs --steps 1500 --warmup 500 --chunk 500; done ;;
 *) echo "unknown stage $stage" ;;
 esac; done

@@ -88,15 +88,16 @@ def test_a_dying_rank_ends_the_job_non_zero():
     """SIGKILL one rank while the job runs: the parent must terminate the other rank (it would wait in a collective forever)
     and return non-zero well inside the timeout."""
     import psutil
-    p = subprocess.Popen([sys.executable, BENCH, '--gpus', '2', '--steps', '400000', '--warmup', '5', '--no-cpu-baseline',
-                          '--no-secondary'], env=_env(**SHARED), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # 10^8 steps in launches of 10^5: minutes of work for two ranks sharing one GPU (400 000 steps were over in two seconds)
+    p = subprocess.Popen([sys.executable, BENCH, '--gpus', '2', '--steps', '100000000', '--chunk', '100000', '--warmup', '5',
+                          '--no-cpu-baseline', '--no-secondary'], env=_env(**SHARED), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         kids, t0 = [], time.time()
         while len(kids) < 2 and time.time() - t0 < 120:
             kids = psutil.Process(p.pid).children()
             time.sleep(0.2)
         assert len(kids) == 2, 'bench.py --gpus 2 did not start two ranks'
-        time.sleep(20.0)  # let them get past the imports and into the run (400 000 steps: several minutes of work)
+        time.sleep(20.0)  # let them get past the imports and into the run (several minutes of work)
         assert p.poll() is None, 'job ended before a rank was killed: %s' % p.stderr.read()[-2000:]
         kids[1].kill()
         rc = p.wait(timeout=120)
