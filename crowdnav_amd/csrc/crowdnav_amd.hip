@@ -96,6 +96,14 @@ int cn_create(const cn_config* c, cn_engine** out) {
     if (P.ring_depth < 1) P.ring_depth = 1;
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     P.kd = P.A > cn::kKdLeaf ? 1 : 0;  // a simulator of more than 10 agents splits its kd-tree: visiting order matters at ties
+    P.sched = -1;
+    e->sched_min = env_int("CROWDNAV_AMD_SCHED_MIN_STEPS", CN_GEOM20_WAVES == 3 ? 48 : (1 << 30));
+    e->sched_force = env_int("CROWDNAV_AMD_SCHED_FORCE", 0) != 0;
+    {
+        hipDeviceProp_t prop;
+        const bool ok = hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0;
+        e->sched_slots = 12 * (ok ? prop.multiProcessorCount : 256);
+    }
     P.kdl = cn::kd_layout(P.nA, P.A, P.E);
     e->smem = cn::smem_bytes(P.nA, P.pairs, e->maxl, P.A, P.E);
     e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", 0) != 0;
@@ -529,8 +537,29 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     } else if (use_geom20 && e->maxl == 10 && !P.robot_unicycle && P.A == 21 && P.NC == 20 && P.E == 1 && P.threads == 64 &&
                P.orca.max_neighbors == 10 && P.kd) {
         const size_t smem20 = CN_COMPACT20 != 0 ? cn::smem_bytes_compact(P.nA, P.pairs, P.A, P.E) : e->smem;
-        hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), smem20, e->stream, e->P,
-                           (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
+        // Three resident waves per SIMD (CN_GEOM20_WAVES): 3072 one-wave workgroups fill the chip, so B = 4096 envs would run as
+        // a full round plus a third of one.  A call of 3 q + r steps becomes one launch of r steps over all envs (if r > 0) and
+        // FOUR launches of q steps over 3 B / 4 workgroups each, sub-launch k leaving out env 3 - k of every group of four
+        // (step_kernels.h: Params::sched): every env makes its steps in order, every launch is one round.
+        // Worth it when it saves rounds: with S = 12 workgroups x CUs resident, a plain launch takes ceil(B / S) rounds of
+        // n steps, the schedule 4 ceil(0.75 B / S) rounds of n / 3 (B = 4096 on 256 CUs: 2 vs 1.33; B = 3072: 1 vs 1.33 - plain).
+        // CROWDNAV_AMD_SCHED_MIN_STEPS / CROWDNAV_AMD_SCHED_FORCE (read by cn_create): shortest call that is split; split
+        // whatever the round count (the parity tests run the schedule on a handful of envs).
+        cn::Params Pk = e->P;
+        Pk.sched = -1;
+        const int slots = e->sched_slots;
+        const int rounds_plain = (P.B + slots - 1) / slots, rounds_sched = (P.B / 4 * 3 + slots - 1) / slots;
+        const bool sched = P.B % 4 == 0 && n_steps >= e->sched_min && action == nullptr &&
+                           (e->sched_force || 4 * rounds_sched < 3 * rounds_plain);
+        const int q = sched ? n_steps / 3 : 0, rest = n_steps - 3 * q;
+        if (rest > 0)
+            hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), smem20, e->stream, Pk,
+                               (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, rest, action);
+        for (int k = 0; k < 4 && q > 0; ++k) {
+            Pk.sched = k;
+            hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(P.B / 4 * 3), dim3(64), smem20, e->stream, Pk,
+                               (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, q, action);
+        }
     } else {
         CN_LAUNCH_ROLLOUT(e, grid_envs(e), e->P, (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     }
@@ -647,6 +676,7 @@ extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cn::cn_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
         unsigned long long zero[16] = {};
+        zero[13] = ~0ull;  // the fastest wave's total (atomicMin)
         if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_phase_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;

@@ -72,6 +72,8 @@ struct cn_engine {
     bool mt_in_lds;    // lane-per-scenario generators keep their MT19937 state in LDS instead of HBM
     bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
     size_t smem;       // dynamic LDS bytes per workgroup
+    int sched_min, sched_slots;  // the 20-human shard kernel's 3-of-4 env schedule (launch_rollout): shortest call split, resident workgroups
+    bool sched_force;
     // Device memory comes from a few large slabs, not one hipMalloc per buffer: an engine has ~60 device buffers, most of them a
     // few KiB; one 32 MiB slab (plus one per buffer larger than that) is 2-4 mappings to create and - each hipFree being a device
     // synchronisation - 2-4 to tear down, and cn_sarl_configure can roll a failed configuration back to a mark.

@@ -34,6 +34,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// threadIdx.x as a value the optimiser cannot see through: everything a phase derives from it (lane group, slot, LDS row
+// addresses) is recomputed where the phase runs instead of being hoisted out of the rollout kernels' step loop and held in
+// VGPRs across it (the 20-human shard's kernel needs every register it can get for its third resident wave).
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 struct OrcaParams {
     float neighbor_dist;
     float inv_time_horizon;  // 1.0f / timeHorizon
@@ -563,12 +572,13 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
     // not the sum over passes of each pass's slowest agent.
     constexpr int W = MAXL - 1, G = kWave / W;
     constexpr unsigned kField = (1u << W) - 1u;
-    const int wl = threadIdx.x & (kWave - 1);
+    const int tid = opaque_tid();
+    const int wl = tid & (kWave - 1);
     const int g = wl / W, l = wl - g * W;
     const int gbase = g * W;
     const int waves = (threads + kWave - 1) / kWave;
-    float4* const crow = cand + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * W;
-    for (int chunk = threadIdx.x / kWave; chunk * G < n_todo; chunk += waves) {
+    float4* const crow = cand + ((tid / kWave) * G + (g < G ? g : 0)) * W;
+    for (int chunk = tid / kWave; chunk * G < n_todo; chunk += waves) {
         const int hand_end = waves == 1 ? n_todo : (chunk * G + G < n_todo ? chunk * G + G : n_todo);  // agents this wave works off
         int next = chunk * G + G;                                                                     // ... the next one to hand out
         // per-agent state of the lane's group
@@ -588,7 +598,7 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
             my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
             tail = l == W - 1 && W < n;  // this lane also watches half-plane W
             last = tail ? lines[a * kLineStride + W] : make_float4(0.f, 0.f, 0.f, 0.f);
-            prow = GROUP_ROWS ? proj + ((threadIdx.x / kWave) * G + (g < G ? g : 0)) * W : proj + a * kLineStride;
+            prow = GROUP_ROWS ? proj + ((tid / kWave) * G + (g < G ? g : 0)) * W : proj + a * kLineStride;
             rx = r0.x, ry = r0.y, r0z = r0.z, distance = 0.0f;
             icur = need ? begin : n;
         };

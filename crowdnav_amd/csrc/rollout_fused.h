@@ -76,6 +76,14 @@ __device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max
 #define CN_FUSED_SYNC() wave_lds_sync()
 #endif
 
+// CN_FUSED_PRIO (compile time): a launch ends with its slowest wave, and in the short launches of the driver's shape (20
+// steps) that is a wave whose env sits in a jam and takes the 3-D fallback every step — 1.8 x the latency of a step without
+// it — while the wave it shares the SIMD with has slack.  1: the wave raises its issue priority (s_setprio) for the fallback
+// block; 2: it keeps the raised priority through the next step as well (a jam lasts many steps).  0: off.
+#ifndef CN_FUSED_PRIO
+#define CN_FUSED_PRIO 2
+#endif
+
 template <bool HEADLINE>
 __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                               RolloutView R, int n_steps, const double* ext_action) {
@@ -156,6 +164,14 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     stage_agent(P, s, L, r, c_hsafety);
     CN_FUSED_SYNC();
 
+#ifdef CN_EXP_DESYNC
+    {   // experiment: the waves in odd slots of a SIMD start the step loop CN_EXP_DESYNC x 64 clocks late, so that the two waves
+        // of a SIMD are not in the same phase (same stalls, same unit) from the first step on
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (hw & 1u) __builtin_amdgcn_s_sleep(CN_EXP_DESYNC);
+    }
+#endif
 #ifdef CN_PHASE_TIMING
     PhaseClock clock = {};
     PhaseClock* clk = &clock;
@@ -233,7 +249,9 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
 #ifdef CN_PHASE_TIMING
         clock.acc[9] += __popcll(nm);
 #endif
+        if (CN_FUSED_PRIO == 2 && nm == 0ull) __builtin_amdgcn_s_setprio(0);
         if (nm != 0ull) {  // wave-uniform: some agent of this wave was infeasible
+            if (CN_FUSED_PRIO != 0) __builtin_amdgcn_s_setprio(3);
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int n_todo = __popcll(nm);
             if (n_todo * kPairs <= kWave) {
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             if (need)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
                          fail, s.sol[L.lane].z, rx, ry);
+            if (CN_FUSED_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         }
         CN_TICK(clk, 8);
 
@@ -390,7 +409,13 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     }
 #ifdef CN_PHASE_TIMING
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        for (int k = 0; k < 10; ++k) atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
+        unsigned long long total = 0ull;
+        for (int k = 0; k < 10; ++k) {
+            atomicAdd(&cn_phase_cycles[k], clock.acc[k]);
+            if (k != 9) total += clock.acc[k];
+        }
+        atomicMax(&cn_phase_cycles[14], total);  // the slowest wave's step loop (what a launch waits for) ...
+        atomicMin(&cn_phase_cycles[13], total);  // ... and the fastest one's (reset to ~0ull by the probe script)
         atomicAdd(&cn_phase_cycles[15], 1ull);
     }
 #endif

@@ -53,6 +53,7 @@ struct Params {
     int robot_visible, robot_orca;
     int robot_unicycle;  // external robot actions are ActionRot(v, r) (agent.py:115-135)
     int async_fill;      // CN_FLAG_ASYNC_SCENARIO_FILL: ring slots are published one by one (StateView::ring_ready)
+    int sched;           // the 20-human shard's kernel: sub-launch 0..3 of the 3-of-4 env schedule (launch_rollout), -1 = all envs
     int kd;              // A > 10: some rvo2 simulator of an env holds more than 10 agents and splits its kd-tree (kd_order.h)
     KdLayout kdl;        // ... and where its bookkeeping lives in LDS (offsets from Smem::kd_off)
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
@@ -131,8 +132,11 @@ struct Smem {
     int* todo;        // [nA + 1] agents that need the 3-D fallback, compacted; [nA] = how many
     double* disc;     // [kMaxDiscount] discount table gamma^(t dt v_pref) (rollout kernel only)
     uint32_t kd_off;  // byte offset (from the start of LDS) of the kd-tree region, simulators of more than 10 agents: kd_view
+    double2* goal2;   // [nA] COMPACT only: the agent's goal ...
+    double* vpref;    // [nA] ... and preferred speed: per-episode constants the step loop does not hold in registers
 };
 
+constexpr int kCompactScratchDoubles = 16;  // COMPACT: Smem::disc holds the step parameters and the robot lane's bookkeeping instead
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
 // CN_CAND_LP3_10 (compile time, default off): the 10-half-plane kernels run the 3-D fallback in candidate form like the
 // 5-half-plane ones (lp3_project / lp_line_candidate on (agent, i, j) lanes, then lp3_scan_n per agent) instead of
@@ -166,11 +170,17 @@ __host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl, int A 
 //                  table of the two-sweep pair phase, 840 B, shares them as before)
 //   act     336 -> 16 B    one robot per workgroup
 //   pinfo  1680 -> 840 B   16-bit pair descriptors (the candidate slot is p - 20 q)
+//   kd visit order + traversal stacks  1008 -> 0 B   needed only while exact distance ties are resolved, when `lines` holds
+//                  nothing that is not recomputed afterwards (kd_resolve_ties re-runs the half-plane sweep): kd_scratch_view
+// and what comes in: the step parameters, the robot lane's episode bookkeeping (128 B), the agents' goals and preferred
+// speeds (504 B) — values the step loop would otherwise hold in VGPRs across every phase (third resident wave per SIMD).
 constexpr int kLazyRows = (kWave / (kMaxNb - 1)) * (kMaxNb - 1);  // 63 float4: 7 groups x 9 projected half-planes
 __host__ __device__ inline size_t smem_bytes_compact(int nA, int pairs, int A, int E) {
     size_t n = (size_t)16 * (nA + 1) + 16 * nA + 16 * E + (size_t)16 * kLineStride * nA + 16 * kLazyRows;
-    n += (size_t)nA * (16 + 16 + 8 + 8 + 4 + 4 + 4 + 4) + 4 * (nA + 1) + 16;
-    n += (size_t)pairs * 4 + (size_t)pairs * 2 + 16 + 16 + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
+    n += (size_t)nA * (16 + 16 + 16 + 8 + 8 + 8 + 4 + 4 + 4 + 4) + 4 * (nA + 1) + 16;
+    n += (size_t)pairs * 4 + (size_t)pairs * 2 + 16 + 16 + 8 * kCompactScratchDoubles + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
+    // the traversal scratch of the tie resolver (visit order + stacks, the LAST two arrays of the kd region) lives in `lines`
+    if (A > kKdLeaf) n -= (size_t)nA * kd_row_bytes(A) + (size_t)nA * (kd_max_nodes(A) + 1) * 2;
     return n;
 }
 
@@ -195,6 +205,11 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     }
     s.sol = reinterpret_cast<float4*>(p), p += 16 * nA;
     s.res = reinterpret_cast<float4*>(p), p += 16 * nA;
+    s.goal2 = nullptr, s.vpref = nullptr;
+    if (COMPACT) {
+        s.goal2 = reinterpret_cast<double2*>(p), p += 16 * nA;
+        s.vpref = reinterpret_cast<double*>(p), p += 8 * nA;
+    }
     s.rad = reinterpret_cast<double*>(p), p += 8 * nA;
     s.closest = reinterpret_cast<double*>(p), p += 8 * nA;
     s.hview = reinterpret_cast<float*>(p), p += 4 * nA;
@@ -207,12 +222,30 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.pinfo = reinterpret_cast<int*>(p), p += (COMPACT ? 2 : 4) * P.pairs;
     s.disc = reinterpret_cast<double*>(p + ((8 - (reinterpret_cast<size_t>(p) & 7)) & 7));
     {
-        char* q = reinterpret_cast<char*>(s.disc + (COMPACT ? 0 : kMaxDiscount));
+        char* q = reinterpret_cast<char*>(s.disc + (COMPACT ? kCompactScratchDoubles : kMaxDiscount));
         q += (16 - (reinterpret_cast<size_t>(q) & 15)) & 15;
         s.kd_off = (uint32_t)(q - reinterpret_cast<char*>(smem_raw));
     }
     return s;
 }
+
+// COMPACT (the 20-human shard's kernel): the seven float64 parameters of a step are not held in registers across the step
+// loop (14 VGPRs) but kept in LDS — Smem::disc[0..6], written once per launch — and requested where a phase needs them;
+// Smem::disc[8..13] hold the robot lane's episode bookkeeping between steps (EpisodeLds).
+enum { kParDt = 0, kParLimit, kParSuccess, kParCollision, kParDDist, kParDFactor, kParHSafety, kParCount };
+template <bool COMPACT>
+__device__ __forceinline__ double step_param(const Params& P, const Smem& s, int which) {
+    if (COMPACT) return s.disc[which];
+    return which == kParDt ? P.dt : which == kParLimit ? P.time_limit : which == kParSuccess ? P.success_reward :
+           which == kParCollision ? P.collision_penalty : which == kParDDist ? P.discomfort_dist :
+           which == kParDFactor ? P.discomfort_factor : P.human_safety;
+}
+struct EpisodeLds {  // at Smem::disc + 8 (one robot per workgroup)
+    double gtime, cur_return, cur_dsum;
+    int cur_steps, cur_danger, ep_count, ring_filled, state;
+    unsigned int transitions;
+};
+static_assert(sizeof(EpisodeLds) <= 8 * (kCompactScratchDoubles - 8), "EpisodeLds outgrew its LDS slot");
 
 // Workgroup barrier of the step / rollout kernels.  A workgroup of ONE wave (P.threads == 64: a compile-time fact in the
 // 20-human shard's instantiation, a uniform branch elsewhere) needs no s_barrier: a wave's LDS instructions execute in order,
@@ -234,12 +267,12 @@ struct Lane {
     size_t gi;                // env * A + a
 };
 
-__device__ __forceinline__ Lane lane_of(const Params& P) {
+__device__ __forceinline__ Lane lane_of(const Params& P, int block = -1) {
     Lane L;
     L.lane = threadIdx.x;
     const int el = L.lane / P.A;
     L.a = L.lane - el * P.A;
-    L.env = blockIdx.x * P.E + el;
+    L.env = (block < 0 ? (int)blockIdx.x : block) * P.E + el;
     L.valid = (L.lane < P.nA) && (L.env < P.B);
     L.ebase = el * P.A;
     L.gi = (size_t)L.env * P.A + L.a;
@@ -324,6 +357,17 @@ __device__ __forceinline__ void load_robot_view(const Params& P, const StateView
 __device__ __forceinline__ KdSmem kd_view(const Params& P, const Smem& s) {
     extern __shared__ double2 smem_raw[];
     return kd_carve(reinterpret_cast<char*>(smem_raw) + s.kd_off, P.kdl);
+}
+
+// COMPACT: the tie resolver's traversal scratch is carved out of `lines` (see carve)
+template <bool COMPACT>
+__device__ __forceinline__ KdSmem kd_scratch_view(const Params& P, const Smem& s) {
+    KdSmem k = kd_view(P, s);
+    if (COMPACT) {
+        k.visit = reinterpret_cast<uint8_t*>(s.lines);
+        k.stack = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(s.lines) + (size_t)P.nA * k.row);
+    }
+    return k;
 }
 
 // A launch keeps the permutations of its envs' simulators in LDS: loaded here (or built fresh), stored by kd_store.
@@ -538,8 +582,9 @@ __device__ __forceinline__ void kd_update_orders(const Params& P, const Smem& s,
 // Position of every agent of this lane's simulator in RVO2's traversal of its tree (queryAgentTreeRecursive without the
 // pruning, which only drops candidates that would be rejected): nearer child first, a leaf in permutation order.  Serial on
 // the lane; runs only for simulators with an exact distance tie.
+template <bool COMPACT = false>
 __device__ __forceinline__ void kd_visit_order(const Params& P, const Smem& s, const Lane& L, int g) {
-    const KdSmem k = kd_view(P, s);
+    const KdSmem k = kd_scratch_view<COMPACT>(P, s);
     const int el = L.ebase / P.A, t = kd_tree_of(L.a, P.robot_visible);
     const KdNode* cur = k.nodes + ((size_t)(g * P.E + el) * 2 + t) * k.mn;
     const int n_cur = kd_tree_on(P.A, t, P.robot_visible) ? k.count[(g * P.E + el) * 2 + t] : 0;
@@ -587,10 +632,11 @@ __device__ __forceinline__ void kd_visit_order(const Params& P, const Smem& s, c
 template <bool DETECT>
 __device__ __forceinline__ void pair_sweep2(const Params& P, const Smem& s) {
     const int* kept = reinterpret_cast<const int*>(s.proj);
-    const int wl = threadIdx.x & (kWave - 1), g = wl / 10, slot = wl - g * 10;
+    const int tid = opaque_tid();
+    const int wl = tid & (kWave - 1), g = wl / 10, slot = wl - g * 10;
     const int waves = (P.threads + kWave - 1) / kWave;
     const KdSmem k = DETECT ? kd_view(P, s) : KdSmem{};
-    for (int q0 = (threadIdx.x / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
+    for (int q0 = (tid / kWave) * 6; q0 < P.nA; q0 += 6 * waves) {
         const int q = q0 + g;
         const bool lane_ok = wl < 60 && q < P.nA;
         const int e = lane_ok ? kept[q * 10 + slot] : -1;
@@ -618,9 +664,9 @@ __device__ __forceinline__ void pair_sweep2(const Params& P, const Smem& s) {
 // registers the rare path spills go to scratch.)  All threads of the workgroup (barriers inside).
 template <bool COMPACT = false>
 __device__ __forceinline__ void kd_resolve_ties(const Params& P, const Smem& s, const Lane& L, int kd_gen, int two_sweeps) {
-    const KdSmem k = kd_view(P, s);
+    const KdSmem k = kd_scratch_view<COMPACT>(P, s);
     const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
-    if (L.lane < P.nA && k.tie[L.lane] != 0) kd_visit_order(P, s, L, kd_gen);
+    if (L.lane < P.nA && k.tie[L.lane] != 0) kd_visit_order<COMPACT>(P, s, L, kd_gen);
     block_sync(P);
     int* kept = reinterpret_cast<int*>(s.proj);
     for (int p = L.lane; p < P.pairs; p += P.threads) {
@@ -722,9 +768,11 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     constexpr bool kCand10 = (MAXL == 10) && (CN_CAND_LP10 == 1) && !kCoop && !kCand3;
     constexpr bool kLazy3 = (MAXL == 10) && (CN_CAND_LP10 == 2) && !kCoop && !kCand3;  // register planar program, lazy fallback
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
-    const float max_speed = (L.a == 0) ? robot_max_speed : (float)r.vpref;
+    // (COMPACT: the per-episode constants of the agent — goal, preferred speed, radius — are read from LDS where needed)
+    const float max_speed = (L.a == 0) ? robot_max_speed : (float)(COMPACT ? (L.lane < P.nA ? s.vpref[L.lane] : 0.0) : r.vpref);
     auto preferred = [&](float& pref_x, float& pref_y) {
-        const double gdx = r.gx - r.px, gdy = r.gy - r.py;
+        const double2 goal = COMPACT ? s.goal2[L.lane] : make_double2(r.gx, r.gy);
+        const double gdx = goal.x - r.px, gdy = goal.y - r.py;
         const double speed = norm2(gdx, gdy);
         pref_x = (float)(speed > 1.0 ? gdx / speed : gdx);
         pref_y = (float)(speed > 1.0 ? gdy / speed : gdy);
@@ -736,8 +784,10 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     if (L.lane < P.nA) {
         s.kin[L.lane] = make_float4((float)r.px, (float)r.py, (float)r.vx, (float)r.vy);
         s.posd[L.lane] = make_double2(r.px, r.py);
-        s.rad[L.lane] = r.rad;
-        s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
+        if (!COMPACT) {  // (COMPACT: written when the agent is loaded, stage_constants)
+            s.rad[L.lane] = r.rad;
+            s.hview[L.lane] = (float)(r.rad + 0.01 + step_param<COMPACT>(P, s, kParHSafety));
+        }
         if (kCoop || kPar || kCand10) {
             float pref_x, pref_y;
             preferred(pref_x, pref_y);
@@ -1127,22 +1177,24 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
         const double2 act = s.act[L.ebase];
         const double x1 = r.px - rp.x, y1 = r.py - rp.y;
         const double wx = r.vx - act.x, wy = r.vy - act.y;
-        const double x2 = x1 + wx * P.dt, y2 = y1 + wy * P.dt;
+        const double c_dt = step_param<COMPACT>(P, s, kParDt);
+        const double x2 = x1 + wx * c_dt, y2 = y1 + wy * c_dt;
         const double sx = x2 - x1, sy = y2 - y1;
         double u = ((0.0 - x1) * sx + (0.0 - y1) * sy) / (sx * sx + sy * sy);
         u = (u > 1.0) ? 1.0 : ((u < 0.0) ? 0.0 : u);
         const bool degenerate = (sx == 0.0 && sy == 0.0);  // utils.py:11-13
         const double cx = degenerate ? 0.0 - x1 : (x1 + u * sx) - 0.0;
         const double cy = degenerate ? 0.0 - y1 : (y1 + u * sy) - 0.0;
-        double endx = r.px + new_vx * P.dt, endy = r.py + new_vy * P.dt;
+        double endx = r.px + new_vx * c_dt, endy = r.py + new_vy * c_dt;
         if (unicycle) {
             const double th = theta0 + rot_r;
-            endx = r.px + cos(th) * rot_v * P.dt;
-            endy = r.py + sin(th) * rot_v * P.dt;
+            endx = r.px + cos(th) * rot_v * c_dt;
+            endy = r.py + sin(th) * rot_v * c_dt;
         }
-        const double d = norm2(human ? cx : endx - r.gx, human ? cy : endy - r.gy);
+        const double2 goal = COMPACT ? s.goal2[L.lane] : make_double2(r.gx, r.gy);
+        const double d = norm2(human ? cx : endx - goal.x, human ? cy : endy - goal.y);
         if (human) {
-            s.closest[L.lane] = d - r.rad - s.rad[L.ebase];
+            s.closest[L.lane] = d - (COMPACT ? s.rad[L.lane] : r.rad) - s.rad[L.ebase];
         } else {
             goal_dist = d;
         }
@@ -1161,35 +1213,37 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
             dmin = (!collision && !hit && c < dmin) ? c : dmin;
             collision = collision || hit;
         }
-        const bool reaching = goal_dist < r.rad;
-        if (gtime >= P.time_limit - 1.0) {
+        const bool reaching = goal_dist < (COMPACT ? s.rad[L.lane] : r.rad);
+        const double c_ddist = step_param<COMPACT>(P, s, kParDDist);
+        if (gtime >= step_param<COMPACT>(P, s, kParLimit) - 1.0) {
             res.reward = 0.0, res.done = 1, res.info = CN_TIMEOUT;
         } else if (collision) {
-            res.reward = P.collision_penalty, res.done = 1, res.info = CN_COLLISION;
+            res.reward = step_param<COMPACT>(P, s, kParCollision), res.done = 1, res.info = CN_COLLISION;
         } else if (reaching) {
-            res.reward = P.success_reward, res.done = 1, res.info = CN_REACH_GOAL;
-        } else if (dmin < P.discomfort_dist) {
-            res.reward = (dmin - P.discomfort_dist) * P.discomfort_factor * P.dt;
+            res.reward = step_param<COMPACT>(P, s, kParSuccess), res.done = 1, res.info = CN_REACH_GOAL;
+        } else if (dmin < c_ddist) {
+            res.reward = (dmin - c_ddist) * step_param<COMPACT>(P, s, kParDFactor) * step_param<COMPACT>(P, s, kParDt);
             res.done = 0, res.info = CN_DANGER;
         } else {
             res.reward = 0.0, res.done = 0, res.info = CN_NOTHING;
         }
         res.dmin = dmin;
         res.ax = unicycle ? rot_v : new_vx, res.ay = unicycle ? rot_r : new_vy;
-        if (update) gtime += P.dt;
+        if (update) gtime += step_param<COMPACT>(P, s, kParDt);
     }
     if (update && L.valid) {  // Agent.step (agent.py:127-135)
+        const double c_dt = step_param<COMPACT>(P, s, kParDt);
         if (unicycle) {
             const double th = theta0 + rot_r;
-            r.px = r.px + cos(th) * rot_v * P.dt;
-            r.py = r.py + sin(th) * rot_v * P.dt;
+            r.px = r.px + cos(th) * rot_v * c_dt;
+            r.py = r.py + sin(th) * rot_v * c_dt;
             const double theta1 = python_fmod(theta0 + rot_r, 2 * 3.141592653589793);
             r.vx = rot_v * cos(theta1);
             r.vy = rot_v * sin(theta1);
             *theta_io = theta1;
         } else {
-            r.px = r.px + new_vx * P.dt;
-            r.py = r.py + new_vy * P.dt;
+            r.px = r.px + new_vx * c_dt;
+            r.py = r.py + new_vy * c_dt;
             r.vx = new_vx;
             r.vy = new_vy;
         }
@@ -1600,8 +1654,11 @@ __device__ __forceinline__ double agent_load(const double* p) {
 
 // scratch: LDS, at least (E * (CN_SUMMARY_FIELDS + 1) + 1) doubles, free after the last barrier of the step loop.
 // Called by every thread of the workgroup (contains barriers); `transitions` / `ep_count` are read on the robot lanes.
+//   extra_env (>= 0, robot lanes): an env that is NOT part of this launch (the 3-of-4 schedule's last sub-launch) whose record
+//   ring this workgroup adds to its sums, so that the statistics the launch leaves behind cover every env of the engine
 __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateView& S, const cn_rollout_io& io, const Lane& L,
-                                                 bool robot, unsigned int transitions, int ep_count, double* scratch) {
+                                                 bool robot, unsigned int transitions, int ep_count, double* scratch,
+                                                 int extra_env = -1) {
     constexpr int F = CN_SUMMARY_FIELDS + 1;  // the eight sums + this launch's transitions (exact in a double)
     const int tid = threadIdx.x;
     const int cap = io.record_capacity;
@@ -1638,6 +1695,21 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
                 acc[5] += (outcome == CN_REACH_GOAL && io.ep_time) ? io.ep_time[k] : 0.0;
                 acc[6] += io.ep_return ? io.ep_return[k] : 0.0;
                 acc[7] += io.ep_danger ? (double)io.ep_danger[k] : 0.0;
+            }
+            if (extra_env >= 0) {
+                const int n2 = io.ep_count[extra_env], held2 = n2 < cap ? n2 : cap;
+                acc[0] += (double)n2;
+                acc[1] += (double)held2;
+                for (int j = 0; j < held2; ++j) {
+                    const size_t k = (size_t)extra_env * cap + j;
+                    const int outcome = io.ep_outcome ? (int)io.ep_outcome[k] : 0;
+                    acc[2] += outcome == CN_REACH_GOAL ? 1.0 : 0.0;
+                    acc[3] += outcome == CN_COLLISION ? 1.0 : 0.0;
+                    acc[4] += outcome == CN_TIMEOUT ? 1.0 : 0.0;
+                    acc[5] += (outcome == CN_REACH_GOAL && io.ep_time) ? io.ep_time[k] : 0.0;
+                    acc[6] += io.ep_return ? io.ep_return[k] : 0.0;
+                    acc[7] += io.ep_danger ? (double)io.ep_danger[k] : 0.0;
+                }
             }
         }
         const int el = L.ebase / P.A;
@@ -1719,7 +1791,7 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
 #endif
 // CN_GEOM20_WAVES: resident waves per SIMD the shard's kernel (HEADLINE instantiation of rollout_kernel<10>) is compiled for
 #ifndef CN_GEOM20_WAVES
-#define CN_GEOM20_WAVES 1
+#define CN_GEOM20_WAVES 3
 #endif
 template <int MAXL, bool UNI, bool HEADLINE = false, bool KD = false>
 __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVES : CN_MAXL10_WAVES) : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
@@ -1742,16 +1814,31 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVE
         P.orca.max_neighbors = 10;
         P.kdl = kd_layout(21, 21, 1);
     }
+    constexpr bool COMPACT = HEADLINE && MAXL == 10 && CN_COMPACT20 != 0;  // the shard kernel's LDS layout (carve)
     // the float64 parameters of a step as VALU operands live in VGPRs (rollout_fused.h: in_vgpr): as SGPR kernel arguments the
-    // 16-dword block was spilled into VGPR lanes and re-read with v_readlane several times per step
-    {
+    // 16-dword block was spilled into VGPR lanes and re-read with v_readlane several times per step (COMPACT: in LDS instead)
+    if (!COMPACT) {
         auto pin = [](double& x) { asm volatile("" : "+v"(x)); };
         pin(P.dt), pin(P.time_limit), pin(P.success_reward), pin(P.collision_penalty), pin(P.discomfort_dist);
         pin(P.discomfort_factor), pin(P.human_safety);
     }
-    constexpr bool COMPACT = HEADLINE && MAXL == 10 && CN_COMPACT20 != 0;  // the shard kernel's LDS layout (carve)
+    // The shard's kernel is compiled for three resident waves per SIMD: 3072 workgroups fill the chip, 4096 envs would run as
+    // a full round and a third of one.  launch_rollout therefore splits a call of 3 q steps into FOUR launches of q steps over
+    // 3 B / 4 workgroups: sub-launch k leaves out env 3 - k of every group of four (ABC, ABD, ACD, BCD), so every env makes
+    // its 3 q steps, in order, and every launch is exactly one round of the chip.
+    int env_block = -1, extra_env = -1;
+    if (HEADLINE && MAXL == 10 && P.sched >= 0) {
+        const int g = (int)blockIdx.x / 3, rr = (int)blockIdx.x - 3 * g, skip = 3 - P.sched;
+        env_block = 4 * g + rr + (rr >= skip ? 1 : 0);
+        if (P.sched == 3 && rr == 0) extra_env = 4 * g;  // the last sub-launch reports for the env it leaves out as well
+    }
     const Smem s = carve<MAXL, COMPACT>(P);
-    const Lane L = lane_of(P);
+    if (COMPACT && threadIdx.x == 0) {
+        s.disc[kParDt] = P.dt, s.disc[kParLimit] = P.time_limit, s.disc[kParSuccess] = P.success_reward;
+        s.disc[kParCollision] = P.collision_penalty, s.disc[kParDDist] = P.discomfort_dist;
+        s.disc[kParDFactor] = P.discomfort_factor, s.disc[kParHSafety] = P.human_safety;
+    }
+    const Lane L = lane_of(P, env_block);
     AgentRegs r = {};
     float robot_max_speed = 0.0f;
     const bool robot = L.valid && L.a == 0;
@@ -1791,9 +1878,27 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVE
         if (KD) kd_new_episode(P, s, L);
         theta = 1.5707963267948966;
     }
+    // COMPACT: what an agent keeps for a whole episode goes to LDS here and whenever the env loads its next scenario
+    const auto stage_constants = [&]() {
+        if (L.lane < P.nA) {
+            s.goal2[L.lane] = make_double2(r.gx, r.gy);
+            s.vpref[L.lane] = r.vpref;
+            s.rad[L.lane] = r.rad;
+            s.hview[L.lane] = (float)(r.rad + 0.01 + P.human_safety);
+        }
+    };
+    if (COMPACT) stage_constants();
     unsigned int transitions = 0;
     if (!COMPACT)
         for (int t = threadIdx.x; t < kMaxDiscount; t += blockDim.x) s.disc[t] = t < R.discount_len ? R.discount[t] : 0.0;
+    // COMPACT: the robot lane's episode bookkeeping waits in LDS while a transition is computed (12 VGPRs the step loop
+    // does not hold across the pair and solve phases)
+    EpisodeLds* const eps = reinterpret_cast<EpisodeLds*>(s.disc + 8);
+    if (COMPACT && robot) {
+        eps->gtime = gtime, eps->cur_return = cur_return, eps->cur_dsum = cur_dsum;
+        eps->cur_steps = cur_steps, eps->cur_danger = cur_danger, eps->ep_count = ep_count;
+        eps->ring_filled = ring_filled, eps->state = state, eps->transitions = 0u;
+    }
     __syncthreads();
     const int disc_len = R.discount_len < kMaxDiscount ? R.discount_len : kMaxDiscount;
 
@@ -1812,39 +1917,78 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVE
         asm volatile("" : "+v"(Ls.lane), "+v"(Ls.a), "+v"(Ls.ebase));
         Ls.valid = L.valid && s.flag[L.ebase] != 0;  // env is running
 
-        // COMPACT: no LDS copy of the discount table — this step's factor is requested here, a whole transition before its use
-        double disc_now = 0.0;
-        if (COMPACT && robot && cur_steps < disc_len) disc_now = R.discount[cur_steps];
-
         StepResult res;
         double nvx, nvy;
-        step_core<MAXL, UNI, KD, COMPACT>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
-
-        if (robot && state == kRunning) {
-            int next_flag = 1;
-            ++transitions;
-            const double disc = COMPACT ? disc_now : (cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0);
-            cur_return = cur_return + disc * res.reward;  // python sum(): left to right
-            ++cur_steps;
-            if (res.info == CN_DANGER) {
-                ++cur_danger;
-                cur_dsum += res.dmin;
+        if constexpr (COMPACT) {
+            // no LDS copy of the discount table: this step's factor is requested here, a whole transition before its use
+            double disc_now = 0.0, gt = 0.0;
+            if (robot) {
+                const int cs = eps->cur_steps;
+                gt = eps->gtime;
+                if (cs < disc_len) disc_now = R.discount[cs];
             }
-            if (res.done) {
-                next_flag = finish_episode(P, *Sd, R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
-                                           cur_steps, cur_return, cur_danger, cur_dsum, state);
-                cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
-                gtime = 0.0;
+            step_core<MAXL, UNI, KD, true>(P, s, Ls, r, gt, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
+            if (robot && eps->state == kRunning) {
+                int next_flag = 1;
+                int e_steps = eps->cur_steps, e_danger = eps->cur_danger;
+                double e_return = eps->cur_return, e_dsum = eps->cur_dsum;
+                eps->transitions += 1u;
+                e_return = e_return + disc_now * res.reward;  // python sum(): left to right
+                ++e_steps;
+                if (res.info == CN_DANGER) {
+                    ++e_danger;
+                    e_dsum += res.dmin;
+                }
+                if (res.done) {
+                    int e_count = eps->ep_count, e_state = kRunning;
+                    next_flag = finish_episode(P, *Sd, R, L.env, P.ring_depth, eps->ring_filled, s.disc[kParLimit], res.info, gt,
+                                               e_count, e_steps, e_return, e_danger, e_dsum, e_state);
+                    eps->ep_count = e_count, eps->state = e_state;
+                    e_steps = 0, e_return = 0.0, e_danger = 0, e_dsum = 0.0;
+                    gt = 0.0;
+                }
+                eps->gtime = gt;
+                eps->cur_steps = e_steps, eps->cur_danger = e_danger, eps->cur_return = e_return, eps->cur_dsum = e_dsum;
+                s.flag[L.lane] = next_flag;
             }
-            s.flag[L.lane] = next_flag;
+        } else {
+            step_core<MAXL, UNI, KD>(P, s, Ls, r, gtime, robot_max_speed, ext_action, 1, res, nvx, nvy, &theta, clk);
+            if (robot && state == kRunning) {
+                int next_flag = 1;
+                ++transitions;
+                const double disc = cur_steps < kMaxDiscount ? s.disc[cur_steps] : 0.0;
+                cur_return = cur_return + disc * res.reward;  // python sum(): left to right
+                ++cur_steps;
+                if (res.info == CN_DANGER) {
+                    ++cur_danger;
+                    cur_dsum += res.dmin;
+                }
+                if (res.done) {
+                    next_flag = finish_episode(P, *Sd, R, L.env, P.ring_depth, ring_filled, P.time_limit, res.info, gtime, ep_count,
+                                               cur_steps, cur_return, cur_danger, cur_dsum, state);
+                    cur_steps = 0, cur_return = 0.0, cur_danger = 0, cur_dsum = 0.0;
+                    gtime = 0.0;
+                }
+                s.flag[L.lane] = next_flag;
+            }
         }
         __syncthreads();
         if (L.valid && s.flag[L.ebase] >= 2) {
             load_from_ring(P, *Sd, L, s.flag[L.ebase] - 2, r);
             if (KD) kd_new_episode(P, s, L);
             theta = 1.5707963267948966;  // robot.set(..., np.pi / 2)
+            if (COMPACT) stage_constants();
         }
         CN_TICK(clk, 7);
+    }
+    if (COMPACT && L.lane < P.nA) {
+        const double2 g = s.goal2[L.lane];
+        r.gx = g.x, r.gy = g.y, r.vpref = s.vpref[L.lane], r.rad = s.rad[L.lane];
+    }
+    if (COMPACT && robot) {
+        gtime = eps->gtime, cur_return = eps->cur_return, cur_dsum = eps->cur_dsum;
+        cur_steps = eps->cur_steps, cur_danger = eps->cur_danger, ep_count = eps->ep_count;
+        state = eps->state, transitions = eps->transitions;
     }
 #ifdef CN_PHASE_TIMING
     if ((threadIdx.x & (kWave - 1)) == 0) {
@@ -1874,7 +2018,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVE
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
         S.ep_word[L.env] = (ep_count << 2) | state;
     }
-    rollout_epilogue(P, S, *R.io, L, robot, transitions, ep_count, reinterpret_cast<double*>(s.lines));
+    rollout_epilogue(P, S, *R.io, L, robot, transitions, ep_count, reinterpret_cast<double*>(s.lines), extra_env);
 }
 
 #endif  // CN_SARL_TU

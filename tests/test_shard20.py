@@ -1,0 +1,77 @@
+"""The 20-human shard's kernel (BASELINE configs[3]: `rollout_kernel<10, false, true, true>`, step_kernels.h) since round 4:
+compact LDS layout (12 workgroups per CU), step parameters / episode bookkeeping / per-episode agent constants in LDS instead of
+registers (three resident waves per SIMD), and the 3-of-4 env schedule of `launch_rollout` (crowdnav_amd.hip): a call of
+3 q + r steps runs as one launch of r steps over all envs and FOUR launches of q steps over 3 B / 4 workgroups, sub-launch k
+leaving out env 3 - k of every group of four.  None of this may change a bit of what an env plays: everything is compared
+with the oracle's rollout (oracle/crowd_oracle.cpp: co_rollout, the restatement of crowd_sim.py:317-420 + explorer.py:50-72),
+and the statistics a call leaves behind (cn_rollout_io.summary / .blocks) with the boundary kernels' own."""
+import numpy as np
+import pytest
+
+from test_ring_wrap import _engine, _np, _oracle, _records_in_order, amd  # noqa: F401  (amd: module fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def force_schedule(monkeypatch):
+    """cn_create reads CROWDNAV_AMD_SCHED_FORCE: split calls of >= 48 steps even where it saves no round (a handful of envs)"""
+    monkeypatch.setenv('CROWDNAV_AMD_SCHED_FORCE', '1')
+
+
+@pytest.mark.parametrize('B,R,launches', [(16, 9.0, [48, 100, 7, 61]), (8, 4.0, [150, 50]), (4, 12.0, [49, 49, 49])])
+def test_env_schedule_plays_the_oracles_episodes(amd, oracle_mod, B, R, launches):
+    """Launch lengths on both sides of the schedule's threshold (48 steps), divisible by three and not: episodes, counters of
+    the running episode, returns and the end state equal the oracle's, transition for transition."""
+    K = 32
+    steps = sum(launches)
+    cfg = dict(num_humans=20, circle_radius=R, robot_visible=1)
+    o, total, rec, cur_steps, cur_ret = _oracle(oracle_mod, B, steps, K, **cfg)
+    eng, bufs = _engine(amd, B, launches, K, None, **cfg)
+    assert int(_np(bufs['transitions'])[0]) == total == B * steps
+    cnt = _records_in_order(bufs, rec, K)
+    assert np.array_equal(cnt, rec['count']) and cnt.sum() > 0
+    assert np.array_equal(_np(bufs['cur_steps']), cur_steps)
+    assert np.allclose(_np(bufs['cur_return']), cur_ret, rtol=0, atol=1e-12)
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+
+
+def test_env_schedule_statistics_cover_every_env(amd):
+    """The last sub-launch leaves one env of every four out and reports for it as well (rollout_epilogue: extra_env): the
+    sums of a scheduled call equal cn_records_summary over cn_rollout_records' blocks, the record blocks are the packed
+    ones, the transitions counter is exact, and a second run leaves the same bits."""
+    import torch
+    B, K = 36, 4
+
+    def run():
+        eng = amd.BatchedCrowdSim(num_envs=B, num_humans=20, robot_policy=amd.ROBOT_ORCA, robot_visible=1, circle_radius=9.0)
+        bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=-1, record_capacity=K, boundary_records=2)
+        for n in (60, 49, 90):
+            eng.rollout(n)
+        eng.sync()
+        return eng, bufs
+
+    eng, bufs = run()
+    assert int(_np(bufs['transitions'])[0]) == B * 199
+    assert torch.equal(bufs['blocks'], eng.rollout_records(max_records=2))
+    want = _np(eng.records_summary(eng.rollout_records(), record_capacity=K))
+    got = _np(bufs['summary'])
+    assert np.array_equal(got[:5], want[:5]) and got[7] == want[7] and got[0] == _np(bufs['ep_count']).sum() > B
+    assert np.abs(got[5:7] - want[5:7]).max() <= 1e-9 * max(1.0, np.abs(want[5:7]).max())
+    _, bufs2 = run()
+    assert torch.equal(bufs['summary'], bufs2['summary']) and torch.equal(bufs['blocks'], bufs2['blocks'])
+
+
+def test_env_schedule_with_asynchronous_fill(amd, oracle_mod):
+    """The schedule next to CN_FLAG_ASYNC_SCENARIO_FILL on the reference's own geometry (4 m circle): timing decides when an
+    env pauses, never what it plays — its finished episodes are the oracle's, in order."""
+    B, K = 16, 64
+    launches = [60, 60, 120, 51]
+    cfg = dict(num_humans=20, circle_radius=4.0, robot_visible=1)
+    o, total, rec, cur_steps, cur_ret = _oracle(oracle_mod, B, sum(launches), K, **cfg)
+    eng, bufs = _engine(amd, B, launches, K, None, flags=amd.FLAG_ASYNC_SCENARIO_FILL, **cfg)
+    cnt = _records_in_order(bufs, rec, K)
+    assert cnt.min() >= 1
+    ran = _np(bufs['ep_steps']).astype(np.int64)
+    per_env = np.array([ran[b, :cnt[b]].sum() for b in range(B)]) + _np(bufs['cur_steps'])
+    assert int(_np(bufs['transitions'])[0]) == per_env.sum()
