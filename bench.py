@@ -307,17 +307,29 @@ def measure_h20(B, local_rank):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in lengths]
         torch.cuda.synchronize()
         done = 0
-        for (e0, e1), n in zip(evs, lengths):
-            if refill_before_each:  # a 1-step launch spends the ring budget's last step: it carries the (untimed) fill
+        if refill_before_each:
+            for (e0, e1), n in zip(evs, lengths):  # a 1-step launch spends the ring budget's last step: it carries the (untimed) fill
                 sim.rollout(1)
                 torch.cuda.synchronize()
+                n0 = int(bufs['transitions'].item())
+                e0.record()
+                sim.rollout(n)
+                e1.record()
+                torch.cuda.synchronize()
+                done += int(bufs['transitions'].item()) - n0
+            secs = sum(a.elapsed_time(b) for a, b in evs) / 1e3
+        else:
+            # back to back, ONE event pair around all of them: with the asynchronous fill the generator kernels of launch k run
+            # beside launch k + 1 on their side streams - a synchronize between the launches would let them finish outside
+            # the timed span (and hand every launch a freshly filled ring)
             n0 = int(bufs['transitions'].item())
-            e0.record()
-            sim.rollout(n)
-            e1.record()
+            evs[0][0].record()
+            for n in lengths:
+                sim.rollout(n)
+            evs[-1][1].record()
             torch.cuda.synchronize()
-            done += int(bufs['transitions'].item()) - n0
-        secs = sum(a.elapsed_time(b) for a, b in evs) / 1e3
+            done = int(bufs['transitions'].item()) - n0
+            secs = evs[0][0].elapsed_time(evs[-1][1]) / 1e3
         res = {'value': done / secs, 'unit': 'env-steps/s', 'launches': lengths, 'seconds': secs,
                'paused_env_steps': B * sum(lengths) - done,
                'roofline_frac_hbm': algorithmic_bytes_per_env_step(H) * done / secs / 1e9 / HBM_PEAK_GBS}
@@ -330,11 +342,12 @@ def measure_h20(B, local_rank):
     seeds = (1000, 1024)  # the 'test' phase seeds, on which the reference's own rejection sampling terminates
     return {
         'workload': '%d envs x %d humans per GPU, ORCA humans + ORCA robot, cn::rollout_kernel<10>' % (B, H),
-        'r4_async_fill': one(4.0, crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL, seeds[0], seeds[1], [500], [1000, 1000]),
+        'r4_async_fill': one(4.0, crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL, seeds[0], seeds[1], [500], [1000] * 6),
         'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47, 47, 47], refill_before_each=True),
         'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [200, 500], [500, 500, 500]),
         'episode_seeds_r4': '%d + c %% %d' % seeds,
-        'note': 'r4_async_fill: resets included (envs whose next scenario is not ready pause: paused_env_steps); '
+        'note': 'r4_async_fill: resets included, six 1000-step launches back to back under one event pair (envs whose next '
+                'scenario is not ready pause: paused_env_steps); '
                 'r4_resets_excluded: HIP events around 47-step launches that stay inside the ring budget, so the timed launch '
                 'is the transition kernel alone (the synchronous fill runs in the untimed 1-step launch before it); r12: '
                 'resets included, cheap at that radius',

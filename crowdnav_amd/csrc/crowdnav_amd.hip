@@ -682,3 +682,9 @@ extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
+#ifdef CN_WAVE_TRACE
+extern "C" int cn_debug_wave_trace(unsigned long long* out, int waves) {
+    if (waves > 8192) waves = 8192;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cn::cn_wave_trace), (size_t)waves * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -84,9 +84,19 @@ __device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max
 #define CN_FUSED_PRIO 2
 #endif
 
+// CN_WAVE_TRACE (profiling builds): every wave leaves four 100 MHz timestamps (kernel entry, step loop entry / exit, kernel
+// exit) and how many of its steps took the 3-D fallback / ended an episode: scripts/probes/wave_trace.py
+#ifdef CN_WAVE_TRACE
+static __device__ unsigned long long cn_wave_trace[8192 * 6];
+#endif
+
 template <bool HEADLINE>
 __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                               RolloutView R, int n_steps, const double* ext_action) {
+#ifdef CN_WAVE_TRACE
+    const unsigned long long wt_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wt_fallbacks = 0ull, wt_ends = 0ull;
+#endif
     // The 17 state pointers are needed before and after the step loop and when an episode ends — never inside a step — so
     // they stay in the engine's device copy of the StateView and are re-read where used (scalar loads) instead of holding
     // 34 SGPRs (and spilling as many into VGPR lanes) across the loop.  ring_filled_in is the one pointer the host swaps
@@ -181,6 +191,9 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     (void)clk;
 #endif
     const float range_sq = P.orca.neighbor_dist * P.orca.neighbor_dist;
+#ifdef CN_WAVE_TRACE
+    const unsigned long long wt_loop = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int step = 0; step < n_steps; ++step) {
         const bool running = L.valid && ep.state == kRunning;
         const bool solve = running && (L.a > 0 || P.robot_orca);
@@ -251,6 +264,9 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
 #endif
         if (CN_FUSED_PRIO == 2 && nm == 0ull) __builtin_amdgcn_s_setprio(0);
         if (nm != 0ull) {  // wave-uniform: some agent of this wave was infeasible
+#ifdef CN_WAVE_TRACE
+            ++wt_fallbacks;
+#endif
             if (CN_FUSED_PRIO != 0) __builtin_amdgcn_s_setprio(3);
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int n_todo = __popcll(nm);
@@ -376,6 +392,9 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             ++cur_steps;
             cur_danger += info == CN_DANGER ? 1 : 0;
             cur_dsum = info == CN_DANGER ? cur_dsum + dmin : cur_dsum;
+#ifdef CN_WAVE_TRACE
+            if (__ballot(done) != 0ull) ++wt_ends;
+#endif
             if (done) {  // explorer.py:50-72: record, then the env's next episode
                 const cn_rollout_io io = *iop;
                 if (L.a == 0) {
@@ -420,6 +439,9 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     }
 #endif
 
+#ifdef CN_WAVE_TRACE
+    const unsigned long long wt_exit = __builtin_amdgcn_s_memrealtime();
+#endif
     const StateView S = *Sd;
     if (L.valid) {
         S.pos[L.gi] = make_double2(r.px, r.py);
@@ -442,6 +464,15 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     }
     // transitions counter, record blocks, explorer.py:74-90 sums: the launch's own tail (step_kernels.h: rollout_epilogue)
     rollout_epilogue(P, S, io, L, robot, transitions, ep.ep_count, reinterpret_cast<double*>(s.lines));
+#ifdef CN_WAVE_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* w = cn_wave_trace + 6 * blockIdx.x;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        w[0] = wt_entry, w[1] = wt_loop, w[2] = wt_exit, w[3] = __builtin_amdgcn_s_memrealtime();
+        w[4] = wt_fallbacks | (wt_ends << 32), w[5] = hw;
+    }
+#endif
 }
 
 }  // namespace cn

@@ -26,6 +26,15 @@ __device__ __forceinline__ void wave_sync() { wave_lds_sync(); }
 #define CN_GEN_PREFILTER 1
 #endif
 
+// CN_GEN_WINDOW (compile time, default on): without randomised attributes every human's attempts look the same — the
+// stream continues right behind the accepted attempt, same radius, same noise scale — so the 64 attempts a wave has
+// evaluated are not thrown away when one of them is accepted: the lanes behind it ARE the next human's first attempts, and
+// all they still have to clear is the human just placed (two exact distance tests).  An easy scenario (20 humans on the
+// 12 m circle: one or two candidates per human) costs two or three window evaluations instead of twenty.
+#ifndef CN_GEN_WINDOW
+#define CN_GEN_WINDOW 1
+#endif
+
 struct WaveRng {
     uint32_t* key;   // [624] generator state (LDS)
     uint32_t* prev;  // [2][624] the states one and two blocks earlier, or NULL (kept only when the stream is handed on)
@@ -122,17 +131,23 @@ struct WaveRng {
     }
 };
 
-// Shared scratch of one generator wave
-struct WaveScratch {
+// Shared scratch of one generator wave.  KEEP: the stream is handed on when the scenario is done (cn_reset: the env's own
+// numpy stream continues behind it), which takes the generator states of the two blocks before the current one; the ring
+// fill and rollout-begin kernels never do that, and 5 KB less per workgroup is 14 generator waves per CU instead of 9.
+template <bool KEEP>
+struct WaveScratchT {
     uint32_t key[624];
-    uint32_t prev[2 * 624];
+    uint32_t prev[KEEP ? 2 * 624 : 2];
     uint32_t out[WaveRng::kWindow];
     double2 ppos[64];
     double2 pgoal[64];
     double prad[64];
     float4 fpg[64];   // float32 copies (pos.x, pos.y, goal.x, goal.y) of the placed agents: the conservative prefilter
     float fthr2[64];  // ... and, per placed agent, (min_dist - margin)^2 for the human being placed
+    double2 giveup;   // window path: the attempt the generator falls back on if a human exhausts its attempts
 };
+using WaveScratch = WaveScratchT<true>;
+using WaveScratchFill = WaveScratchT<false>;
 
 // Conservative float32 prefilter of the circle-crossing rejection test (crowd_sim.py:159-175).  On the reference's own
 // geometry (20 humans on the 4 m circle) the last humans of a scenario are accepted once in 10^3..10^4 attempts: almost every
@@ -148,7 +163,8 @@ __device__ __forceinline__ float prefilter_margin(double R) { return 2.0e-5f * (
 // Builds agents [0, A) at pos/vel/goal/rv[base + agent] (vel may be NULL); returns np.random.random() calls consumed.
 // Must be called by all 64 lanes of a one-wave workgroup.
 // mt_key_out / mt_stride / mt_pos_out (optional): where the env's own generator continues (cn_reset: epsilon-greedy draws).
-__device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScratch& s, uint32_t seed, size_t base,
+template <class Scratch>
+__device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch& s, uint32_t seed, size_t base,
                                                   double2* pos, double2* vel, double2* goal, double2* rv,
                                                   uint32_t* mt_key_out = nullptr, int mt_stride = 0,
                                                   int* mt_pos_out = nullptr) {
@@ -170,6 +186,11 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
         rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
     }
     wave_sync();
+    // window state of the CN_GEN_WINDOW path (circle crossing, fixed attributes): lane l holds the attempt at stream position
+    // rng.cursor + 6 l once `win` is set; lanes below wstart belong to humans already placed
+    bool win = false, w_collide = true;
+    int wstart = 0;
+    double w_x = 0.0, w_y = 0.0;
     for (int i = 1; i < A; ++i) {
         double radius = c.human_radius, v_pref = c.human_v_pref;
         if (c.randomize) {
@@ -180,7 +201,106 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
         }
         unsigned long long attempts = 0;
         const float vpf = (float)v_pref;
-        if (c.rule == 0) {
+        if (c.rule == 0 && !c.randomize && CN_GEN_WINDOW != 0) {
+            // the reference examines attempts until one is free (crowd_sim.py:159-175); this generator gives up after N of them,
+            // counted per human in passes of 64 like the loop below (attempt N - 64 is taken then, and the error flagged)
+            const unsigned long long N = ((c.max_attempts + 63ull) / 64ull) * 64ull;
+            const uint32_t hstart = rng.cursor + (win ? 6u * wstart : 0u);  // stream position of this human's first attempt
+            unsigned long long tried = 0;
+            if (lane == i - 1) {  // the prefilter's threshold against the agent placed last (same for every later human)
+                const float t = (float)(radius + s.prad[lane] + c.discomfort_dist) - margin;
+                s.fthr2[lane] = t > 0.0f ? t * t : 0.0f;
+            }
+            wave_sync();
+            for (;;) {
+                if (!win) {  // evaluate the 64 attempts at the cursor against everybody placed so far
+                    rng.ensure(6 * 64, lane);
+                    const uint32_t at = rng.cursor + 6u * lane;
+                    bool inside = false;
+                    if (CN_GEN_PREFILTER) {
+                        const float frac = (float)(rng.word(at) >> 5) * 0x1p-27f;
+                        float sn, cs;
+                        sincosf(frac * 6.2831855f, &sn, &cs);
+                        const float fx = Rf * cs + ((float)(rng.word(at + 2) >> 5) * 0x1p-27f - 0.5f) * vpf;
+                        const float fy = Rf * sn + ((float)(rng.word(at + 4) >> 5) * 0x1p-27f - 0.5f) * vpf;
+                        for (int k = 0; k < i; ++k) {
+                            const float4 q = s.fpg[k];
+                            const float t2 = s.fthr2[k];
+                            const float ax = fx - q.x, ay = fy - q.y, bx = fx - q.z, by = fy - q.w;
+                            inside = inside | (ax * ax + ay * ay < t2) | (bx * bx + by * by < t2);
+                        }
+                    }
+                    w_collide = true;
+                    if (__ballot(!inside) != 0ull) {  // somebody may be free: the reference arithmetic
+                        const double angle = rng.random_at(at) * kPi * 2;
+                        const double nx = (rng.random_at(at + 2) - 0.5) * v_pref;
+                        const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
+                        w_x = R * cos(angle) + nx;
+                        w_y = R * sin(angle) + ny;
+                        w_collide = inside;
+                        if (!inside)
+                            for (int k = 0; k < i; ++k) {
+                                const double2 p = s.ppos[k], g = s.pgoal[k];
+                                const double min_dist = radius + s.prad[k] + c.discomfort_dist;
+                                if (closer_than(w_x - p.x, w_y - p.y, min_dist) || closer_than(w_x - g.x, w_y - g.y, min_dist)) {
+                                    w_collide = true;
+                                    break;
+                                }
+                            }
+                    }
+                    win = true, wstart = 0;
+                }
+                const unsigned long long left = N - tried;  // attempts this human may still examine
+                const bool mine = lane >= wstart && (unsigned long long)(lane - wstart) < left;
+                if (lane >= wstart && tried + (unsigned long long)(lane - wstart) == N - 64ull) {
+                    // the attempt the give-up rule would take (first of the last pass of 64): remembered while its words
+                    // are in the window — with the default cap (2^23 attempts) this lane exists once in a blue moon
+                    const uint32_t at = rng.cursor + 6u * lane;
+                    const double angle = rng.random_at(at) * kPi * 2;
+                    const double nx = (rng.random_at(at + 2) - 0.5) * v_pref;
+                    const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
+                    s.giveup = make_double2(R * cos(angle) + nx, R * sin(angle) + ny);
+                }
+                const unsigned long long ok = __ballot(mine && !w_collide);
+                if (ok) {
+                    const int first = __ffsll((long long)ok) - 1;
+                    if (lane == first) {
+                        s.ppos[i] = make_double2(w_x, w_y);
+                        s.pgoal[i] = make_double2(-w_x, -w_y);
+                        s.fpg[i] = make_float4((float)w_x, (float)w_y, (float)-w_x, (float)-w_y);
+                        s.prad[i] = radius;
+                    }
+                    wave_sync();
+                    // the lanes behind the accepted attempt are the next human's first attempts: what they still have to clear
+                    // is this human (same expression as the loop above, with prad[i] = radius)
+                    if (lane > first && !w_collide) {
+                        const double2 p = s.ppos[i], g = s.pgoal[i];
+                        const double min_dist = radius + s.prad[i] + c.discomfort_dist;
+                        w_collide = closer_than(w_x - p.x, w_y - p.y, min_dist) || closer_than(w_x - g.x, w_y - g.y, min_dist);
+                    }
+                    wstart = first + 1;
+                    if (wstart == 64) rng.cursor += 6u * 64, win = false, wstart = 0;
+                    break;
+                }
+                const unsigned long long span = (unsigned long long)(64 - wstart);
+                tried += span < left ? span : left;
+                if (tried >= N) {  // give up like nobody would: take the first candidate of the last pass of 64, flag it
+                    wave_sync();
+                    if (lane == 0) {
+                        const double x = s.giveup.x, y = s.giveup.y;
+                        s.ppos[i] = make_double2(x, y);
+                        s.pgoal[i] = make_double2(-x, -y);
+                        s.fpg[i] = make_float4((float)x, (float)y, (float)-x, (float)-y);
+                        s.prad[i] = radius;
+                        *c.error = 1;
+                    }
+                    rng.cursor = hstart + 6u * (uint32_t)(N - 64ull + 1ull);
+                    win = false, wstart = 0;
+                    break;
+                }
+                rng.cursor += 6u * 64, win = false, wstart = 0;
+            }
+        } else if (c.rule == 0) {
             // circle crossing: attempt = (angle, px_noise, py_noise) = 6 words; reject if within min_dist of any placed
             // agent's position or goal (crowd_sim.py:159-175)
             if (lane < i) {  // this human's thresholds against everybody placed so far
@@ -295,6 +415,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, WaveScra
         }
     }
     wave_sync();
+    if (win) rng.cursor += 6u * wstart;  // (window path: the stream stands behind the last accepted attempt)
     if (mt_key_out) rng.persist(mt_key_out, mt_stride, mt_pos_out, lane);
     return (uint64_t)(rng.cursor / 2);
 }

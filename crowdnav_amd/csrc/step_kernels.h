@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(kWave) void reset_wave_kernel(Params P, ScenarioCfg
 }
 
 __global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
-    __shared__ WaveScratch scratch;
+    __shared__ WaveScratchFill scratch;
     const int b = blockIdx.x;
     const cn_rollout_io io = *R.io;
     const int64_t c0 = episode_id(io, b, 0);
@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__(kWave) void rollout_begin_wave_kernel(Params P, Sce
 }
 
 __global__ __launch_bounds__(kWave) void ring_fill_wave_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
-    __shared__ WaveScratch scratch;
+    __shared__ WaveScratchFill scratch;
     const int idx = blockIdx.x;  // (env, ring slot)
     const int D = P.ring_depth;
     const int b = idx / D, slot = idx - b * D;
@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(kWave) void ring_fill_wave_kernel(Params P, Scenari
 // ring_claim), generated, and published with a device-scope release store of ordinal + 1 to ring_ready.  Only slots whose
 // scenario the env consumed before the transition kernel running beside the fill was launched are ever overwritten.
 __global__ __launch_bounds__(kWave) void ring_fill_wave_async_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
-    __shared__ WaveScratch scratch;
+    __shared__ WaveScratchFill scratch;
     __shared__ int go;
     const int idx = blockIdx.x;  // workgroup = (env, slot)
     const int D = P.ring_depth;

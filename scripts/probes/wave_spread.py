@@ -36,3 +36,5 @@ for n in (5, 20, 20, 20, 20, 100, 1000):
           'fallback mean %5.0f; agents in fallback per wave-step %.3f'
           % (n, e0.elapsed_time(e1) * 1e3, e0.elapsed_time(e1) * 1e3 / n, mean, out[14] / n, out[14] / n / mean, fb,
              out[9] / waves / n))
+    print('           per phase (ticks per wave-step): pairs %5.0f  2-D solve %5.0f  collide %5.0f  bookkeeping %5.0f  fallback %5.0f; '
+          'of the bookkeeping at episode ends: io block %5.0f  ring loads %5.0f' % tuple(out[k] / waves / n for k in (2, 3, 5, 7, 8, 0, 1)))
