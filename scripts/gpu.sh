@@ -46,8 +46,8 @@ PY
   ;;
 bench32k) bench bench_32k -- --no-cpu-baseline --no-secondary --envs 32768 --steps 4000 ;;
 benchh20)
-  bench bench_h20_r12 -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 2000 --warmup 500 --chunk 500
-  bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 8000 --warmup 400 --chunk 1000 --preroll 100 --seed-base 1000 --seed-mod 1024 --async-fill ;;
+  bench bench_h20_r12 -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 2004 --warmup 501 --chunk 501
+  bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1024 --async-fill ;;
 ab)
   for lib in "" $REPO/build/exp/lib_ab_*.so; do
     n=$(basename "${lib:-intree}" .so)
@@ -81,13 +81,16 @@ pmc)
   declare -A CMD
   CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary"
   CMD[driver]="$REPO/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5"
-  CMD[h20]="$REPO/bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1500 --warmup 500 --chunk 500"
+  # (h20 counters: one dispatch per call - the 3-of-4 env schedule off - so that a dispatch is 4096 envs x 500 steps)
+  CMD[h20]="$REPO/bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1503 --warmup 501 --chunk 501"
   for shape in ${CN_PMC_SHAPES:-default driver h20}; do
+    [ $shape = h20 ] && export CROWDNAV_AMD_SCHED_MIN_STEPS=1000000000 || unset CROWDNAV_AMD_SCHED_MIN_STEPS
     prof pmc_${shape}_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${shape}_fetch -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${shape}_write -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_sq1 --pmc $SQ1 --output-format csv -d $OUT/pmc_${shape}_sq1 -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_sq2 --pmc $SQ2 --output-format csv -d $OUT/pmc_${shape}_sq2 -o p -- python ${CMD[$shape]}
   done
+  unset CROWDNAV_AMD_SCHED_MIN_STEPS
   for v in sarl om_sarl; do
     a=""; [ $v = om_sarl ] && a="--om 1"
     prof pmc_${v}_mfma --pmc $MF --output-format csv -d $OUT/pmc_${v}_mfma -o p -- python $REPO/scripts/sarl_bench.py --iters 3 $a
@@ -98,7 +101,7 @@ pmc)
   P="python scripts/pmc_to_traffic.py $OUT/${TAG}_traffic.json"
   $P 4096 5 1000 rollout_fused_kernel tail $OUT/pmc_default_fetch $OUT/pmc_default_write $OUT/pmc_default_sq1 $OUT/pmc_default_sq2 > /dev/null
   $P 4096 5 20 rollout_fused_kernel 2 $OUT/pmc_driver_fetch $OUT/pmc_driver_write $OUT/pmc_driver_sq1 $OUT/pmc_driver_sq2 > /dev/null
-  CN_PMC_RADIUS=12 $P 4096 20 500 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 > /dev/null
+  CN_PMC_RADIUS=12 $P 4096 20 501 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 > /dev/null
   python scripts/prof_summary.py $OUT/pmc_sarl_mfma | tail -n 4; python scripts/prof_summary.py $OUT/pmc_om_sarl_mfma | tail -n 4
   head -c 1500 $OUT/${TAG}_traffic.json ;;
 h20ab)

@@ -1,4 +1,4 @@
-"""rocprofv3 PMC csv files -> one record of profiles/r03_traffic.json (what bench.py prints as roofline.traffic / issue_roofline).
+"""rocprofv3 PMC csv files -> one record of profiles/r04_traffic.json (what bench.py prints as roofline.traffic / issue_roofline).
 
     python scripts/pmc_to_traffic.py <out.json> <envs> <humans> <steps_per_launch> <kernel substring> <dispatch index, or 'tail'> <dir> [<dir> ...]
 
