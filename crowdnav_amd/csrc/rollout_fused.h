@@ -110,33 +110,53 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     const Lane L = lane_of(P);
     AgentRegs r = {};
     float robot_max_speed = 0.0f;
-    {
-        const StateView S = *Sd;
-        if (L.valid) load_agent(S, L.gi, r);
-        if (P.robot_orca) load_robot_view(P, S, s, L, r, robot_max_speed);
-    }
-    build_pairs(P, s);
-
     const bool robot = L.valid && L.a == 0;
     // the ~20 pointers of the io block are needed at launch start / end and when an episode ends: they are re-read from
     // the device copy there (scalar loads) instead of occupying SGPRs across the step loop
     const cn_rollout_io* iop = R.io;
-    double theta = robot ? Sd->theta[L.env] : 0.0;
+    double theta = 0.0;
     EpisodeRegs ep{0.0, kRetired, 0, 0};
     double cur_return = 0.0, cur_dsum = 0.0;
     int cur_steps = 0, cur_danger = 0;
-    if (L.valid) {
-        ep.gtime = Sd->gtime[L.env];
-        ep.state = iop->active[L.env];
-        ep.ep_count = iop->ep_count[L.env];
-        ep.ring_filled = ring_filled_in[L.env];
+    {
+        // Launch prologue in TWO memory round trips: every pointer it needs in one batch of scalar loads (both structs are
+        // dead again before the step loop), then every per-lane value in one batch of vector loads — unconditional, on clamped
+        // indices, so that none waits for another's result (the robot's captured radii are read speculatively: the buffers
+        // exist whether or not the policy's simulator has been built).  As a chain of `S->field[..]` / `io->field[..]` reads
+        // under their own conditions this was a dozen dependent trips, ~4 of the 113 us of a 20-step launch.
+        const StateView S = *Sd;
+        const cn_rollout_io io = *iop;
+        const size_t gi = L.valid ? L.gi : 0;
+        const int env = L.valid ? L.env : 0;
+        const double2 p0 = S.pos[gi], v0 = S.vel[gi], g0 = S.goal[gi], q0 = S.rv[gi];
+        const bool have = P.robot_orca ? S.rsim_valid[env] != 0 : false;
+        const float rr_kept = P.robot_orca ? S.rsim_radius[gi] : 0.0f;
+        const float ms_kept = P.robot_orca ? S.rsim_max_speed[env] : 0.0f;
+        const double theta0 = S.theta[env], gtime0 = S.gtime[env];
+        const int state0 = io.active[env], count0 = io.ep_count[env], filled0 = ring_filled_in[env];
+        const int steps0 = io.cur_steps[env];
+        const double return0 = io.cur_return[env];
+        const int danger0 = io.cur_danger ? io.cur_danger[env] : 0;
+        const double dsum0 = io.cur_danger_dmin_sum ? io.cur_danger_dmin_sum[env] : 0.0;
+        if (L.valid) {
+            r.px = p0.x, r.py = p0.y, r.vx = v0.x, r.vy = v0.y, r.gx = g0.x, r.gy = g0.y, r.rad = q0.x, r.vpref = q0.y;
+            ep.gtime = gtime0, ep.state = state0, ep.ep_count = count0, ep.ring_filled = filled0;
+            // (every lane of the env: the accumulators are carried redundantly, see the reduce phase)
+            cur_steps = steps0, cur_return = return0, cur_danger = danger0, cur_dsum = dsum0;
+            if (L.a == 0) theta = theta0;
+            if (P.robot_orca) {  // load_robot_view (step_kernels.h), without its dependent loads
+                const float rr = have ? rr_kept : (float)(r.rad + 0.01 + P.robot_safety);
+                if (!have) S.rsim_radius[L.gi] = rr;
+                s.rview[L.lane] = rr;
+                if (L.a == 0) {
+                    robot_max_speed = have ? ms_kept : (float)r.vpref;
+                    if (!have) S.rsim_max_speed[L.env] = robot_max_speed;
+                }
+            }
+        }
     }
-    if (L.valid) {  // (every lane of the env: the accumulators are carried redundantly, see the reduce phase)
-        cur_steps = iop->cur_steps[L.env];
-        cur_return = iop->cur_return[L.env];
-        if (iop->cur_danger) cur_danger = iop->cur_danger[L.env];
-        if (iop->cur_danger_dmin_sum) cur_dsum = iop->cur_danger_dmin_sum[L.env];
-    }
+    build_pairs(P, s);
+
     if (L.valid && ep.state == kWaitingScenario && ep.ep_count < ep.ring_filled) {  // the fill kernel has just produced it
         // (the asynchronous fill is for the wave generators, more than 8 humans: never this kernel)
         load_from_ring(P, *Sd, L, ep.ep_count % P.ring_depth, r);

@@ -47,7 +47,7 @@ PY
 bench32k) bench bench_32k -- --no-cpu-baseline --no-secondary --envs 32768 --steps 4000 ;;
 benchh20)
   bench bench_h20_r12 -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 2004 --warmup 501 --chunk 501
-  bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1024 --async-fill ;;
+  bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill ;;
 ab)
   for lib in "" $REPO/build/exp/lib_ab_*.so; do
     n=$(basename "${lib:-intree}" .so)
@@ -110,7 +110,7 @@ h20ab)
   for lib in "" $REPO/build/exp/lib_ab_*.so; do
     n=$(basename "${lib:-intree}" .so)
     bench h20_${n}_r12 CROWDNAV_AMD_LIB=$lib -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1500 --warmup 500 --chunk 500
-    bench h20_${n}_r4_async CROWDNAV_AMD_LIB=$lib -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 2000 --warmup 500 --chunk 1000 --preroll 100 --seed-base 1000 --seed-mod 1024 --async-fill
+    bench h20_${n}_r4_async CROWDNAV_AMD_LIB=$lib -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 2000 --warmup 500 --chunk 1000 --preroll 100 --seed-base 1000 --seed-mod 1021 --async-fill
     ( export CROWDNAV_AMD_LIB=$lib; timeout 120 python scripts/reset_probe.py 22 2>&1 | grep "reset ms" | sed "s/^/$n: /" | tee -a $OUT/reset_probe.txt )
   done
   for envs in ${CN_H20_ENVS:-}; do bench h20_intree_r12_envs$envs -- --no-cpu-baseline --humans 20 --circle-radius 12 --envs $envs --steps 1500 --warmup 500 --chunk 500; done ;;
