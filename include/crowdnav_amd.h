@@ -203,7 +203,9 @@ int cn_set_gamma(cn_engine* e, double gamma);
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io);
 /* replaces the `while not done: action = robot.act(ob); env.step(action)` loop of
  * Explorer.run_k_episodes (explorer.py:41-48) for an on-device robot policy (robot_policy ==
- * CN_ROBOT_ORCA): n_steps transitions per active env in ONE launch, with in-kernel auto-reset. */
+ * CN_ROBOT_ORCA): n_steps transitions per active env in ONE call, with in-kernel auto-reset.  (A call is one kernel launch,
+ * except for 20-human crowds of 4096 and more envs, where calls of 48 and more steps are split into up to five launches on the
+ * engine's stream — groups of envs taking turns, every env making its n_steps transitions in order; results are the same.) */
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
 
 /* ------------------------------------------------------------------------------------------------------
