@@ -40,6 +40,8 @@ def main():
     extra = [a for a in sys.argv[1:] if a.startswith('-D')]
     pat = re.compile(args[0]) if args else None
     rows = report(extra)
+    if not rows:
+        sys.exit('no kernel resource remarks: the compile failed (run the hipcc command by hand to see why)')
     names = demangle([r['name'] for r in rows])
     print('%-52s %5s %5s %5s %7s %7s %8s %4s %7s' % ('kernel', 'SGPR', 'VGPR', 'AGPR', 'sp.SGPR', 'sp.VGPR', 'scratch', 'occ', 'LDS'))
     for r, n in zip(rows, names):
