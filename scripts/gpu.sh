@@ -6,6 +6,7 @@
 #   bench                 bench.py default shape (1000-step launches) + the driver's shape (--steps 20 --warmup 5), with secondary
 #   bench32k, benchh20    other headline-kernel sizes
 #   ab                    bench lines of every build/exp/lib_ab_*.so against the in-tree library, both shapes
+#   h20ab                 the same for the 20-human shard (12 m circle, 4 m circle with the asynchronous fill), reset probe, LDS granule
 #   probe                 shader-clock phase probes of build/exp/lib_timing.so (5 and 20 humans), launch probe
 #   sarl                  cn_sarl_select timing (scripts/sarl_bench.py) for the in-tree library and build/exp/lib_ab_sarl*.so
 #   trace                 rocprofv3 --kernel-trace --stats of both bench shapes and the SARL decision
@@ -81,7 +82,7 @@ pmc)
   declare -A CMD
   CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary"
   CMD[driver]="$REPO/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5"
-  # (h20 counters: one dispatch per call - the 3-of-4 env schedule off - so that a dispatch is 4096 envs x 500 steps)
+  # (h20 counters: one dispatch per call - the 3-of-4 env schedule off - so that a dispatch is 4096 envs x 501 steps)
   CMD[h20]="$REPO/bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1503 --warmup 501 --chunk 501"
   for shape in ${CN_PMC_SHAPES:-default driver h20}; do
     [ $shape = h20 ] && export CROWDNAV_AMD_SCHED_MIN_STEPS=1000000000 || unset CROWDNAV_AMD_SCHED_MIN_STEPS
