@@ -75,3 +75,43 @@ def test_env_schedule_with_asynchronous_fill(amd, oracle_mod):
     ran = _np(bufs['ep_steps']).astype(np.int64)
     per_env = np.array([ran[b, :cnt[b]].sum() for b in range(B)]) + _np(bufs['cur_steps'])
     assert int(_np(bufs['transitions'])[0]) == per_env.sum()
+
+
+def test_shard_kernel_with_external_robot_actions(amd, oracle_mod):
+    """cn_rollout_step on the 20-human geometry — the value-network rollouts' transition: one bookkept step per call, the
+    robot's action from outside — runs the same compact-layout kernel (never the schedule: one step per call).  150 calls,
+    every env through several episodes, against the oracle stepped and reset by hand."""
+    import torch
+    n, steps, K = 12, 150, 64
+    cfg = dict(num_humans=20, robot_visible=1, circle_radius=5.0)
+    eng = amd.BatchedCrowdSim(num_envs=n, robot_policy=amd.ROBOT_EXTERNAL, **cfg)
+    bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, record_capacity=K)
+    o = oracle_mod.CrowdOracle(num_envs=n, robot_policy=0, **cfg)
+    o.reset(1000 + np.arange(n))
+    ep, cur = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    rec_steps, rec_outcome = [[] for _ in range(n)], [[] for _ in range(n)]
+    rng = np.random.RandomState(5)
+    for _ in range(steps):
+        s = o.get_state()[0]
+        to_goal = s[:, 0, 4:6] - s[:, 0, 0:2]
+        act = to_goal / np.maximum(np.linalg.norm(to_goal, axis=1, keepdims=True), 1.0) + rng.uniform(-0.3, 0.3, (n, 2))
+        eng.rollout_step(torch.from_numpy(act))
+        out = o.step(act, update=True)
+        cur += 1
+        done = out['done'] != 0
+        for b in np.nonzero(done)[0]:
+            rec_steps[b].append(int(cur[b]))
+            rec_outcome[b].append(int(out['info'][b]))
+        ep += done
+        cur[done] = 0
+        if done.any():
+            o.reset(1000 + (np.arange(n) + ep * n) % 500, mask=done.astype(np.uint8))
+    eng.sync()
+    assert ep.min() >= 2
+    assert int(_np(bufs['transitions'])[0]) == n * steps
+    assert np.array_equal(_np(bufs['ep_count']), ep) and np.array_equal(_np(bufs['cur_steps']), cur)
+    got_steps, got_out = _np(bufs['ep_steps']), _np(bufs['ep_outcome'])
+    for b in range(n):
+        k = len(rec_steps[b])
+        assert got_steps[b, :k].tolist() == rec_steps[b] and got_out[b, :k].tolist() == rec_outcome[b]
+    assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
