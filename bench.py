@@ -353,7 +353,7 @@ def measure_h20(B, local_rank):
         'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47, 47, 47], refill_before_each=True),
         # (launch lengths divisible by three: the shard kernel's 3-of-4 env schedule splits a call of 3 q + r steps into four
         # launches of q steps and one of r over all envs, crowdnav_amd.hip: launch_rollout)
-        'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [200, 501], [501, 501, 501]),
+        'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [201, 999], [999, 999, 999]),
         'episode_seeds_r4': '%d + c %% %d' % seeds,
         'note': 'r4_async_fill: resets included, six 999-step launches back to back under one event pair (envs whose next '
                 'scenario is not ready pause: paused_env_steps); '

@@ -47,7 +47,7 @@ PY
   ;;
 bench32k) bench bench_32k -- --no-cpu-baseline --no-secondary --envs 32768 --steps 4000 ;;
 benchh20)
-  bench bench_h20_r12 -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 2004 --warmup 501 --chunk 501
+  bench bench_h20_r12 -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 3996 --warmup 999 --chunk 999
   bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill ;;
 ab)
   for lib in "" $REPO/build/exp/lib_ab_*.so; do
