@@ -14,12 +14,13 @@ start their first episode in lock step, so without it a short run would time a s
 ends; after it the episodes are spread over all phases and the timed steps contain their share of episode ends and
 auto-resets (`episodes_finished`).
 
-The timed region is the step path: the K batched steps, whose rollout launches also leave the shard's episode statistics
-(explorer.py:74-90) and record blocks behind (their last workgroup; no boundary kernel).  Multi-GPU: the env axis is sharded
-(weak scaling: 4096 envs per GPU, global env ids offset by rank, no collective on the step path); every rank times its own K
-steps between a barrier + synchronize on both sides, value = all ranks' transitions / the slowest rank's time; the one
-exchange of a job — the all-gather (RCCL) of the per-env record blocks + the job-wide summary kernel at the END of a run —
-is timed separately as `boundary_ms` (and `value_incl_boundary` charges it to these K steps).  The JSON line also carries
+The timed region is the step path: the K batched steps — transitions, in-kernel auto-resets, the per-episode records and the
+per-env transition counters.  The env axis is sharded over the GPUs (weak scaling: 4096 envs per GPU, global env ids offset
+by rank, no collective on the step path); every rank times its own K steps between a barrier + synchronize on both sides,
+value = all ranks' transitions / the slowest rank's time.  What a run does ONCE when it ends — the job-wide statistics of
+explorer.py:74-90 (the reference computes them after its episode loop), i.e. the record blocks of every shard, on several GPUs
+their all-gather (RCCL), and the summary kernel — is the shard boundary: timed separately as `boundary_ms` AT EVERY WORLD SIZE,
+1 included (and `value_incl_boundary` charges it to these K steps).  The JSON line also carries
 `roofline` (algorithmic bytes of the dominant kernel over its HIP-event duration), `issue_roofline` (the bound that
 actually limits this kernel, only when the committed PMC profile is of the same launch shape) and, at N=1, `cpu_baseline`
 (the CPU oracle timed on this host's cores on a bounded sample of the same workload; + the unmodified reference Python
@@ -575,14 +576,19 @@ def main():
                                        robot_visible=1, device=local_rank, circle_radius=args.circle_radius,
                                        flags=crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL if args.async_fill else 0)
     # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply.
-    # boundary_records=1: every rollout launch leaves the shard's explorer.py:74-90 sums (bufs['summary']) and one record
-    # block per env (bufs['blocks'], 56 B per env: the all-gather's input) behind — its own last workgroup, no extra kernel
-    # record_capacity = boundary_records: the shard's own in-kernel summary (single GPU) and the summary of the gathered blocks
-    # (sharded) are then the same statistic — over each env's most recent finished episode — whatever the world size
-    # (tests/test_bench_multirank.py compares the two through this script)
+    # The timed region is the K steps: transitions, auto-resets, per-episode records.  The job-wide statistics
+    # (explorer.py:74-90: the reference computes them ONCE, after its episode loop) and the record exchange belong to the
+    # shard boundary, timed separately as boundary_ms at every world size: a launch counts its transitions per env
+    # (per_env_transitions, ABI v6) and ends without any hand-off between its workgroups — no in-kernel summary / blocks
+    # (boundary_records = 0), which were ~9 us of the last wave's tail in every launch of the driver's 20-step shape.
+    # record_capacity = RECORDS on every path: the summary of one engine and of the gathered shards is then the same
+    # statistic — over each env's most recent finished episode — whatever the world size (tests/test_bench_multirank.py)
+    # (CROWDNAV_AMD_BENCH_INKERNEL_STATS=1: round 3's arrangement for A/B runs — every launch leaves the job-wide counter,
+    # the summary and the record blocks behind itself)
+    inkernel = os.environ.get('CROWDNAV_AMD_BENCH_INKERNEL_STATS') == '1'
     bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=RECORDS,
                              env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1],
-                             boundary_records=RECORDS)
+                             boundary_records=RECORDS if inkernel else 0, per_env_transitions=not inkernel)
 
     # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
     # inside the timed region costs more host time than a 20-step launch's enqueue
@@ -596,9 +602,7 @@ def main():
         ev.record()
 
     def run(n_steps, events=None):
-        left = n_steps
-        if events is not None:
-            pool[0].record()
+        left = n_steps  # (events: the caller has recorded pool[0] on the idle stream, in front of its clock)
         while left > 0:
             n = min(args.chunk, left)
             eng.rollout(n)
@@ -621,22 +625,30 @@ def main():
         comm.barrier()
 
     def shard_boundary():
-        """What a run does ONCE, when it ends (explorer.py:74): single GPU - nothing, the last launch has written the
-        statistics; sharded - the record blocks of every rank (one RCCL all-gather of 56 B per env) and the job-wide
-        summary of explorer.py:74-90 (one kernel): float64 [8] on the device"""
-        if world == 1:
+        """What a run does ONCE, when it ends (explorer.py:74-90): the record blocks of this shard (cn_rollout_records), on
+        several GPUs the blocks of every rank (one RCCL all-gather of 56 B per env), and the job-wide summary
+        (cn_records_summary: one kernel): float64 [8] on the device"""
+        if inkernel and world == 1:
             return bufs['summary']
-        return eng.records_summary(cd.gather_blocks(bufs['blocks']), record_capacity=RECORDS)
+        blocks = bufs['blocks'] if inkernel else eng.rollout_records(RECORDS)
+        if world > 1:
+            blocks = cd.gather_blocks(blocks)
+        return eng.records_summary(blocks, record_capacity=RECORDS)
+
+    def snapshot():
+        """device copies of the shard's counters (transitions, episodes finished per env): asynchronous, no host round trip —
+        whatever the host does between the warm-up launches and the timed ones is device idle time in front of a 120 us launch"""
+        return (bufs['transitions'] if inkernel else bufs['env_transitions']).clone(), bufs['ep_count'].clone()
 
     run(args.preroll)
+    shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
     gc.collect()  # (before the warm-up launches: see no_gc)
     run(args.warmup)
-    shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
-    fence()
-    before = int(bufs['transitions'].item())
-    ep_before = float(bufs['summary'][0].item())
+    snap_t, snap_e = snapshot()
     events = []
-    fence()  # barrier + synchronize
+    fence()  # barrier + synchronize ...
+    fence()  # ... twice: the first drains the warm-up launches and the snapshot copies, the second finds an idle device
+    pool[0].record()  # opens the first timed launch's event span (an idle stream stamps it at once)
     with no_gc():
         t0 = time.perf_counter()
         run(args.steps, events)
@@ -646,10 +658,10 @@ def main():
     tb = time.perf_counter()
     summary = shard_boundary()
     drain()
-    boundary = time.perf_counter() - tb if world > 1 else 0.0
-    own_episodes = float(bufs['summary'][0].item()) - ep_before
-
-    transitions = int(bufs['transitions'].item()) - before
+    boundary = time.perf_counter() - tb
+    now_t, now_e = snapshot()
+    own_episodes = int((now_e - snap_e).sum().item())
+    transitions = int((now_t - snap_t).sum().item())
     # an env whose 48-deep scenario ring ran dry inside one launch pauses until the next launch; count what ran
     paused_env_steps = B * args.steps - transitions
     per_rank = comm.all_gather({'rank': rank, 'transitions': transitions, 'seconds': elapsed, 'boundary_seconds': boundary})
@@ -680,18 +692,21 @@ def main():
                    'episode_seeds': '%d + c %% %d' % (args.seed_base, args.seed_mod),
                    'scenario_fill': 'asynchronous (side streams, per-slot ready flags)' if args.async_fill else 'before each launch',
                    'preroll_steps': args.preroll,
-                   'parallelism': 'env-axis shards x%d, no collective on the step path; one all-gather of episode records '
-                                  'when a run ends (boundary_ms)' % world,
+                   'parallelism': 'env-axis shards x%d, no collective on the step path; the job-wide statistics (record blocks, '
+                                  'their all-gather on several GPUs, summary kernel) once when a run ends (boundary_ms)' % world,
                    'backend': backend if world > 1 else None, 'shared_gpu': share_gpu},
         'ranks': per_rank,
         'summary': s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof) if fresh else None,
                      'traffic_from': src if fresh else None,
-                     'kernel': 'cn::rollout_fused_kernel (one cn_rollout call incl. its in-kernel statistics epilogue; + '
-                               'cn::ring_fill_kernel when the scenario ring needs topping up)' if H <= 5 else
+                     'kernel': 'cn::rollout_fused_kernel (one cn_rollout call; + cn::ring_fill_kernel when the scenario ring needs '
+                               'topping up)' if H <= 5 else
                                'cn::rollout_kernel<10> (+ cn::ring_fill_wave_kernel)',
                      'avg_launch_ms': avg_launch_s * 1e3,
+                     'avg_launch_ms_note': 'HIP-event span per cn_rollout call; the opening event is recorded on the idle stream '
+                                           'just before the host clock starts, so the span of the first launch includes the '
+                                           'host\'s enqueue latency and can exceed ms_per_step x steps by a few us',
                      'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(H)},
         'issue_roofline': pmc_issue(prof, B, steps_per_launch, avg_launch_s),
         'boundary_ms': boundary * 1e3,

@@ -1679,7 +1679,11 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
             rec[5] = (have && io.ep_danger_dmin_sum) ? io.ep_danger_dmin_sum[k] : 0.0;
         }
     }
+    if (robot && io.env_transitions) io.env_transitions[L.env] += (uint64_t)transitions;  // (ABI v6) this env's own counter
     const bool want = io.summary != nullptr;  // uniform over the launch
+    // nothing job-wide asked for: the launch ends here — no partial sums, no arrival tickets, no hand-off between workgroups
+    // (eight dependent memory round trips of the LAST wave, ~9 of the 113 us of a 20-step launch)
+    if (!want && io.transitions == nullptr) return;
     if (robot) {  // this env's sums over its record ring (cn_records_summary's fields) + its transitions
         double acc[F] = {};
         acc[F - 1] = (double)transitions;

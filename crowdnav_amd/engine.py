@@ -180,13 +180,17 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_set_gamma(self._h, float(gamma)))
 
     def rollout_begin(self, seed_base, seed_mod, episode_limit=-1, record_capacity=8, env_offset=0,
-                      env_stride=None, boundary_records=0):
+                      env_stride=None, boundary_records=0, per_env_transitions=False):
         """Start Explorer-style episode bookkeeping: env b runs global episodes b, b+B, b+2B, ... (< limit),
         episode c seeded with seed_base + c % seed_mod.  A shard of a larger job passes its first global env
         id as env_offset and the global env count as env_stride.
         boundary_records = K > 0: every rollout launch also leaves the shard-boundary outputs itself (its last workgroup):
         bufs['summary'] float64 [8] (what records_summary() returns for this engine) and bufs['blocks'] float64
-        [B, 1 + 6 K] (what rollout_records(K) returns) — no boundary kernels on a single GPU, only the all-gather on many."""
+        [B, 1 + 6 K] (what rollout_records(K) returns) — no boundary kernels on a single GPU, only the all-gather on many.
+        per_env_transitions (ABI v6): instead of the ONE job-wide counter bufs['transitions'] every launch adds up (arrival
+        tickets between the workgroups at the end of every launch), each env counts its own transitions in
+        bufs['env_transitions'] int64 [B] and a launch ends without any hand-off — with boundary_records = 0 the statistics are
+        then computed once, when the caller asks (rollout_records + records_summary), as explorer.py:74-90 does."""
         B, K = self.B, int(record_capacity)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
         bufs = dict(
@@ -195,7 +199,11 @@ class BatchedCrowdSim(object):
             ep_danger_dmin_sum=z((B, K), torch.float64),
             ep_count=z((B,), torch.int32), cur_steps=z((B,), torch.int32), cur_return=z((B,), torch.float64),
             cur_danger=z((B,), torch.int32), cur_danger_dmin_sum=z((B,), torch.float64),
-            active=z((B,), torch.uint8), transitions=z((1,), torch.int64))
+            active=z((B,), torch.uint8))
+        if per_env_transitions:
+            bufs['env_transitions'] = z((B,), torch.int64)
+        else:
+            bufs['transitions'] = z((1,), torch.int64)
         Kb = int(boundary_records)
         if Kb > 0:
             bufs['summary'] = z((_lib.SUMMARY_FIELDS,), torch.float64)

@@ -9,15 +9,18 @@ class SarlRollout(object):
                  record_capacity=8):
         self.eng = eng
         eng.set_gamma(gamma)
+        # one bookkept step per launch: the transitions are counted per env (ABI v6), so that a launch ends without the
+        # hand-off between its workgroups that a job-wide counter costs (~9 us behind a ~20 us cn_rollout_step launch)
         self.bufs = eng.rollout_begin(seed_base=seed_base, seed_mod=seed_mod, episode_limit=episode_limit,
-                                      record_capacity=record_capacity, env_offset=env_offset, env_stride=env_stride)
+                                      record_capacity=record_capacity, env_offset=env_offset, env_stride=env_stride,
+                                      per_env_transitions=True)
         b = self.bufs
         self.rec = dict(outcome=b['ep_outcome'], steps=b['ep_steps'], ret=b['ep_return'], time=b['ep_time'],
                         danger=b['ep_danger'], dsum=b['ep_danger_dmin_sum'])
 
     @property
     def transitions(self):
-        return self.bufs['transitions'][0]
+        return self.bufs['env_transitions'].sum()
 
     @property
     def ep_count(self):

@@ -192,6 +192,11 @@ typedef struct cn_rollout_io {
     double* summary;       /* [CN_SUMMARY_FIELDS] the numbers of cn_records_summary over THIS engine's record rings */
     double* blocks;        /* [B][CN_RECORD_BLOCK_DOUBLES(blocks_records)] what cn_rollout_records(blocks_records) packs */
     int32_t blocks_records; /* >= 1 when blocks != NULL */
+    /* (ABI v6) per-env transition counters, [B], optional: env b's entry grows by the transitions env b made in the call.
+     * With `transitions` and `summary` both NULL a launch ends WITHOUT any hand-off between workgroups (no arrival tickets: ~9 us
+     * of the last wave's tail): whoever wants a job-wide number sums this array, and computes the statistics once per run with
+     * cn_rollout_records + cn_records_summary — which is when explorer.py:74-90 computes them. */
+    uint64_t* env_transitions;
 } cn_rollout_io;
 
 /* discount table used for ep_return: gamma^(t * time_step * robot_v_pref), computed on the host with libm

@@ -42,7 +42,8 @@ def test_struct_layouts_match_header(built):
     assert built.CnConfig.time_step.offset == 8 and built.CnConfig.neighbor_dist.offset == 80
     assert built.CnConfig.device.offset == C.sizeof(built.CnConfig) - 12
     assert built.CnConfig.robot_kinematics.offset == C.sizeof(built.CnConfig) - 8
-    assert C.sizeof(built.CnRolloutIo) == 8 + 8 + 8 + 8 + 8 + 13 * 8 + 2 * 8 + 8  # v5: + summary, blocks, blocks_records (+ pad)
+    assert C.sizeof(built.CnRolloutIo) == 8 + 8 + 8 + 8 + 8 + 13 * 8 + 2 * 8 + 8 + 8  # v5: + summary, blocks, blocks_records (+ pad); v6: + env_transitions
+    assert built.CnRolloutIo.env_transitions.offset == 168
     assert built.CnRolloutIo.summary.offset == 144 and built.CnRolloutIo.blocks_records.offset == 160
     assert C.sizeof(built.CnSarlConfig) == 16 + 16 + 4 + 8 + 8 + 12 + 16 + 4 + 16 + 4 + 8  # 112: ints, 2 doubles, dims, pad, model flags
 

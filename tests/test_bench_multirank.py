@@ -62,7 +62,7 @@ def test_two_ranks_sharing_one_gpu_orca():
     # sharding invariance through the real script: ONE engine with all 8192 envs (global env ids 0..8191, the same episode
     # seeds) leaves the same job-wide statistics as the two shards' gathered record blocks
     one = _run(['--gpus', '1', '--envs', '8192'] + flags)
-    assert one['n_gpus'] == 1 and one['boundary_ms'] == 0.0
+    assert one['n_gpus'] == 1 and one['boundary_ms'] > 0.0  # the statistics are a boundary at every world size
     assert one['episodes_finished'] == two['episodes_finished'] > 0
     assert sum(r['transitions'] for r in one['ranks']) == total
     s1, s2 = one['summary'], two['summary']

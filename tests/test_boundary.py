@@ -205,3 +205,36 @@ def test_asynchronous_scenario_fill_changes_timing_not_trajectories(amd, oracle_
     # the synchronous engine on the same seeds: identical to the oracle transition for transition
     eng2, bufs2 = _rollout(amd, B, [n] * launches, K=K, **{k: v for k, v in cfg.items() if k != 'robot_visible'})
     assert int(_np(bufs2['transitions'])[0]) == B * launches * n and np.array_equal(_np(bufs2['ep_count']), rec['count'])
+
+
+@pytest.mark.parametrize('B,H,R,launches', [(300, 5, 4.0, [20, 1, 100]), (37, 20, 9.0, [60, 45]), (16, 20, 9.0, [48, 90])])
+def test_per_env_transition_counters_and_statistics_on_request(amd, monkeypatch, B, H, R, launches):
+    """ABI v6 (`cn_rollout_io.env_transitions`): with neither the job-wide counter nor the in-kernel summary requested, a
+    launch ends without any hand-off between its workgroups; every env counts its own transitions, and the statistics computed
+    on request (cn_rollout_records + cn_records_summary) equal what the launches of a second, identical run left behind
+    themselves (rollout_epilogue) — counts exactly, float sums to rounding; the episodes are the same ones bit for bit.  Also
+    through the 20-human shard's 3-of-4 env schedule (forced on 16 envs)."""
+    import torch
+    monkeypatch.setenv('CROWDNAV_AMD_SCHED_FORCE', '1')
+    K = 4
+
+    def run(per_env):
+        eng = amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=amd.ROBOT_ORCA, robot_visible=1, circle_radius=R)
+        bufs = eng.rollout_begin(seed_base=1000, seed_mod=500, episode_limit=-1, record_capacity=K,
+                                 boundary_records=0 if per_env else 2, per_env_transitions=per_env)
+        for n in launches:
+            eng.rollout(n)
+        eng.sync()
+        return eng, bufs
+
+    eng, bufs = run(True)
+    assert 'transitions' not in bufs and 'summary' not in bufs
+    assert torch.equal(bufs['env_transitions'], torch.full((B,), sum(launches), dtype=torch.int64, device=bufs['env_transitions'].device))
+    eng2, bufs2 = run(False)
+    assert int(_np(bufs2['transitions'])[0]) == B * sum(launches)
+    for k in ('ep_count', 'ep_outcome', 'ep_steps', 'ep_return', 'cur_steps', 'cur_return'):
+        assert torch.equal(bufs[k], bufs2[k]), k
+    got = _np(eng.records_summary(eng.rollout_records(), record_capacity=K))
+    want = _np(bufs2['summary'])
+    assert np.array_equal(got[:5], want[:5]) and got[7] == want[7] and got[0] == _np(bufs['ep_count']).sum() > 0
+    assert np.abs(got[5:7] - want[5:7]).max() <= 1e-9 * max(1.0, np.abs(want[5:7]).max())
