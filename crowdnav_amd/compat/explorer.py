@@ -120,7 +120,9 @@ class Explorer(object):
             eng = BatchedCrowdSim(**env.engine_config(B, human_num, rule, _lib.ROBOT_ORCA))
             eng.set_gamma(self.gamma)
             self._share_robot_sim(eng, human_num, rule, offset + start)
-            bufs = eng.rollout_begin(seed_base=offset + start, seed_mod=size, episode_limit=k, record_capacity=per_env)
+            # (no job-wide counter, no in-kernel statistics: the records are read once below, as explorer.py:50-90 does)
+            bufs = eng.rollout_begin(seed_base=offset + start, seed_mod=size, episode_limit=k, record_capacity=per_env,
+                                     per_env_transitions=True)
             while True:
                 eng.rollout(max_steps)
                 if int(bufs['active'].sum().item()) == 0:
