@@ -625,11 +625,11 @@ def main():
         comm.barrier()
 
     def shard_boundary():
-        """What a run does ONCE, when it ends (explorer.py:74-90): the record blocks of this shard (cn_rollout_records), on
-        several GPUs the blocks of every rank (one RCCL all-gather of 56 B per env), and the job-wide summary
-        (cn_records_summary: one kernel): float64 [8] on the device"""
-        if inkernel and world == 1:
-            return bufs['summary']
+        """What a run does ONCE, when it ends (explorer.py:74-90): on one GPU the summary of the engine's record rings
+        (cn_rollout_summary: one kernel); on several the record blocks of this shard (cn_rollout_records), the blocks of every
+        rank (one RCCL all-gather of 56 B per env) and the job-wide summary (cn_records_summary): float64 [8] on the device"""
+        if world == 1:  # one engine: straight from its record rings (cn_rollout_summary, one kernel)
+            return bufs['summary'] if inkernel else eng.rollout_summary()
         blocks = bufs['blocks'] if inkernel else eng.rollout_records(RECORDS)
         if world > 1:
             blocks = cd.gather_blocks(blocks)

@@ -108,6 +108,7 @@ SYMBOLS = {
     'cn_rollout_records': (C.c_int, [_P, C.POINTER(CnRolloutIo), C.c_int, _P]),
     'cn_gather_records': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     'cn_records_summary': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    'cn_rollout_summary': (C.c_int, [_P, C.POINTER(CnRolloutIo), _P]),
     'cn_mt_random': (C.c_int, [_P, C.c_uint32, C.c_int, _P]),
 }
 

@@ -56,21 +56,42 @@ constexpr int kSummaryFields = CN_SUMMARY_FIELDS;
 // workgroup order: the same bits for the same input on every run and every rank, without a second launch.
 //   scratch: double [kSummaryBlocks][8] followed by one unsigned ticket counter (zero before the first launch; the
 //   last workgroup leaves it zero again)
-__global__ __launch_bounds__(kSummaryThreads) void records_summary_kernel(int64_t n_envs, int K, int capacity,
-                                                                          const double* blocks, double* summary,
-                                                                          double* scratch) {
+// Where a record comes from: packed blocks (a shard's own or the gathered ones) ...
+struct BlockRecords {
+    const double* blocks;
+    size_t stride;
+    __device__ void get(int64_t b, int j, double& n, double& outcome, double& ret, double& time, double& danger) const {
+        const double* blk = blocks + (size_t)b * stride;
+        const double* r = blk + 1 + (size_t)j * kRecordFields;
+        n = blk[0], outcome = r[0], ret = r[2], time = r[3], danger = r[4];
+    }
+};
+// ... or the engine's own record rings, straight from the rollout io block (cn_rollout_summary: a single engine needs no blocks)
+struct RingRecords {
+    const cn_rollout_io* io;
+    __device__ void get(int64_t b, int j, double& n, double& outcome, double& ret, double& time, double& danger) const {
+        const size_t k = (size_t)b * io->record_capacity + j;
+        n = (double)io->ep_count[b];
+        outcome = io->ep_outcome ? (double)io->ep_outcome[k] : 0.0;
+        ret = io->ep_return ? io->ep_return[k] : 0.0;
+        time = io->ep_time ? io->ep_time[k] : 0.0;
+        danger = io->ep_danger ? (double)io->ep_danger[k] : 0.0;
+    }
+};
+
+template <class Records>
+__global__ __launch_bounds__(kSummaryThreads) void records_summary_kernel(int64_t n_envs, int K, int capacity, Records src,
+                                                                          double* summary, double* scratch) {
     __shared__ double part[kSummaryFields][kSummaryThreads];
     __shared__ unsigned ticket;
     double acc[kSummaryFields] = {};
     const int64_t items = n_envs * K;
-    const size_t stride = record_block_doubles(K);
     for (int64_t it = (int64_t)blockIdx.x * kSummaryThreads + threadIdx.x; it < items;
          it += (int64_t)kSummaryBlocks * kSummaryThreads) {
         const int64_t b = it / K;
         const int j = (int)(it - b * K);
-        const double* blk = blocks + (size_t)b * stride;
-        const double* r = blk + 1 + (size_t)j * kRecordFields;
-        const double n = blk[0], r0 = r[0], r2 = r[2], r3 = r[3], r4 = r[4];
+        double n, r0, r2, r3, r4;
+        src.get(b, j, n, r0, r2, r3, r4);
         const bool held = (double)j < n && j < capacity;
         const int outcome = (int)r0;
         if (j == 0) acc[0] += n;

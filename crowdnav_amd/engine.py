@@ -260,6 +260,15 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_records_summary(self._h, int(blocks.shape[0]), K, cap, _ptr(blocks), _ptr(out)))
         return out
 
+    def rollout_summary(self):
+        """records_summary(rollout_records()) of this engine in ONE kernel, straight from its record rings (cn_rollout_summary):
+        the statistics of explorer.py:74-90 for a run on one engine."""
+        if self._rollout is None:
+            raise RuntimeError('call rollout_begin() first')
+        out = self._new((_lib.SUMMARY_FIELDS,), torch.float64)
+        check(self._lib.cn_rollout_summary(self._h, C.byref(self._rollout[0]), _ptr(out)))
+        return out
+
     def gather_records_rccl(self, comm, n_ranks, blocks):
         """All-gather the record blocks of every rank over the caller's RCCL communicator (`comm`: the ncclComm_t as an
         integer, see crowdnav_amd.rccl) on the engine's stream (cn_gather_records): [n_ranks * B, 1 + 6 K]."""

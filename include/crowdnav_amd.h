@@ -330,6 +330,9 @@ int cn_gather_records(cn_engine* e, void* rccl_comm, int n_ranks, int max_record
  * are quotients of these). */
 int cn_records_summary(cn_engine* e, int64_t n_envs, int max_records, int record_capacity, const double* blocks,
                        double* summary);
+/* (ABI v6) the same numbers for THIS engine's own record rings, without packing blocks first: what a single-engine run calls
+ * where explorer.py:74 starts (bitwise equal to cn_records_summary over cn_rollout_records(record_capacity)). */
+int cn_rollout_summary(cn_engine* e, const cn_rollout_io* io, double* summary);
 
 /* numpy legacy RNG probe (np.random.seed(seed); n × np.random.random()): out double [n].  For tests. */
 int cn_mt_random(cn_engine* e, uint32_t seed, int n, double* out);

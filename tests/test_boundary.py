@@ -235,6 +235,7 @@ def test_per_env_transition_counters_and_statistics_on_request(amd, monkeypatch,
     for k in ('ep_count', 'ep_outcome', 'ep_steps', 'ep_return', 'cur_steps', 'cur_return'):
         assert torch.equal(bufs[k], bufs2[k]), k
     got = _np(eng.records_summary(eng.rollout_records(), record_capacity=K))
+    assert torch.equal(eng.rollout_summary(), eng.records_summary(eng.rollout_records(), record_capacity=K))  # same bits, one kernel
     want = _np(bufs2['summary'])
     assert np.array_equal(got[:5], want[:5]) and got[7] == want[7] and got[0] == _np(bufs['ep_count']).sum() > 0
     assert np.abs(got[5:7] - want[5:7]).max() <= 1e-9 * max(1.0, np.abs(want[5:7]).max())
