@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
-REFERENCE_PYTHON_PROFILE = os.path.join(ROOT, 'profiles', 'r03_reference_python.json')
+REFERENCE_PYTHON_PROFILE = os.path.join(ROOT, 'profiles', 'r05_reference_python.json')
 
 
 def algorithmic_bytes_per_env_step(H):
@@ -180,7 +180,6 @@ def pmc_provenance():
 
 
 # the sources of the rollout kernels (what roofline.traffic / issue_roofline describe); the value-network kernels live elsewhere
-RECORDS = 1  # episode records kept per env by the ORCA workload (ring capacity = records per boundary block)
 ROLLOUT_SOURCES = ('kd_order.h', 'orca_device.h', 'rollout_fused.h', 'scenario_device.h', 'scenario_wave.h', 'step_kernels.h')
 
 
@@ -296,7 +295,7 @@ def bench_sarl(args, world, rank, local_rank, comm):
 def measure_h20(B, local_rank):
     """BASELINE configs[3]'s shard on one GPU: 4096 envs x 20 humans (rollout_kernel<10>, one env per wave).  Three figures:
     the reference geometry (4 m circle, where the reference's rejection sampling makes RESETS the bound) with the
-    asynchronous scenario fill, resets included; the same geometry with resets excluded (47-step launches inside the
+    asynchronous scenario fill, resets included; the same geometry with resets excluded (thirty 47-step launches inside the
     48-episode ring budget, the fill launch before each of them untimed); and the 12 m circle, where resets are cheap."""
     import torch
     import crowdnav_amd
@@ -351,7 +350,7 @@ def measure_h20(B, local_rank):
     return {
         'workload': '%d envs x %d humans per GPU, ORCA humans + ORCA robot, cn::rollout_kernel<10>' % (B, H),
         'r4_async_fill': one(4.0, crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL, seeds[0], seeds[1], [501], [999] * 6),
-        'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47, 47, 47], refill_before_each=True),
+        'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47] * 30, refill_before_each=True),
         # (launch lengths divisible by three: the shard kernel's 3-of-4 env schedule splits a call of 3 q + r steps into four
         # launches of q steps and one of r over all envs, crowdnav_amd.hip: launch_rollout)
         'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [201, 999], [999, 999, 999]),
@@ -455,15 +454,7 @@ def cpu_baseline(envs, humans, target_seconds=8.0):
     steps1 = max(20, int(0.4 * target_seconds * n / dt / envs))
     n_one, dt_one = run(1, steps1)
     crowd_oracle.CrowdOracle.set_threads(cores)
-    # north_star: "next to the reference Python-RVO2 CPU path": the unmodified reference loop cannot run on the GPU box
-    # (/root/reference does not travel); its timing in the build container is committed by oracle/time_reference_python.py
-    ref_py = None
-    ref_path = REFERENCE_PYTHON_PROFILE
-    if os.path.exists(ref_path):
-        r = json.load(open(ref_path))
-        ref_py = {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'],
-                  'host': r['host_cpu'] + ' (build container, NOT this host)',
-                  'note': r['what'] + '; on the float32 rvo2 restatement; profiles/r03_reference_python.json'}
+    ref_py = reference_python_baseline()
     return {
         'reference_python': ref_py,
         'value': n_all / dt_all, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
@@ -472,6 +463,223 @@ def cpu_baseline(envs, humans, target_seconds=8.0):
                   'all cores' % (envs, humans, steps, dt_all),
         'single_core_value': n_one / dt_one,
     }
+
+
+def ring_depth():
+    """depth of an engine's scenario ring (cn_create reads the same variable; default 48 episodes ahead of every env)"""
+    return max(1, int(os.environ.get('CROWDNAV_AMD_RING_DEPTH') or 48))
+
+
+def measure_fill_seconds(eng, depth):
+    """What ONE steady-state top-up of the scenario ring costs: 1-step calls with a HIP-event pair each, classified by the
+    engine's own launch counters into calls that carried a fill (one per `depth` steps: it regenerates the slots consumed since
+    the previous one) and calls that did not; the difference of the medians.  Device time on the engine's stream."""
+    import torch
+    n = 3 * (depth + 1)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    kinds = []
+    for e0, e1 in evs:
+        before = eng.launch_counts()['ring_fills']
+        e0.record()
+        eng.rollout(1)
+        e1.record()
+        kinds.append(eng.launch_counts()['ring_fills'] > before)
+    torch.cuda.synchronize()
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    with_fill = [a.elapsed_time(b) for (a, b), k in zip(evs, kinds) if k]
+    without = [a.elapsed_time(b) for (a, b), k in zip(evs, kinds) if not k]
+    if not with_fill or not without:
+        return None
+    return max(0.0, med(with_fill) - med(without)) / 1e3
+
+
+def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_probe=True):
+    """One measurement of the ORCA workload on a fresh engine: preroll, warm-up, the K timed steps, the shard boundary.
+    inkernel: round 3's arrangement (every launch leaves the job-wide counter, the explorer.py:74-90 sums and the record
+    blocks itself) instead of ABI v6's (per-env counters, statistics once at the boundary)."""
+    import torch
+    import torch.distributed as dist
+    import crowdnav_amd
+    from crowdnav_amd import distributed as cd
+    B, H, RECORDS = args.envs, args.humans, args.records
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
+                                       robot_visible=1, device=local_rank, circle_radius=args.circle_radius,
+                                       flags=crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL if args.async_fill else 0)
+    # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply.
+    # The timed region is the K steps: transitions, auto-resets, per-episode records.  The job-wide statistics
+    # (explorer.py:74-90: the reference computes them ONCE, after its episode loop) and the record exchange belong to the
+    # shard boundary, timed separately as boundary_ms at every world size: a launch counts its transitions per env
+    # (per_env_transitions, ABI v6) and ends without any hand-off between its workgroups — no in-kernel summary / blocks
+    # (boundary_records = 0), which were ~9 us of the last wave's tail in every launch of the driver's 20-step shape.
+    # record_capacity = --records (default 1) on every path: the summary of one engine and of the gathered shards is then the
+    # same statistic — over each env's most recent finished episode — whatever the world size (tests/test_bench_multirank.py)
+    off, stride = cd.shard(rank, world, B)
+    bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=RECORDS,
+                             env_offset=off, env_stride=stride,
+                             boundary_records=RECORDS if inkernel else 0, per_env_transitions=not inkernel)
+    summary_out = torch.zeros(crowdnav_amd._lib.SUMMARY_FIELDS, dtype=torch.float64, device=eng.device)  # the boundary's output
+    rccl = {'world': dist.get_world_size(), 'backend': dist.get_backend(), 'gathered_rows': None,
+            'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} if world > 1 else None
+
+    # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
+    # inside the timed region costs more host time than a 20-step launch's enqueue
+    # One event in front of the first timed launch and one behind EVERY launch: launch k is timed from the event behind launch
+    # k - 1 to its own (the stream has nothing else in between), and the last of them doubles as the "stream has drained" flag
+    # the host spins on — n + 1 event records in the timed region instead of 2 n + 1 (each is a packet the command processor
+    # handles between the kernels).
+    n_launches = (args.steps + args.chunk - 1) // args.chunk
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 2)]
+    for ev in pool:
+        ev.record()
+
+    def run(n_steps, events=None):
+        left = n_steps  # (events: the caller has recorded pool[0] on the idle stream, in front of its clock)
+        while left > 0:
+            n = min(args.chunk, left)
+            eng.rollout(n)
+            if events is not None:
+                k = len(events)
+                pool[k + 1].record()
+                events.append((pool[k], pool[k + 1], n))
+            left -= n
+
+    def spin(last=None):
+        if last is None:
+            last = pool[-1]
+            last.record()
+        while not last.query():  # spin until the stream has drained: a blocking synchronize alone wakes up late
+            pass
+
+    def drain(last=None):
+        spin(last)
+        torch.cuda.synchronize()
+
+    def fence():
+        drain()
+        comm.barrier()
+
+    def shard_boundary():
+        """What a run does ONCE, when it ends (explorer.py:74-90): on one GPU the summary of the engine's record rings
+        (cn_rollout_summary: one kernel, into the preallocated output); on several the record blocks of this shard
+        (cn_rollout_records), the blocks of every rank (one RCCL all-gather of 56 B per env) and the job-wide summary
+        (cn_records_summary): float64 [8] on the device"""
+        if world == 1:  # one engine: straight from its record rings
+            return bufs['summary'] if inkernel else eng.rollout_summary(out=summary_out)
+        blocks = bufs['blocks'] if inkernel else eng.rollout_records(RECORDS)
+        blocks = cd.gather_blocks(blocks)
+        rccl['gathered_rows'] = int(blocks.shape[0])
+        return eng.records_summary(blocks, record_capacity=RECORDS, out=summary_out)
+
+    def snapshot():
+        """device copies of the shard's counters (transitions, episodes finished per env): asynchronous, no host round trip —
+        whatever the host does between the warm-up launches and the timed ones is device idle time in front of a 120 us launch"""
+        return (bufs['transitions'] if inkernel else bufs['env_transitions']).clone(), bufs['ep_count'].clone()
+
+    run(args.preroll)
+    shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
+    gc.collect()  # (before the warm-up launches: see no_gc)
+    run(args.warmup)
+    snap_t, snap_e = snapshot()
+    events = []
+    fence()  # barrier + synchronize ...
+    fence()  # ... twice: the first drains the warm-up launches and the snapshot copies, the second finds an idle device
+    counts0 = eng.launch_counts()
+    pool[0].record()  # opens the first timed launch's event span (an idle stream stamps it at once)
+    with no_gc():
+        t0 = time.perf_counter()
+        run(args.steps, events)
+        drain(events[-1][1])  # this rank's K steps are done (synchronize) ...
+        elapsed = time.perf_counter() - t0
+    counts1 = eng.launch_counts()
+    comm.barrier()  # ... and every rank's, before anything else is launched
+    with no_gc():
+        tb = time.perf_counter()
+        summary = shard_boundary()
+        spin()  # the event behind the boundary's last kernel has completed: its results are on the device
+        boundary = time.perf_counter() - tb
+    torch.cuda.synchronize()
+    now_t, now_e = snapshot()
+    own_episodes = int((now_e - snap_e).sum().item())
+    transitions = int((now_t - snap_t).sum().item())
+    s = [float(v) for v in summary.cpu().tolist()]
+    event_spans = [(e0.elapsed_time(e1) / 1e3, n) for e0, e1, n in events]
+    fill_s = None
+    if fill_probe and not args.async_fill:
+        fill_s = measure_fill_seconds(eng, ring_depth())
+    per_rank = comm.all_gather({'rank': rank, 'transitions': transitions, 'seconds': elapsed, 'boundary_seconds': boundary})
+    # the slowest rank's K steps, the slowest rank's boundary; transitions of every shard (they differ by the few ring-dry pauses)
+    mx = comm.all_reduce([elapsed, boundary, fill_s if fill_s is not None else -1.0], op='max')
+    total, episodes, fills = (int(v) for v in comm.all_reduce([transitions, own_episodes,
+                                                               counts1['ring_fills'] - counts0['ring_fills']]))
+    eng.sync()
+    eng.close()
+    del eng, bufs
+    torch.cuda.empty_cache()
+    return {'elapsed': mx[0], 'boundary': mx[1], 'fill_s': mx[2] if mx[2] >= 0 else None, 'total': total, 'episodes': episodes,
+            'fills_in_timed_region': fills // world if world > 1 else fills, 'events': event_spans, 'summary': s,
+            'per_rank': per_rank, 'rccl': rccl, 'ring_depth': ring_depth()}
+
+
+def init_distributed(backend, local_rank):
+    """init_process_group + the FIRST collective on a device tensor (RCCL builds its communicator lazily: a transport problem
+    would otherwise surface in the middle of the run).  A failure exits with a message that names the one environment switch
+    this pool is known to need: the host driver supports dmabuf IPC only, and with HSA_ENABLE_IPC_MODE_LEGACY unset or != 0
+    RCCL / device-tensor sharing between processes fails with `hipIpcGetMemHandle: invalid argument`.  (No in-process retry:
+    the HSA runtime reads the variable once, when it initialises, long before a communicator exists.)"""
+    import torch
+    import torch.distributed as dist
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            t = torch.ones(1, dtype=torch.float64, device=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
+            t = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(t)
+        if float(t.item()) != float(dist.get_world_size()):
+            raise RuntimeError('first all-reduce returned %r for a world of %d' % (t.item(), dist.get_world_size()))
+    except Exception as exc:  # noqa: BLE001 (whatever the backend raises: the message is what matters)
+        raise SystemExit(
+            'bench.py: torch.distributed (%s) failed on rank %s of %s: %s: %s\n'
+            'HSA_ENABLE_IPC_MODE_LEGACY is %r in this process; this pool\'s host driver supports dmabuf IPC only, so it must be 0 '
+            '(bench.py sets it with setdefault before the first HIP call and never overrides an exported value). '
+            'If it IS 0 and RCCL still fails, run once with the variable unset to compare.'
+            % (backend, os.environ.get('RANK'), os.environ.get('WORLD_SIZE'), type(exc).__name__, exc,
+               os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')))
+
+
+def reference_python_baseline(cases=250, timeout=240):
+    """north_star: "reported next to the reference Python-RVO2 CPU path timed on the same host (core count stated)".
+    The UNMODIFIED reference's own loop (env.reset / robot.act / env.step, crowd_nav/test.py:86-92 with --policy orca) timed ON
+    THIS HOST, one core, by oracle/time_reference_python.py in a subprocess (the reference is test infrastructure: the copy
+    `make -C oracle ref` leaves under the git-ignored oracle/_ref/ travels with the snapshot; its rvo2 module is the float32
+    restatement oracle/rvo2_pymodule.cpp — upstream Python-RVO2 is not installable offline).  A bounded sample: 2 x `cases`
+    test cases (~17 k env-steps, a few seconds).  Without a reference copy on this machine: the figure committed from the build
+    container, labelled as such."""
+    script = os.path.join(ROOT, 'oracle', 'time_reference_python.py')
+    try:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='', OMP_NUM_THREADS='1')
+        p = subprocess.run([sys.executable, script, '--json', '--cases', str(cases)], capture_output=True, text=True,
+                           timeout=timeout, env=env)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+        if p.returncode == 0 and line:
+            r = json.loads(line[-1])
+            return {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'], 'kind': 'reference',
+                    'host': r['host_cpu'] + ' (THIS host, timed in this run)',
+                    'sample': '%d + %d env-steps in %.1f s (2 x %d test cases, robot invisible / visible), %s'
+                              % (r['runs'][0]['env_steps'], r['runs'][1]['env_steps'],
+                                 r['runs'][0]['seconds'] + r['runs'][1]['seconds'], cases, r['what']),
+                    'value_visible_robot': r['value_visible_robot'],
+                    'note': 'unmodified reference Python (oracle/_ref or /root/reference) on the float32 rvo2 restatement'}
+    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired):
+        pass
+    if os.path.exists(REFERENCE_PYTHON_PROFILE):
+        r = json.load(open(REFERENCE_PYTHON_PROFILE))
+        return {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'], 'kind': 'reference',
+                'host': r['host_cpu'] + ' (build container, NOT this host)',
+                'note': r['what'] + '; on the float32 rvo2 restatement; committed figure (%s): no reference copy on this machine'
+                        % os.path.relpath(REFERENCE_PYTHON_PROFILE, ROOT)}
+    return None
 
 
 def self_launch(n):
@@ -522,14 +730,19 @@ def main():
     ap.add_argument('--seed-mod', type=int, default=2 ** 32 - 2000)
     ap.add_argument('--async-fill', action='store_true',
                     help='CN_FLAG_ASYNC_SCENARIO_FILL: scenario generation on side streams (crowds of more than 8 humans)')
+    ap.add_argument('--records', type=int, default=1,
+                    help='episode records kept per env (the record ring\'s capacity = records per boundary block); 1: the '
+                         'summary of one engine and of gathered shards is the same statistic at every world size')
+    ap.add_argument('--no-r3-definition', action='store_true',
+                    help='skip the second measurement (value_r3_definition: in-kernel job-wide statistics, rounds 1-3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the configs[2] / configs[3] measurements that follow the headline at N=1')
     ap.add_argument('--workload', choices=['orca', 'sarl', 'om-sarl'], default='orca',
                     help="orca = BASELINE configs[1] (the headline metric); sarl / om-sarl = configs[2]")
     args = ap.parse_args()
-    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.preroll < 0 or args.chunk < 1:
-        raise SystemExit('--gpus/--steps/--chunk must be >= 1, --warmup/--preroll >= 0')
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.preroll < 0 or args.chunk < 1 or args.records < 1:
+        raise SystemExit('--gpus/--steps/--chunk/--records must be >= 1, --warmup/--preroll >= 0')
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
@@ -560,10 +773,7 @@ def main():
         raise SystemExit('rank %d needs GPU %d but only %d are visible' % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group('gloo')
+        init_distributed(backend, local_rank)
     comm = Comm(world, rank, backend)
 
     B, H = args.envs, args.humans
@@ -572,130 +782,72 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA,
-                                       robot_visible=1, device=local_rank, circle_radius=args.circle_radius,
-                                       flags=crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL if args.async_fill else 0)
-    # phase 'train' seeds: 2000 + global episode id (crowd_sim.py:272-276), unbounded episode supply.
-    # The timed region is the K steps: transitions, auto-resets, per-episode records.  The job-wide statistics
-    # (explorer.py:74-90: the reference computes them ONCE, after its episode loop) and the record exchange belong to the
-    # shard boundary, timed separately as boundary_ms at every world size: a launch counts its transitions per env
-    # (per_env_transitions, ABI v6) and ends without any hand-off between its workgroups — no in-kernel summary / blocks
-    # (boundary_records = 0), which were ~9 us of the last wave's tail in every launch of the driver's 20-step shape.
-    # record_capacity = RECORDS on every path: the summary of one engine and of the gathered shards is then the same
-    # statistic — over each env's most recent finished episode — whatever the world size (tests/test_bench_multirank.py)
-    # (CROWDNAV_AMD_BENCH_INKERNEL_STATS=1: round 3's arrangement for A/B runs — every launch leaves the job-wide counter,
-    # the summary and the record blocks behind itself)
+    # CROWDNAV_AMD_BENCH_INKERNEL_STATS=1: round 3's arrangement for the HEADLINE (A/B runs); the default line measures both
     inkernel = os.environ.get('CROWDNAV_AMD_BENCH_INKERNEL_STATS') == '1'
-    bufs = eng.rollout_begin(seed_base=args.seed_base, seed_mod=args.seed_mod, episode_limit=-1, record_capacity=RECORDS,
-                             env_offset=cd.shard(rank, world, B)[0], env_stride=cd.shard(rank, world, B)[1],
-                             boundary_records=RECORDS if inkernel else 0, per_env_transitions=not inkernel)
+    m = measure_orca(args, world, rank, local_rank, comm, inkernel, backend)
+    # `value` changed definition in round 4 (the job-wide statistics left the timed launches).  The same K
+    # steps in round 3's arrangement — every launch leaves the job-wide transition counter, the explorer.py:74-90 sums and the
+    # record blocks behind itself — are measured right after, on a fresh engine, and reported beside it
+    m3 = None if (inkernel or args.no_r3_definition) else measure_orca(args, world, rank, local_rank, comm, True, backend,
+                                                                         fill_probe=False)
 
-    # HIP events of the timed launches exist (and have been recorded once) before the clock starts: creating one lazily
-    # inside the timed region costs more host time than a 20-step launch's enqueue
-    # One event in front of the first timed launch and one behind EVERY launch: launch k is timed from the event behind launch
-    # k - 1 to its own (the stream has nothing else in between), and the last of them doubles as the "stream has drained" flag
-    # the host spins on — n + 1 event records in the timed region instead of 2 n + 1 (each is a packet the command processor
-    # handles between the kernels).
-    n_launches = (args.steps + args.chunk - 1) // args.chunk
-    pool = [torch.cuda.Event(enable_timing=True) for _ in range(n_launches + 2)]
-    for ev in pool:
-        ev.record()
-
-    def run(n_steps, events=None):
-        left = n_steps  # (events: the caller has recorded pool[0] on the idle stream, in front of its clock)
-        while left > 0:
-            n = min(args.chunk, left)
-            eng.rollout(n)
-            if events is not None:
-                k = len(events)
-                pool[k + 1].record()
-                events.append((pool[k], pool[k + 1], n))
-            left -= n
-
-    def drain(last=None):
-        if last is None:
-            last = pool[-1]
-            last.record()
-        while not last.query():  # spin until the stream has drained: a blocking synchronize alone wakes up late
-            pass
-        torch.cuda.synchronize()
-
-    def fence():
-        drain()
-        comm.barrier()
-
-    def shard_boundary():
-        """What a run does ONCE, when it ends (explorer.py:74-90): on one GPU the summary of the engine's record rings
-        (cn_rollout_summary: one kernel); on several the record blocks of this shard (cn_rollout_records), the blocks of every
-        rank (one RCCL all-gather of 56 B per env) and the job-wide summary (cn_records_summary): float64 [8] on the device"""
-        if world == 1:  # one engine: straight from its record rings (cn_rollout_summary, one kernel)
-            return bufs['summary'] if inkernel else eng.rollout_summary()
-        blocks = bufs['blocks'] if inkernel else eng.rollout_records(RECORDS)
-        if world > 1:
-            blocks = cd.gather_blocks(blocks)
-        return eng.records_summary(blocks, record_capacity=RECORDS)
-
-    def snapshot():
-        """device copies of the shard's counters (transitions, episodes finished per env): asynchronous, no host round trip —
-        whatever the host does between the warm-up launches and the timed ones is device idle time in front of a 120 us launch"""
-        return (bufs['transitions'] if inkernel else bufs['env_transitions']).clone(), bufs['ep_count'].clone()
-
-    run(args.preroll)
-    shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
-    gc.collect()  # (before the warm-up launches: see no_gc)
-    run(args.warmup)
-    snap_t, snap_e = snapshot()
-    events = []
-    fence()  # barrier + synchronize ...
-    fence()  # ... twice: the first drains the warm-up launches and the snapshot copies, the second finds an idle device
-    pool[0].record()  # opens the first timed launch's event span (an idle stream stamps it at once)
-    with no_gc():
-        t0 = time.perf_counter()
-        run(args.steps, events)
-        drain(events[-1][1])  # this rank's K steps are done (synchronize) ...
-        elapsed = time.perf_counter() - t0
-    comm.barrier()  # ... and every rank's, before anything else is launched
-    tb = time.perf_counter()
-    summary = shard_boundary()
-    drain()
-    boundary = time.perf_counter() - tb
-    now_t, now_e = snapshot()
-    own_episodes = int((now_e - snap_e).sum().item())
-    transitions = int((now_t - snap_t).sum().item())
-    # an env whose 48-deep scenario ring ran dry inside one launch pauses until the next launch; count what ran
-    paused_env_steps = B * args.steps - transitions
-    per_rank = comm.all_gather({'rank': rank, 'transitions': transitions, 'seconds': elapsed, 'boundary_seconds': boundary})
-    # the slowest rank's K steps, the slowest rank's boundary; transitions of every shard (they differ by the few ring-dry pauses)
-    elapsed, boundary = comm.all_reduce([elapsed, boundary], op='max')
-    total, episodes = (int(v) for v in comm.all_reduce([transitions, own_episodes]))
-
-    kernel_s = sum(e0.elapsed_time(e1) for e0, e1, _ in events) / 1e3
+    elapsed, boundary, total, episodes = m['elapsed'], m['boundary'], m['total'], m['episodes']
+    events = m['events']
+    kernel_s = sum(t for t, _ in events)
     launches = len(events)
-    shapes = sorted({k for _, _, k in events})
+    shapes = sorted({k for _, k in events})
     steps_per_launch = shapes[-1]  # = min(chunk, steps); a shorter tail launch exists when chunk does not divide steps
     avg_launch_s = kernel_s / launches
     achieved = algorithmic_bytes_per_env_step(H) * B * args.steps / kernel_s / 1e9
     prof = pmc_profile(B, H, steps_per_launch, args.circle_radius) if len(shapes) == 1 else None
-    s = [float(v) for v in summary.cpu().tolist()]
+    s = m['summary']
     src = pmc_provenance() if prof is not None else None
     fresh = src is not None and not src['stale']  # the PMC record describes the kernels of this tree
+    fills = m['fills_in_timed_region']
+    # a call tops the scenario ring up only when the steps since the last fill exceed its depth (cn_rollout: the ring budget
+    # rule), so a short timed region can contain no fill at all: value_amortised_fill charges it the steady-state share —
+    # one fill (fill_ms: a 1-step call that carries one minus a 1-step call that does not, measured after the timed region on
+    # the same engine) per ring_depth steps.  A region that contains its fills (fills_in_timed_region > 0) needs no correction.
+    fill_s = m['fill_s']
+    if fills > 0 or args.async_fill:
+        amortised = total / elapsed
+    elif fill_s is not None:
+        amortised = total / (elapsed + fill_s * args.steps / m['ring_depth'])
+    else:
+        amortised = None
     out = {
         'metric': 'env-steps/sec (whole node), %d envs x %d humans, ORCA step' % (B, H),
         'value': total / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 ORCA solve + f64 env step', 'data': 'synthetic',
+        'value_definition': 'all ranks\' transitions / the slowest rank\'s wall time of the K batched steps (transitions, in-kernel '
+                            'auto-resets, per-episode records, per-env transition counters), barrier + synchronize on both sides.  '
+                            'Since round 4 the job-wide statistics of explorer.py:74-90 are computed ONCE, at the shard boundary, '
+                            'outside this region (boundary_ms; value_incl_boundary charges them to the K steps).  '
+                            'value_r3_definition: the same K steps with every launch leaving the job-wide statistics itself — '
+                            'the definition of rounds 1-3, for round-over-round comparison.  value_amortised_fill: value with '
+                            'the steady-state share of the scenario-ring fill charged when the timed region contained none.'
+                            if not inkernel else 'round 3 arrangement (CROWDNAV_AMD_BENCH_INKERNEL_STATS=1): every launch leaves '
+                                                 'the job-wide statistics itself',
         'config': {'workload': '%s%d batched envs x %d humans per GPU, ORCA humans + holonomic ORCA robot (visible), '
                                'circle_crossing radius %g, in-kernel auto-reset'
                                % ('BASELINE configs[1]: ' if (B, H) == (4096, 5) else "BASELINE configs[3]'s shard: " if
                                   (B, H) == (4096, 20) else '', B, H, args.circle_radius),
                    'envs_per_gpu': B, 'humans': H, 'steps_per_launch': steps_per_launch, 'launches': launches,
                    'episode_seeds': '%d + c %% %d' % (args.seed_base, args.seed_mod),
-                   'scenario_fill': 'asynchronous (side streams, per-slot ready flags)' if args.async_fill else 'before each launch',
+                   'records_per_env': args.records,
+                   'scenario_fill': 'asynchronous (side streams, per-slot ready flags): one fill launch beside every call'
+                                    if args.async_fill else
+                                    'synchronous, in front of a call only when the steps since the last fill exceed the %d-deep '
+                                    'ring (ring budget rule); calls of the timed region that carried one: %d of %d'
+                                    % (m['ring_depth'], fills, launches),
+                   'fills_in_timed_region': fills,
                    'preroll_steps': args.preroll,
                    'parallelism': 'env-axis shards x%d, no collective on the step path; the job-wide statistics (record blocks, '
                                   'their all-gather on several GPUs, summary kernel) once when a run ends (boundary_ms)' % world,
                    'backend': backend if world > 1 else None, 'shared_gpu': share_gpu},
-        'ranks': per_rank,
+        'ranks': m['per_rank'],
+        'rccl': m['rccl'],
         'summary': s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(prof) if fresh else None,
@@ -711,7 +863,10 @@ def main():
         'issue_roofline': pmc_issue(prof, B, steps_per_launch, avg_launch_s),
         'boundary_ms': boundary * 1e3,
         'value_incl_boundary': total / (elapsed + boundary),
-        'paused_env_steps': paused_env_steps,
+        'value_r3_definition': None if m3 is None else m3['total'] / m3['elapsed'],
+        'fill_ms': None if fill_s is None else fill_s * 1e3,
+        'value_amortised_fill': amortised,
+        'paused_env_steps': B * args.steps * world - total,
         'episodes_finished': episodes,
         'mean_recorded_return': s[6] / max(s[1], 1.0),
         'recorded_success_rate': s[2] / max(s[1], 1.0),
@@ -719,10 +874,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(B, H)
     if rank == 0 and world == 1 and not args.no_secondary and (B, H) == (4096, 5):
-        eng.sync()
-        eng.close()
-        del eng, bufs
-        torch.cuda.empty_cache()
         out['secondary'] = secondary(B, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CROWDNAV_AMD_LIB: another build of the same library (kernel A/B experiments, scripts/gpu_ab.sh); default in-tree
 LIB_PATH = os.environ.get('CROWDNAV_AMD_LIB') or os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
@@ -19,6 +19,7 @@ ROBOT_EXTERNAL, ROBOT_ORCA = 0, 1
 CIRCLE_CROSSING, SQUARE_CROSSING, MIXED = 0, 1, 2
 HOLONOMIC, UNICYCLE = 0, 1
 RECORD_FIELDS, SUMMARY_FIELDS = 6, 8
+LAUNCH_COUNTERS = ('rollout_kernels', 'scheduled_kernels', 'ring_fills', 'async_fills')  # CN_COUNT_*
 FLAG_ASYNC_SCENARIO_FILL = 1
 
 
@@ -109,6 +110,7 @@ SYMBOLS = {
     'cn_gather_records': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     'cn_records_summary': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P]),
     'cn_rollout_summary': (C.c_int, [_P, C.POINTER(CnRolloutIo), _P]),
+    'cn_launch_counts': (C.c_int, [_P, _P]),
     'cn_mt_random': (C.c_int, [_P, C.c_uint32, C.c_int, _P]),
 }
 

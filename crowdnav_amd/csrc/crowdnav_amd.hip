@@ -23,7 +23,7 @@ void cn_launch_orca(cn_engine* e, float* out_vel) { CN_LAUNCH_MAXL(e, orca_kerne
 extern "C" {
 
 const char* cn_last_error(void) { return cn_g_err; }
-int cn_abi_version(void) { return 6; }
+int cn_abi_version(void) { return 7; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
     if (!c || !out) return fail(CN_ERR_INVALID, "cn_create: NULL argument");
@@ -69,6 +69,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->rollout_done = nullptr;
     e->next_fill_stream = 0;
     for (int i = 0; i < cn_engine::kFillStreams; ++i) e->fill_streams[i] = nullptr;
+    for (uint64_t& c : e->launch_counts) c = 0;
     cn::Params& P = e->P;
     P.B = c->num_envs;
     P.A = c->num_humans + 1;
@@ -489,6 +490,7 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
         // of kernels hung on the GPU box and was not pursued)
         hipLaunchKernelGGL(cn::ring_fill_wave_async_kernel, dim3(e->P.B * e->P.ring_depth), dim3(cn::kWave), 0, fs, e->P, e->C,
                            e->S, R);
+        e->launch_counts[CN_COUNT_ASYNC_FILLS] += 1;
         e->steps_since_fill = 0;
         return CN_OK;
     }
@@ -510,6 +512,7 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
                            e->S);
     }
     std::swap(e->S.ring_filled_in, e->S.ring_filled_out);
+    e->launch_counts[CN_COUNT_RING_FILLS] += 1;
     e->steps_since_fill = n_steps;
     return CN_OK;
 }
@@ -518,6 +521,7 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
 // with BASELINE configs[1]'s geometry folded in as compile-time constants; the general phase kernel otherwise.
 static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, const double* action) {
     const cn::Params& P = e->P;
+    const uint64_t kernels_before = e->launch_counts[CN_COUNT_ROLLOUT_KERNELS];
     static const bool use_fused = env_int("CROWDNAV_AMD_FUSED", 1) != 0;
     static const bool use_geom20 = env_int("CROWDNAV_AMD_GEOM20", 1) != 0;  // the compile-time geometry of configs[3]'s shard
     const bool headline = P.A == 6 && P.NC == 5 && P.E == 2 && P.nA == 12 && P.pairs == 60 && P.threads == 64;
@@ -552,6 +556,8 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
         const bool sched = P.B % 4 == 0 && n_steps >= e->sched_min && action == nullptr &&
                            (e->sched_force || 4 * rounds_sched < 3 * rounds_plain);
         const int q = sched ? n_steps / 3 : 0, rest = n_steps - 3 * q;
+        e->launch_counts[CN_COUNT_ROLLOUT_KERNELS] += (rest > 0 ? 1 : 0) + (q > 0 ? 4 : 0);
+        e->launch_counts[CN_COUNT_SCHEDULED_KERNELS] += q > 0 ? 4 : 0;
         if (rest > 0)
             hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(grid_envs(e)), dim3(64), smem20, e->stream, Pk,
                                (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, rest, action);
@@ -563,6 +569,7 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
     } else {
         CN_LAUNCH_ROLLOUT(e, grid_envs(e), e->P, (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     }
+    if (e->launch_counts[CN_COUNT_ROLLOUT_KERNELS] == kernels_before) e->launch_counts[CN_COUNT_ROLLOUT_KERNELS] += 1;
 }
 
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps) {
@@ -593,6 +600,12 @@ int cn_rollout_step(cn_engine* e, const cn_rollout_io* io, const double* action)
     if ((rc = fill_ring_if_needed(e, R, 1))) return rc;
     launch_rollout(e, R, 1, action);
     CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
+int cn_launch_counts(cn_engine* e, uint64_t* counts_host) {
+    if (!e || !counts_host) return fail(CN_ERR_INVALID, "cn_launch_counts: NULL argument");
+    for (int i = 0; i < CN_LAUNCH_COUNTERS; ++i) counts_host[i] = e->launch_counts[i];
     return CN_OK;
 }
 

@@ -74,6 +74,7 @@ struct cn_engine {
     size_t smem;       // dynamic LDS bytes per workgroup
     int sched_min, sched_slots;  // the 20-human shard kernel's 3-of-4 env schedule (launch_rollout): shortest call split, resident workgroups
     bool sched_force;
+    uint64_t launch_counts[CN_LAUNCH_COUNTERS];  // cn_launch_counts: what the host enqueued since cn_create
     // Device memory comes from a few large slabs, not one hipMalloc per buffer: an engine has ~60 device buffers, most of them a
     // few KiB; one 32 MiB slab (plus one per buffer larger than that) is 2-4 mappings to create and - each hipFree being a device
     // synchronisation - 2-4 to tear down, and cn_sarl_configure can roll a failed configuration back to a mark.

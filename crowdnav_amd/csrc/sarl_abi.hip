@@ -275,10 +275,17 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         (rc = dev_alloc(e, &s->X, s->n_tiles * H * net.ks_x * 64)) ||
         (rc = dev_alloc(e, &s->hcount, s->n_tiles * cn::kSarlGroups)))
         return rc;
-    if (e->cfg.scenario_rule == CN_MIXED && s->chunked)
+    if (e->cfg.scenario_rule == CN_MIXED && s->chunked) {
+        if (H <= cn::kSarlMaxHumans && !cadrl && !lstm)  // the network, not the crowd, is too large for one tile
+            return fail(CN_ERR_UNSUPPORTED,
+                        "value networks under the mixed rule run the one-tile kernel (it masks an episode's absent humans), whose "
+                        "tile — activations %zu B + the pipelined side buffer %zu B — must fit the 160 KiB of LDS; these layer "
+                        "widths do not (narrower mlp1 / mlp3 layers do: the shipped 150-wide network needs 150.5 KiB)",
+                        cn::sarl_mlp_lds_bytes(net), cn::sarl_mlp_pipe_extra_lds_bytes(net));
         return fail(CN_ERR_UNSUPPORTED,
                     "value networks under the mixed rule run the one-tile kernels (they mask an episode's absent humans): "
                     "num_humans must be 5 (the rule never draws more)");
+    }
     CN_HIP(hipMemcpy(s->actions, actions_host, sizeof(double) * 2 * C.n_actions, hipMemcpyHostToDevice));
     s->ref = cn::SarlNetRef{};
     s->ref.base = s->arena;

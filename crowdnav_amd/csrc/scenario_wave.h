@@ -108,6 +108,20 @@ struct WaveRng {
     __device__ void ensure(uint32_t n, int lane) {
         while (produced < cursor + n) next_block(lane);
     }
+    // Move the cursor BACK to stream word `target` (the give-up rule of the window path: up to 62 attempts = 372 words behind
+    // the window base).  The ring holds words [produced - kWindow, produced) and the window may run a block ahead of the
+    // cursor, so the target can have been overwritten already; and persist() knows the generator states of the latest two
+    // blocks only.  In either case the stream is regenerated from its seed up to the target's block (an error path: the
+    // human that gave up has just cost max_attempts / 64 window passes).
+    __device__ void rewind_to(uint32_t seed0, uint32_t target, int lane) {
+        const bool held = target + kWindow >= produced;
+        const bool persistable = target / 624u + 2u >= produced / 624u;
+        if (!held || !persistable) {
+            seed(seed0, lane);
+            while (produced <= target) next_block(lane);
+        }
+        cursor = target;
+    }
     __device__ uint32_t word(uint32_t stream_index) const { return out[stream_index % kWindow]; }
     // np.random.random() from the two words at stream_index
     __device__ double random_at(uint32_t stream_index) const {
@@ -294,7 +308,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
                         s.prad[i] = radius;
                         *c.error = 1;
                     }
-                    rng.cursor = hstart + 6u * (uint32_t)(N - 64ull + 1ull);
+                    rng.rewind_to(seed, hstart + 6u * (uint32_t)(N - 64ull + 1ull), lane);
                     win = false, wstart = 0;
                     break;
                 }

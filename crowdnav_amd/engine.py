@@ -8,6 +8,7 @@ torch is used for device memory and streams only; all compute happens in libcrow
 Agent 0 of every env is the robot, agents 1..H the humans.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -250,22 +251,30 @@ class BatchedCrowdSim(object):
         check(self._lib.cn_rollout_records(self._h, C.byref(io), K, _ptr(blocks)))
         return blocks
 
-    def records_summary(self, blocks, record_capacity=None):
+    def records_summary(self, blocks, record_capacity=None, out=None):
         """float64 [8]: episodes finished, records held, ReachGoal / Collision / Timeout among them, sum of successful nav
         times, sum of discounted returns, sum of Danger steps — of any [n, 1 + 6 K] record blocks, a shard's own or the
         gathered ones (cn_records_summary: one workgroup, fixed summation order)."""
         K = (int(blocks.shape[1]) - 1) // _lib.RECORD_FIELDS
         cap = K if record_capacity is None else int(record_capacity)
-        out = self._new((_lib.SUMMARY_FIELDS,), torch.float64)
+        out = self._summary_out(out)
         check(self._lib.cn_records_summary(self._h, int(blocks.shape[0]), K, cap, _ptr(blocks), _ptr(out)))
         return out
 
-    def rollout_summary(self):
+    def _summary_out(self, out):
+        if out is None:
+            return self._new((_lib.SUMMARY_FIELDS,), torch.float64)
+        if out.dtype != torch.float64 or out.device != self.device or out.numel() != _lib.SUMMARY_FIELDS or not out.is_contiguous():
+            raise ValueError('summary output: a contiguous float64 [%d] tensor on %s' % (_lib.SUMMARY_FIELDS, self.device))
+        return out
+
+    def rollout_summary(self, out=None):
         """records_summary(rollout_records()) of this engine in ONE kernel, straight from its record rings (cn_rollout_summary):
-        the statistics of explorer.py:74-90 for a run on one engine."""
+        the statistics of explorer.py:74-90 for a run on one engine.  out: the caller's float64 [8] device tensor (a run that
+        asks once per boundary keeps one: no allocation between the last launch and the kernel)."""
         if self._rollout is None:
             raise RuntimeError('call rollout_begin() first')
-        out = self._new((_lib.SUMMARY_FIELDS,), torch.float64)
+        out = self._summary_out(out)
         check(self._lib.cn_rollout_summary(self._h, C.byref(self._rollout[0]), _ptr(out)))
         return out
 
@@ -276,6 +285,13 @@ class BatchedCrowdSim(object):
         out = self._new((n_ranks * self.B, int(blocks.shape[1])), torch.float64)
         check(self._lib.cn_gather_records(self._h, C.c_void_p(int(comm)), int(n_ranks), K, _ptr(blocks), _ptr(out)))
         return out
+
+    def launch_counts(self):
+        """What the host has enqueued for this engine since it was created (cn_launch_counts): dict of _lib.LAUNCH_COUNTERS ->
+        int.  Host-side, no device work: the difference of two calls says which launches a region contained."""
+        out = (C.c_uint64 * len(_lib.LAUNCH_COUNTERS))()
+        check(self._lib.cn_launch_counts(self._h, out))
+        return dict(zip(_lib.LAUNCH_COUNTERS, (int(v) for v in out)))
 
     def mt_random(self, seed, n):
         out = self._new((n,), torch.float64)
@@ -415,7 +431,11 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
         if t_.device != self.device or t_.dtype != dt or tuple(t_.shape) != shape or not t_.is_contiguous():
             raise ValueError('sarl_sampler: expected a contiguous %s %s tensor on %s, got %s %s on %s (contiguous: %s)'
                              % (dt, shape, self.device, t_.dtype, tuple(t_.shape), t_.device, t_.is_contiguous()))
-    keep = (self, traj, rew, info, dmin, act, alive, done, action)  # the closure owns what its addresses point into
+    # the closure owns the tensors its addresses point into, but only a WEAK reference to the engine: stored on the engine or on
+    # a rollout object it would otherwise form a cycle, and cn_destroy (a stream synchronize + hipFree) would run whenever the
+    # cyclic collector gets to it — e.g. in the middle of somebody's timed region (bench.py closes its engines explicitly)
+    keep = (traj, rew, info, dmin, act, alive, done, action)
+    alive_engine = weakref.ref(self)
     lib, h, V = self._lib, self._h, C.c_void_p
     p_traj, p_rew, p_inf, p_dmn, p_act = traj.data_ptr(), rew.data_ptr(), info.data_ptr(), dmin.data_ptr(), act.data_ptr()
     p_alive, p_done, p_action = V(alive.data_ptr()), V(done.data_ptr()), V(action.data_ptr())
@@ -423,13 +443,15 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     stride = T * H * D
 
     def step(t, epsilon):
-        if not keep[0]._h.value:
+        eng = alive_engine()
+        if eng is None or eng._h is not h or not h.value:
             raise RuntimeError('sarl_sampler: the engine has been closed')
         best = V(p_act + 4 * B * t)
         check(lib.cn_sarl_select(h, None, best, p_action))
         check(lib.cn_sarl_explore(h, epsilon, p_alive, best, p_action, None))
         check(lib.cn_sarl_transform(h, V(p_traj + 4 * H * D * t), stride, sort))
         check(lib.cn_step(h, p_action, 1, V(p_rew + 8 * B * t), p_done, V(p_inf + B * t), V(p_dmn + 8 * B * t), None, None, None))
+    step.keep = keep  # the tensors live as long as the step function does
     return step
 
 

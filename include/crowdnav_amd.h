@@ -208,10 +208,29 @@ int cn_set_gamma(cn_engine* e, double gamma);
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io);
 /* replaces the `while not done: action = robot.act(ob); env.step(action)` loop of
  * Explorer.run_k_episodes (explorer.py:41-48) for an on-device robot policy (robot_policy ==
- * CN_ROBOT_ORCA): n_steps transitions per active env in ONE call, with in-kernel auto-reset.  (A call is one kernel launch,
- * except for 20-human crowds of 4096 and more envs, where calls of 48 and more steps are split into up to five launches on the
- * engine's stream — groups of envs taking turns, every env making its n_steps transitions in order; results are the same.) */
+ * CN_ROBOT_ORCA): n_steps transitions per active env in ONE call, with in-kernel auto-reset.  A call is one kernel launch,
+ * except on the 20-human shard geometry (20 humans + robot, max_neighbors 10, holonomic) when the 3-of-4 env schedule saves
+ * rounds of the chip: with S = 12 x CUs resident one-wave workgroups, a call of n >= 48 steps is split when num_envs % 4 == 0
+ * and 4 ceil(0.75 B / S) < 3 ceil(B / S) (on 256 CUs: B = 4096 yes; 2048, 3072, 6144 no; CROWDNAV_AMD_SCHED_FORCE=1 splits
+ * any multiple of four, CROWDNAV_AMD_SCHED_MIN_STEPS moves the 48) into one launch of n % 3 steps over all envs and four
+ * launches of n / 3 steps over three envs of every four — every env makes its n transitions in order.  Per-env state, the
+ * per-env counters and the episode records are bit-identical to an unsplit call; the float64 SUMS of io.summary (nav time,
+ * return) are accumulated in a different workgroup order under the schedule and may differ from an unsplit call's, and from
+ * cn_records_summary's, in the last bits (counts are exact).  cn_launch_counts reports whether a call was split. */
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
+
+/* (ABI v7) what the HOST has enqueued for this engine since cn_create — counts_host: HOST uint64 [CN_LAUNCH_COUNTERS], indexed
+ * by CN_COUNT_*; synchronous, no device work.  Lets a caller (bench.py, the parity tests) state which launches a timed region
+ * contained — e.g. whether a cn_rollout call carried a scenario fill (the ring budget rule: a fill only when the steps since the
+ * last one exceed the ring depth) and whether the 20-human shard's 3-of-4 env schedule was taken — instead of inferring it. */
+enum {
+    CN_COUNT_ROLLOUT_KERNELS = 0,   /* transition kernels launched by cn_rollout / cn_rollout_step */
+    CN_COUNT_SCHEDULED_KERNELS = 1, /* ... of which sub-launches of the 3-of-4 env schedule (four per split call) */
+    CN_COUNT_RING_FILLS = 2,        /* synchronous scenario-ring fills (one per cn_rollout call that needed one) */
+    CN_COUNT_ASYNC_FILLS = 3        /* fill launches on the side streams (CN_FLAG_ASYNC_SCENARIO_FILL: one per call) */
+};
+#define CN_LAUNCH_COUNTERS 4
+int cn_launch_counts(cn_engine* e, uint64_t* counts_host);
 
 /* ------------------------------------------------------------------------------------------------------
  * SARL robot decision (crowd_nav/policy/sarl.py:9-86 on top of multi_human_rl.py:11-63, cadrl.py:82-222).
@@ -259,7 +278,12 @@ typedef struct cn_sarl_config {
 } cn_sarl_config;
 
 /* replaces SARL.configure + CADRL.build_action_space: actions_host = double [n_actions][2] (ActionXY table, HOST
- * pointer, computed by the caller exactly as cadrl.py:86-99 does).  Synchronous; once per engine. */
+ * pointer, computed by the caller exactly as cadrl.py:86-99 does).  Synchronous; once per engine.
+ * Layer widths are free (the shipped ones have register-resident kernels).  A sarl.ValueNetwork whose tile — one (env, action)
+ * group's activations for all humans plus the pipelined side buffer, 4 x 64 x (H (ks_a + ks_b + ks_c + 4) + ks_b + 3 ks_a) bytes,
+ * ks = the widest layer of each buffer in 4-column steps — exceeds the 160 KiB of LDS streams the humans through in chunks
+ * instead (at 5 humans: a first mlp1 / mlp3 layer of 192 or more); under the `mixed` rule, whose one-tile kernel masks absent
+ * humans, such a network is CN_ERR_UNSUPPORTED. */
 int cn_sarl_configure(cn_engine* e, const cn_sarl_config* cfg, const double* actions_host);
 /* replaces model.load_state_dict: params_host_array = HOST array of 22 DEVICE pointers to the float32 tensors of
  * sarl.ValueNetwork.state_dict() in its own order (mlp1.0.weight, mlp1.0.bias, mlp1.2.*, mlp2.0.*, mlp2.2.*,

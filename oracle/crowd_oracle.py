@@ -77,6 +77,8 @@ def lib():
         L.co_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.co_rollout.restype = C.c_int64
         L.co_rollout.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 7
+        L.co_rollout_full.restype = C.c_int64
+        L.co_rollout_full.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 12
         L.co_mt_random.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -177,6 +179,22 @@ class CrowdOracle(object):
                                  _p(ep_count), _p(ep_outcome), _p(ep_steps), _p(ep_return),
                                  _p(ep_index), _p(cur_steps), _p(cur_return))
         return total, dict(count=ep_count, outcome=ep_outcome, steps=ep_steps, ret=ep_return)
+
+    def rollout_full(self, n_steps, seed_base, seed_mod, max_ep, ep_index=None, cur=None):
+        """rollout() with everything Explorer.run_k_episodes keeps per episode (explorer.py:46-62): + nav time, Danger steps,
+        sum of their min_dist; `cur` (dict steps / ret / danger / dsum, in/out) carries the running episode between calls."""
+        B = self.B
+        z = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
+        rec = dict(count=z(B, np.int32), outcome=z((B, max_ep), np.uint8), steps=z((B, max_ep), np.int32),
+                   ret=z((B, max_ep), np.float64), time=z((B, max_ep), np.float64), danger=z((B, max_ep), np.int32),
+                   dsum=z((B, max_ep), np.float64))
+        ep_index = z(B, np.int32) if ep_index is None else ep_index
+        cur = cur or dict(steps=z(B, np.int32), ret=z(B, np.float64), danger=z(B, np.int32), dsum=z(B, np.float64))
+        total = lib().co_rollout_full(self._h, int(n_steps), int(seed_base), int(seed_mod), int(max_ep), _p(rec['count']),
+                                      _p(rec['outcome']), _p(rec['steps']), _p(rec['ret']), _p(rec['time']), _p(rec['danger']),
+                                      _p(rec['dsum']), _p(ep_index), _p(cur['steps']), _p(cur['ret']), _p(cur['danger']),
+                                      _p(cur['dsum']))
+        return total, rec, cur
 
     @staticmethod
     def set_threads(n):

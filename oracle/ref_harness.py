@@ -1,9 +1,11 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.
 
-Imports the UNMODIFIED reference (/root/reference) on top of the shims and the float32 `rvo2`
-restatement, and offers small helpers to drive it.  Only usable in the build container (the
-reference does not exist on the GPU box); it is used to pin the C oracle and to generate the
-committed fixtures under tests/golden/ (see gen_golden.py).
+Imports the UNMODIFIED reference on top of the shims and the float32 `rvo2` restatement, and offers
+small helpers to drive it.  The reference is /root/reference in the build container; on the GPU box —
+which has none — it is the byte-for-byte copy `make -C oracle ref` left under oracle/_ref/ (git-ignored,
+travels with the snapshot).  Used to pin the C oracle, to generate the committed fixtures under
+tests/golden/ (gen_golden.py), to run the reference's own scripts on crowdnav_amd.compat
+(tests/test_dropin_surface.py) and to time the reference's Python loop (time_reference_python.py).
 """
 import configparser
 import logging
@@ -11,7 +13,17 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REFERENCE = os.environ.get('CROWDNAV_REFERENCE', '/root/reference')
+
+
+def find_reference():
+    """$CROWDNAV_REFERENCE, else /root/reference (build container), else oracle/_ref (the copy that travels); None if none"""
+    for cand in (os.environ.get('CROWDNAV_REFERENCE'), '/root/reference', os.path.join(HERE, '_ref')):
+        if cand and os.path.isfile(os.path.join(cand, 'crowd_nav', 'train.py')):
+            return cand
+    return None
+
+
+REFERENCE = find_reference() or '/root/reference'
 
 
 def available():

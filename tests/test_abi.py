@@ -67,6 +67,10 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert 'crowd_oracle' not in text and 'rvo2_oracle' not in text, os.path.join(dirpath, f)
                 assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f
+                # ... nor the unmodified reference that build() copies to oracle/_ref/ as test infrastructure
+                # (comments cite /root/reference file:line; no code may open, import or put on sys.path anything under it)
+                assert 'oracle/_ref' not in text and "'_ref'" not in text and 'ref_harness' not in text, os.path.join(dirpath, f)
+                assert not re.search(r'(sys\.path|import_module|run_path|open\(|os\.path|chdir)[^\n]*/root/reference', text), f
 
 
 def test_create_rejects_bad_configs_before_touching_the_device(built):

@@ -1,6 +1,8 @@
 """The drop-in claim, checked mechanically: "train.py / test.py are drop-in".
 
-Needs the reference on disk (/root/reference: the build container; the GPU box has none, the tests skip there).  Three checks:
+Needs the unmodified reference on disk: /root/reference in the build container, or the byte-for-byte copy that
+`make -C oracle ref` (run by __graft_entry__.build()) leaves under the git-ignored oracle/_ref/, which travels to the GPU box
+with the snapshot — there the `-m gpu` legs at the end run the reference's scripts TO COMPLETION.  Checks:
 
 1. The reference's UNMODIFIED crowd_nav/test.py and crowd_nav/train.py are executed on crowdnav_amd.compat through
    `python -m crowdnav_amd.compat.reference <script> ...` (module aliases, not a line of the reference changed).  Without a
@@ -11,18 +13,25 @@ Needs the reference on disk (/root/reference: the build container; the GPU box h
    from their ASTs) exists on the compat objects, and every call binds to the compat signature.
 3. The public method sets of the reference's classes against their compat mirrors: whatever is absent must be listed in
    INTEGRATION.md ("not mirrored"), and the signatures of the shared methods must agree.
+4. (-m gpu) `test.py --policy orca --phase test` runs to its last log line on the MI355X and that line is the paper's ORCA row
+   (success 0.43, collision 0.57, nav time 10.86: robot invisible, env.config:33); `train.py --policy sarl --gpu` runs imitation
+   learning, RL episodes, evaluations and the final test on a shortened train.config (passed with --train_config: not a line
+   of the reference changed), and its output.log holds the lines crowd_nav/utils/plot.py parses.
 """
 import ast
+import configparser
 import importlib
 import inspect
 import os
+import re
 import subprocess
 import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.environ.get('CROWDNAV_REFERENCE', '/root/reference')
+REF = next((c for c in (os.environ.get('CROWDNAV_REFERENCE'), '/root/reference', os.path.join(ROOT, 'oracle', '_ref'))
+            if c and os.path.isfile(os.path.join(c, 'crowd_nav', 'train.py'))), '/root/reference')
 HAVE_REF = os.path.isfile(os.path.join(REF, 'crowd_nav', 'train.py'))
 needs_ref = pytest.mark.skipif(not HAVE_REF, reason='the reference is not on this machine')
 
@@ -33,9 +42,10 @@ NOT_MIRRORED = {
 }
 
 
-def _run_reference_script(script, args, tmp_path):
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, 'oracle', 'shims'), PYTHONDONTWRITEBYTECODE='1',
-               HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+def _run_reference_script(script, args, tmp_path, gpu=False):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, 'oracle', 'shims'), PYTHONDONTWRITEBYTECODE='1')
+    if not gpu:
+        env.update(HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
     return subprocess.run([sys.executable, '-m', 'crowdnav_amd.compat.reference', script] + args,
                           cwd=os.path.join(REF, 'crowd_nav'), env=env, capture_output=True, text=True, timeout=600)
 
@@ -233,3 +243,55 @@ def test_mirrored_helpers_agree_with_their_definitions():
     with pytest.raises(AssertionError):
         r.check_validity(cn.ActionRot(1.0, 0.0))
     assert cn.Policy.reach_destination(cn.JointState(cn.FullState(0.0, 3.9, 0, 0, 0.3, 0.0, 4.0, 1.0, 0.0), [])) is True
+
+
+# ------------------------------------------------------------------------------------------------ to completion, on the GPU
+# crowd_nav/utils/plot.py:38-40, 53-55 — the log lines the reference's own plotting script parses
+VAL_PATTERN = (r"VAL   in episode (?P<episode>\d+) has success rate: (?P<sr>[0-1].\d+), "
+               r"collision rate: (?P<cr>[0-1].\d+), nav time: (?P<time>\d+.\d+), total reward: (?P<reward>[-+]?\d+.\d+)")
+TRAIN_PATTERN = VAL_PATTERN.replace('VAL  ', 'TRAIN')
+TEST_PATTERN = VAL_PATTERN.replace('VAL  ', 'TEST ')
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.timeout(700)
+def test_reference_test_py_runs_to_completion_on_the_device():
+    """/root/reference/crowd_nav/test.py:64-109, unmodified, on compat: 500 test cases of the ORCA robot (invisible,
+    env.config:33) — the k episodes run as ONE batch inside cn_rollout — and the Explorer's log line is the paper's ORCA row."""
+    p = _run_reference_script('test.py', ['--policy', 'orca', '--phase', 'test'], None, gpu=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    log = p.stderr + p.stdout
+    assert 'TEST  has success rate: 0.43, collision rate: 0.57, nav time: 10.86, total reward: -0.0220' in log, log[-3000:]
+    assert 'Frequency of being in danger: 0.30 and average min separate distance in danger: 0.08' in log
+    assert 'Collision cases: 0 1 2 5 8' in log and 'Timeout cases:' in log  # explorer.py:88-90 (SURVEY App. D: cases 0..19)
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.timeout(900)
+def test_reference_train_py_runs_to_completion_on_the_device(tmp_path):
+    """/root/reference/crowd_nav/train.py:76-170, unmodified, on compat with --gpu: imitation learning from device ORCA
+    demonstrations, the RL loop (evaluation / sampling / optimize_batch / target update / checkpoint) and the final test, on a
+    train.config shortened through the script's own --train_config flag."""
+    cfg = configparser.RawConfigParser()
+    cfg.read(os.path.join(REF, 'crowd_nav', 'configs', 'train.config'))
+    for sec, key, val in (('imitation_learning', 'il_episodes', 300), ('imitation_learning', 'il_epochs', 3),
+                          ('train', 'train_episodes', 6), ('train', 'train_batches', 5), ('train', 'evaluation_interval', 3),
+                          ('train', 'target_update_interval', 2), ('train', 'checkpoint_interval', 3)):
+        cfg.set(sec, key, str(val))
+    short = tmp_path / 'train.config'
+    with open(short, 'w') as f:
+        cfg.write(f)
+    out = tmp_path / 'run'
+    p = _run_reference_script('train.py', ['--policy', 'sarl', '--gpu', '--train_config', str(short), '--output_dir', str(out)],
+                              tmp_path, gpu=True)
+    assert p.returncode == 0, (p.stderr + p.stdout)[-3000:]
+    log = (out / 'output.log').read_text()
+    assert 'Using device: cuda:0' in log and 'Policy: SARL w/ global state' in log
+    assert re.search(r'TRAIN has success rate: [0-1]\.\d+, collision rate: [0-1]\.\d+, nav time: \d+\.\d+', log)  # IL batch
+    assert 'Finish imitation learning. Weights saved.' in log and re.search(r'Experience set size: \d+/100000', log)
+    assert [int(m[0]) for m in re.findall(VAL_PATTERN, log)] == [0, 3]          # train.py:155-156
+    assert [int(m[0]) for m in re.findall(TRAIN_PATTERN, log)] == [0, 1, 2, 3, 4, 5]  # :159
+    assert [int(m[0]) for m in re.findall(TEST_PATTERN, log)] == [6]            # :170
+    assert sorted(os.listdir(out)) == ['env.config', 'il_model.pth', 'output.log', 'policy.config', 'rl_model.pth', 'train.config']

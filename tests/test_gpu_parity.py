@@ -383,6 +383,51 @@ def test_unsatisfiable_scenario_is_reported_not_hung(amd, monkeypatch, humans):
     assert np.all(np.isfinite(_np(eng.get_state()[0])))
 
 
+@pytest.mark.parametrize('cap_log2', [6, 8])
+def test_window_generator_give_up_keeps_the_sequential_stream(amd, monkeypatch, cap_log2):
+    """when a human exhausts its attempts in the window path (scenario_wave.h, CN_GEN_WINDOW), the give-up rule
+    takes attempt N - 64 and the stream continues at attempt N - 63 — up to 62 attempts BEHIND the window base when the human
+    started mid-window, i.e. at words the 1248-word ring may have overwritten (WaveRng::rewind_to regenerates the stream then).
+    With a cap of 64 / 256 attempts on the reference's own crowded geometry (20 humans, 4 m circle) nearly every scenario
+    gives up several times: placements, the number of random() calls consumed and the env's numpy stream BEHIND the scenario
+    (what cn_sarl_explore draws from: mt_key / mt_pos) must be those of the plain sequential loop."""
+    import ctypes as C
+    import torch
+    from test_generator_window_emulation import attempts_of, sequential
+    monkeypatch.setenv('CROWDNAV_AMD_MAX_ATTEMPTS_LOG2', str(cap_log2))
+    B, H, R, K = 64, 20, 4.0, 81
+    eng = amd.BatchedCrowdSim(num_envs=B, num_humans=H, circle_radius=R, robot_policy=amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.sarl_configure(actions=np.stack([np.arange(K), -np.arange(K)], axis=1).astype(np.float64))
+    seeds = 1000 + 7 * np.arange(B)
+    sd = torch.from_numpy(seeds.astype(np.uint32).view(np.int32)).to(eng.device)
+    draws = torch.zeros(B, dtype=torch.int64, device=eng.device)
+    from crowdnav_amd._lib import check
+    check(eng._lib.cn_reset(eng._h, C.c_void_p(sd.data_ptr()), None, C.c_void_p(draws.data_ptr())))
+    with pytest.raises(amd.CrowdNavAmdError) as ei:  # the give-ups are reported (once) at the next sync
+        eng.sync()
+    assert 'rejected placements' in str(ei.value)
+    state, draws = _np(eng.get_state()[0]), _np(draws)
+    gave_up = 0
+    cap = 1 << cap_log2
+    for b in range(B):
+        placed, attempts, err = sequential(attempts_of(int(seeds[b]), H * (cap + 64)), H, R, 1.0, 0.8, cap)
+        gave_up += int(err)
+        assert draws[b] == 3 * attempts, (b, draws[b], 3 * attempts)
+        want = np.array([(x, y, gx, gy) for x, y, gx, gy in placed])
+        assert np.abs(state[b, 1:, [0, 1, 4, 5]].T - want).max() <= 1e-12, b
+    assert gave_up >= B // 2
+    # the env's own stream continues right behind the scenario's last draw
+    sel = dict(best=torch.full((B,), 5, dtype=torch.int32, device=eng.device),
+               action=torch.zeros(B, 2, dtype=torch.float64, device=eng.device))
+    eng.sarl_explore(sel, 1.0)
+    eng.sync()
+    got = _np(sel['best'])
+    for b in range(B):
+        rs = np.random.RandomState(int(seeds[b]))
+        rs.random_sample(int(draws[b]))
+        assert rs.random_sample() < 1.0 and got[b] == int(rs.choice(K)), b
+
+
 def test_head_generator_overflow_falls_back_exactly(amd, oracle_mod):
     """Lane-per-scenario generation tries a register-only generator good for 113 random() calls and regenerates
     with the memory-backed one beyond that: a crowded circle (8 humans, radius 2.6) needs both; stream-exact."""

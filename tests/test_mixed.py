@@ -246,3 +246,42 @@ def test_mixed_value_networks_need_five_slots():
     acts = np.zeros((81, 2))
     with pytest.raises(crowdnav_amd.CrowdNavAmdError):
         eng.sarl_configure(actions=acts)  # 6 slots stream through the chunked kernel, which does not mask
+
+
+@pytest.mark.gpu
+def test_mixed_value_network_lds_limit_at_the_boundary_width():
+    """under the mixed rule the one-tile SARL kernel must hold a tile's activations AND the pipelined side buffer
+    in 160 KiB of LDS (include/crowdnav_amd.h: cn_sarl_configure).  At 5 humans a first mlp1 layer of 176 still fits
+    (159 808 B), 192 does not (168 000 B, although the activations alone — 155 712 B — would): configured and run / refused
+    with a message that says why.  Outside the mixed rule the same 192-wide network streams through the chunked kernel."""
+    import torch
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    acts = np.zeros((81, 2))
+    acts[1:, 0] = np.linspace(-1, 1, 80)
+
+    def engine(rule):
+        return crowdnav_amd.BatchedCrowdSim(num_envs=4, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                            robot_visible=1, scenario_rule=rule)
+
+    def run(eng, width, compare):
+        eng.sarl_configure(actions=acts, mlp1_dims=(width, 100))
+        torch.manual_seed(0)
+        net = ValueNetwork(13, 6, [width, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+        eng.sarl_set_weights(net.state_dict())
+        eng.reset(1000 + np.arange(4))
+        sel = eng.sarl_select()
+        eng.sync()
+        assert np.isfinite(sel['values'].cpu().numpy()).all()
+        if compare:  # (a mixed episode's absent humans are masked out of the attention: compared in the test above)
+            with torch.no_grad():
+                want = net(eng.sarl_export('X').cpu().reshape(4 * 81, 5, 13)).reshape(4, 81).numpy()
+            assert np.abs(eng.sarl_export('V').cpu().numpy() - want).max() <= 1e-5
+
+    run(engine(crowdnav_amd.MIXED), 176, False)
+    with pytest.raises(crowdnav_amd.CrowdNavAmdError) as ei:
+        engine(crowdnav_amd.MIXED).sarl_configure(actions=acts, mlp1_dims=(192, 100))
+    assert ei.value.status == -2  # CN_ERR_UNSUPPORTED
+    assert '160 KiB' in str(ei.value) and 'side buffer' in str(ei.value)
+    run(engine(crowdnav_amd.CIRCLE_CROSSING), 176, True)   # one-tile kernel
+    run(engine(crowdnav_amd.CIRCLE_CROSSING), 192, True)   # chunked kernel: the same network, streamed
