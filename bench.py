@@ -576,7 +576,8 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
         return (bufs['transitions'] if inkernel else bufs['env_transitions']).clone(), bufs['ep_count'].clone()
 
     run(args.preroll)
-    shard_boundary()  # warm-up of the boundary too (lazy code-object loads, communicator setup)
+    for _ in range(3):  # warm-up of the boundary too (lazy code-object loads, communicator setup, its kernels' code in the caches)
+        shard_boundary()
     gc.collect()  # (before the warm-up launches: see no_gc)
     run(args.warmup)
     snap_t, snap_e = snapshot()

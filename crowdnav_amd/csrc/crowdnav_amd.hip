@@ -628,9 +628,13 @@ int cn_records_summary(cn_engine* e, int64_t n_envs, int max_records, int record
     if (rc) return rc;
     if (n_envs < 0 || max_records < 1 || record_capacity < 0 || !blocks || !summary)
         return fail(CN_ERR_INVALID, "cn_records_summary: bad arguments");
-    hipLaunchKernelGGL(cn::records_summary_kernel<cn::BlockRecords>, dim3(cn::kSummaryBlocks), dim3(cn::kSummaryThreads), 0,
-                       e->stream, n_envs, max_records, record_capacity, cn::BlockRecords{blocks, cn::record_block_doubles(max_records)},
-                       summary, e->summary_scratch);
+    const cn::BlockRecords src{blocks, cn::record_block_doubles(max_records)};
+    if (n_envs * max_records <= cn::kSummarySmallItems)
+        hipLaunchKernelGGL(cn::records_summary_small_kernel<cn::BlockRecords>, dim3(1), dim3(cn::kSummarySmallThreads), 0, e->stream,
+                           n_envs, max_records, record_capacity, src, summary);
+    else
+        hipLaunchKernelGGL(cn::records_summary_kernel<cn::BlockRecords>, dim3(cn::kSummaryBlocks), dim3(cn::kSummaryThreads), 0,
+                           e->stream, n_envs, max_records, record_capacity, src, summary, e->summary_scratch);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -642,9 +646,13 @@ int cn_rollout_summary(cn_engine* e, const cn_rollout_io* io, double* summary) {
     if (!summary) return fail(CN_ERR_INVALID, "cn_rollout_summary: summary is NULL");
     if (io->record_capacity < 1) return fail(CN_ERR_INVALID, "cn_rollout_summary: the rollout keeps no records (record_capacity 0)");
     if ((rc = upload_io(e, io))) return rc;
-    hipLaunchKernelGGL(cn::records_summary_kernel<cn::RingRecords>, dim3(cn::kSummaryBlocks), dim3(cn::kSummaryThreads), 0,
-                       e->stream, (int64_t)e->P.B, io->record_capacity, io->record_capacity, cn::RingRecords{e->io_dev}, summary,
-                       e->summary_scratch);
+    if ((int64_t)e->P.B * io->record_capacity <= cn::kSummarySmallItems)
+        hipLaunchKernelGGL(cn::records_summary_small_kernel<cn::RingRecords>, dim3(1), dim3(cn::kSummarySmallThreads), 0, e->stream,
+                           (int64_t)e->P.B, io->record_capacity, io->record_capacity, cn::RingRecords{e->io_dev}, summary);
+    else
+        hipLaunchKernelGGL(cn::records_summary_kernel<cn::RingRecords>, dim3(cn::kSummaryBlocks), dim3(cn::kSummaryThreads), 0,
+                           e->stream, (int64_t)e->P.B, io->record_capacity, io->record_capacity, cn::RingRecords{e->io_dev}, summary,
+                           e->summary_scratch);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }

@@ -305,6 +305,60 @@ __device__ __forceinline__ void lp3_scan(const float4* lines, const float4* proj
     }
 }
 
+// lp3_scan split in two (round 5).  The planar program over the projections onto half-plane i — the inner loop above —
+// reads the projections and their candidates only: NOT the running result (it starts at the normal of half-plane i times the
+// radius).  The running result merely decides whether program i's solution is TAKEN.  So the four non-empty programs of an
+// agent (i = 1..4: 1 + 2 + 3 + 4 steps) run side by side, each on a lane of its own (lp3_inner_program: the item lane that
+// holds slot (i, 0)), and the agent's lane keeps the five outer compare-and-select steps (lp3_outer_scan) — a dependent chain
+// of 4 inner + 5 outer steps and one LDS exchange instead of 10 inner + 5 outer behind 25 ds_read_b128.  Same operations on
+// the same operands in the same order as lp3_scan: bit-identical.
+//   proj / cand: the agent's 10 projected half-planes and their candidates (slot i (i - 1) / 2 + k); li: half-plane i
+//   returns (solution.x, solution.y, infeasible ? 1 : 0, -) of program i
+__device__ __forceinline__ float4 lp3_inner_program(const float4* proj, const float4* cand, int i, const float4 li, float radius) {
+    const int base = i * (i - 1) / 2;
+    float4 pk[4], ck[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // slots beyond the program's own (k >= i) belong to the next program or are unused: masked
+        const int slot = base + k < 10 ? base + k : 9;
+        pk[k] = proj[slot];
+        ck[k] = cand[slot];
+    }
+    float r2x = -li.w * radius, r2y = li.z * radius;  // linearProgram2, directionOpt: start at opt * radius
+    bool failed = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float det = pk[k].z * (pk[k].y - r2y) - pk[k].w * (pk[k].x - r2x);
+        const bool viol = (k < i) & !failed & (det > 0.0f);
+        const bool feasible = ck[k].z != 0.0f;
+        r2x = (viol & feasible) ? ck[k].x : r2x;
+        r2y = (viol & feasible) ? ck[k].y : r2y;
+        failed = failed | (viol & !feasible);
+    }
+    return make_float4(r2x, r2y, failed ? 1.0f : 0.0f, 0.0f);
+}
+//   prog: the agent's row of program solutions, slot i = lp3_inner_program(.., i, ..) for i = 1..4 (slot 0 unused)
+__device__ __forceinline__ void lp3_outer_scan(const float4* lines, const float4* prog, int n, int begin, float radius,
+                                               float& rx, float& ry) {
+    float4 li[5], pg[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        li[i] = lines[i];
+        pg[i] = prog[i];
+    }
+    pg[0] = make_float4(-li[0].w * radius, li[0].z * radius, 0.0f, 0.0f);  // program 0 has no projected half-plane
+    float distance = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float viol_i = li[i].z * (li[i].y - ry) - li[i].w * (li[i].x - rx);
+        const bool active = (i >= begin) & (i < n) & (viol_i > distance);
+        const bool take = active & (pg[i].z == 0.0f);
+        rx = take ? pg[i].x : rx;
+        ry = take ? pg[i].y : ry;
+        const float pen = li[i].z * (li[i].y - ry) - li[i].w * (li[i].x - rx);
+        distance = active ? pen : distance;
+    }
+}
+
 // The same for any MAXL (the 10-half-plane kernels): 45 (i, j) projections and 45 (i, k) candidates per infeasible agent.
 //   slot of (i, k) = i (i - 1) / 2 + k;  lp3_program_of_n: the i of a slot
 template <int MAXL>
@@ -427,6 +481,126 @@ __device__ __forceinline__ void lp_planar_coop(const float4* lines, const int* c
             }
         }
         if (live && l == 0) res[a] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------ 2-D program on three lanes per agent
+// linearProgram2 (Appendix A.4-A.5) for up to 10 half-planes with lane 3 g + m of a wave working for the g-th agent of a chunk of
+// 21: lane m keeps the CONSTRAINT half-planes 3 m .. 3 m + 2 of its agent in registers (half-plane 9 never constrains another
+// one; lane m = 2 merely watches it for violation), 12 + 4 registers instead of the 40 of lp_planar_reg<10>, 63 of 64 lanes
+// busy instead of 21.  Per round every agent advances to its next violated half-plane i (the three lanes agree on it through
+// wave-shift DPP moves), each lane intersects its three half-planes with i — three divisions instead of nine — and folds them
+// into a private interval; the three private intervals are then folded IN LANE ORDER (= line order) onto the speed disc's
+// with RVO2's strict comparisons, which selects exactly the element the sequential loop keeps (the first one in line order
+// that attains the minimum / maximum; RVO2's early exits are monotone, so testing them after the fold is equivalent — as in
+// lp_on_line_reg and lp_planar_coop).  Rounds per step = the largest number of violated half-planes of any agent of the wave
+// (1.5 on average per agent in the 20-human shard), ~150 instructions each, against ~1 500 fully unrolled, mostly masked-off
+// instructions per step.
+//   lines [nA][kLineStride], count [nA], sol [nA] = (pref.x, pref.y, maxSpeed, solve ? 1 : 0)
+//   res   [nA] = (result.x, result.y, int bits: first infeasible half-plane or n, -)
+__device__ __forceinline__ float dpp_lane_below(float v) {  // lane l reads lane l - 1 (wave_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_lane_above(float v) {  // lane l reads lane l + 1 (wave_shl:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+// the values the three lanes of an agent hold, in lane order, on every one of them
+__device__ __forceinline__ void tri_gather(float v, int m, float& v0, float& v1, float& v2) {
+    const float a1 = dpp_lane_below(v), a2 = dpp_lane_below(a1);
+    const float b1 = dpp_lane_above(v), b2 = dpp_lane_above(b1);
+    v0 = m == 0 ? v : (m == 1 ? a1 : a2);
+    v1 = m == 0 ? b1 : (m == 1 ? v : a1);
+    v2 = m == 0 ? b2 : (m == 1 ? b1 : v);
+}
+constexpr int kTriAgents = kWave / 3;  // 21 agents per wave pass
+__device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* count, const float4* sol, float4* res, int nA,
+                                              int threads) {
+    constexpr int kNone = 99;
+    const int tid = opaque_tid();
+    const int wl = tid & (kWave - 1);
+    const int g = wl / 3, m = wl - 3 * g;
+    const int waves = (threads + kWave - 1) / kWave;
+    const float inf = __builtin_inff();
+    for (int chunk = tid / kWave; chunk * kTriAgents < nA; chunk += waves) {
+        const int a = chunk * kTriAgents + g;
+        const bool live = g < kTriAgents && a < nA;
+        const int aa = live ? a : 0;
+        const float4 so = sol[aa];
+        const float ox = so.x, oy = so.y, radius = so.z;
+        const int n = (live && so.w != 0.0f) ? count[aa] : 0;
+        const float4* lq = lines + aa * kLineStride;
+        const float4 c0 = lq[3 * m], c1 = lq[3 * m + 1], c2 = lq[3 * m + 2];  // (slots >= n hold stale half-planes: masked by j < n)
+        const float4 c9 = lq[9];
+        float rx, ry;
+        lp_start_point(radius, ox, oy, rx, ry);
+        int cursor = 0;  // half-planes below the cursor are settled
+        int fail = n;
+        while (true) {
+            // the agent's first violated half-plane at or above the cursor
+            const int j0 = 3 * m;
+            const bool v0 = j0 >= cursor && j0 < n && (c0.z * (c0.y - ry) - c0.w * (c0.x - rx) > 0.0f);
+            const bool v1 = j0 + 1 >= cursor && j0 + 1 < n && (c1.z * (c1.y - ry) - c1.w * (c1.x - rx) > 0.0f);
+            const bool v2 = j0 + 2 >= cursor && j0 + 2 < n && (c2.z * (c2.y - ry) - c2.w * (c2.x - rx) > 0.0f);
+            const bool v9 = m == 2 && 9 >= cursor && 9 < n && (c9.z * (c9.y - ry) - c9.w * (c9.x - rx) > 0.0f);
+            const int mine = v0 ? j0 : (v1 ? j0 + 1 : (v2 ? j0 + 2 : (v9 ? 9 : kNone)));
+            float f0, f1, f2;
+            tri_gather(__int_as_float(mine), m, f0, f1, f2);
+            const int i0 = __float_as_int(f0), i1 = __float_as_int(f1), i2 = __float_as_int(f2);
+            const int first = i0 < i1 ? (i0 < i2 ? i0 : i2) : (i1 < i2 ? i1 : i2);
+            const bool act = live && first != kNone;
+            if (__ballot(act) == 0ull) break;
+            const int i = act ? first : 0;
+            const float4 li = lq[i];
+            const float px = li.x, py = li.y, dx = li.z, dy = li.w;
+            // half-plane i inside the speed disc
+            const float dp = px * dx + py * dy;
+            const float disc = (dp * dp + radius * radius) - (px * px + py * py);
+            bool ok = !(disc < 0.0f);
+            const float root = sqrtf(disc);
+            float t_lo = -dp - root;
+            float t_hi = -dp + root;
+            // this lane's three half-planes against half-plane i, folded in line order into a private interval
+            float hi = inf, lo = -inf;
+            bool bad = false;
+            const float4 cs[3] = {c0, c1, c2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool use = act && j0 + k < i;
+                const float den = dx * cs[k].w - dy * cs[k].z;
+                const float num = cs[k].z * (py - cs[k].y) - cs[k].w * (px - cs[k].x);
+                const bool parallel = fabsf(den) <= kRvoEps;
+                const float t = num / den;
+                bad = bad || (use && parallel && num < 0.0f);
+                const bool upper = use && !parallel && den >= 0.0f;
+                const bool lower = use && !parallel && !(den >= 0.0f);
+                hi = (upper && t < hi) ? t : hi;
+                lo = (lower && lo < t) ? t : lo;
+            }
+            float h0, h1, h2, l0, l1, l2;
+            tri_gather(hi, m, h0, h1, h2);
+            tri_gather(lo, m, l0, l1, l2);
+            t_hi = (h0 < t_hi) ? h0 : t_hi;
+            t_hi = (h1 < t_hi) ? h1 : t_hi;
+            t_hi = (h2 < t_hi) ? h2 : t_hi;
+            t_lo = (t_lo < l0) ? l0 : t_lo;
+            t_lo = (t_lo < l1) ? l1 : t_lo;
+            t_lo = (t_lo < l2) ? l2 : t_lo;
+            const unsigned badm = (unsigned)(__ballot(bad) >> (3 * g)) & 7u;
+            ok = ok && badm == 0u && !(t_lo > t_hi);
+            float tt = dx * (ox - px) + dy * (oy - py);
+            tt = (tt < t_lo) ? t_lo : ((tt > t_hi) ? t_hi : tt);
+            if (act) {
+                if (ok) {
+                    rx = px + tt * dx;
+                    ry = py + tt * dy;
+                    cursor = i + 1;
+                } else {  // linearProgram2 returns i with the previous result
+                    fail = i;
+                    cursor = n;
+                }
+            }
+        }
+        if (live && m == 0) res[a] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
     }
 }
 

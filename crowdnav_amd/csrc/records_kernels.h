@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/crowdnav_amd.h"
+#include "orca_device.h"
 
 namespace cn {
 
@@ -125,6 +126,51 @@ __global__ __launch_bounds__(kSummaryThreads) void records_summary_kernel(int64_
         summary[threadIdx.x] = total;
     }
     if (threadIdx.x == 0) *counter = 0u;
+}
+
+// The same reduction for SMALL inputs (a single engine's rings at the shard boundary of a short run: 4096 envs x 1 record) in
+// ONE workgroup of 1024 threads: no partials in global memory, no ticket, no fence — the two-level kernel above spends 8 us on
+// 4096 items, most of it in the hand-off between its 64 workgroups; this one is a strided pass and a fixed LDS tree.  The
+// summation order is a function of (n_envs, K) only: the same bits on every run, for rings and for packed blocks alike
+// (cn_rollout_summary == cn_records_summary over cn_rollout_records, as tested).
+constexpr int kSummarySmallThreads = 1024;
+constexpr int64_t kSummarySmallItems = 16 * kSummarySmallThreads;  // launch_records_summary: up to 16 items per thread
+template <class Records>
+__global__ __launch_bounds__(kSummarySmallThreads) void records_summary_small_kernel(int64_t n_envs, int K, int capacity, Records src,
+                                                                                     double* summary) {
+    __shared__ double part[kSummaryFields][kSummarySmallThreads / kWave];
+    double acc[kSummaryFields] = {};
+    const int64_t items = n_envs * K;
+    for (int64_t it = threadIdx.x; it < items; it += kSummarySmallThreads) {
+        const int64_t b = it / K;
+        const int j = (int)(it - b * K);
+        double n, r0, r2, r3, r4;
+        src.get(b, j, n, r0, r2, r3, r4);
+        const bool held = (double)j < n && j < capacity;
+        const int outcome = (int)r0;
+        if (j == 0) acc[0] += n;
+        acc[1] += held ? 1.0 : 0.0;
+        acc[2] += (held && outcome == CN_REACH_GOAL) ? 1.0 : 0.0;
+        acc[3] += (held && outcome == CN_COLLISION) ? 1.0 : 0.0;
+        acc[4] += (held && outcome == CN_TIMEOUT) ? 1.0 : 0.0;
+        acc[5] += (held && outcome == CN_REACH_GOAL) ? r3 : 0.0;
+        acc[6] += held ? r2 : 0.0;
+        acc[7] += held ? r4 : 0.0;
+    }
+    // lanes of a wave by a fixed shuffle tree, the 16 waves in index order
+#pragma unroll
+    for (int f = 0; f < kSummaryFields; ++f) {
+        double v = acc[f];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & (kWave - 1)) == 0) part[f][threadIdx.x / kWave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSummaryFields) {
+        double total = 0.0;
+        for (int w = 0; w < kSummarySmallThreads / kWave; ++w) total += part[threadIdx.x][w];
+        summary[threadIdx.x] = total;
+    }
 }
 
 }  // namespace cn

@@ -84,6 +84,12 @@ __device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max
 #define CN_FUSED_PRIO 2
 #endif
 
+// CN_LP3_PAR (compile time, default on): the one-pass fallback runs the four planar programs of an infeasible agent on four
+// lanes (orca_device.h: lp3_inner_program / lp3_outer_scan) instead of all ten inner steps on the agent's own lane (lp3_scan).
+#ifndef CN_LP3_PAR
+#define CN_LP3_PAR 1
+#endif
+
 // CN_WAVE_TRACE (profiling builds): every wave leaves four 100 MHz timestamps (kernel entry, step loop entry / exit, kernel
 // exit) and how many of its steps took the 3-D fallback / ended an episode: scripts/probes/wave_trace.py
 #ifdef CN_WAVE_TRACE
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             if (CN_FUSED_PRIO != 0) __builtin_amdgcn_s_setprio(3);
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int n_todo = __popcll(nm);
+            bool one_pass_done = false;  // (wave-uniform)
             if (n_todo * kPairs <= kWave) {
                 // one pass: item = lane = (t, m); the t-th infeasible agent is the t-th set bit of the ballot (scalar bit
                 // tricks, no LDS list), and the item's half-planes are requested once for both stages
@@ -314,6 +321,16 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                     s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, radius, -li.w, li.z, true);
                 }
                 CN_FUSED_SYNC();
+                if (CN_LP3_PAR != 0) {
+                    // the four planar programs of an infeasible agent side by side: the item lane of slot (i, 0) runs program i
+                    // and leaves its solution in the agent's cand2 row (free since the planar scan above), slot i
+                    if (item && m == base)
+                        s.cand2[a * kLineStride + i] = lp3_inner_program(s.proj + a * kLineStride, s.cand3 + a * kLineStride, i, li, radius);
+                    CN_FUSED_SYNC();
+                    if (need)
+                        lp3_outer_scan(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, fail, s.sol[L.lane].z, rx, ry);
+                    one_pass_done = true;
+                }
             } else {
                 if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
                 CN_FUSED_SYNC();
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 }
                 CN_FUSED_SYNC();
             }
-            if (need)
+            if (need && !one_pass_done)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
                          fail, s.sol[L.lane].z, rx, ry);
             if (CN_FUSED_PRIO == 1) __builtin_amdgcn_s_setprio(0);

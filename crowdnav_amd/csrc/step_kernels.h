@@ -37,6 +37,12 @@ namespace cn {
 #ifndef CN_CAND_LP10
 #define CN_CAND_LP10 2
 #endif
+// CN_TRI_LP10 (compile time, default on): the 10-half-plane kernels solve the planar program on three lanes per agent
+// (lp_planar_tri: 63 of 64 lanes, rounds over the violated half-planes) instead of one unrolled, predicated program per agent
+// lane (lp_planar_reg<10>: 21 of 64 lanes, ~1 500 instructions, 40 registers of half-planes).
+#ifndef CN_TRI_LP10
+#define CN_TRI_LP10 1
+#endif
 
 constexpr int kMaxBlock = 512;  // threads per workgroup of the transition kernels (1..8 waves)
 
@@ -767,6 +773,8 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     constexpr bool kPar = (MAXL == 5) && (CN_PAR_LP5 != 0) && !kCoop;
     constexpr bool kCand10 = (MAXL == 10) && (CN_CAND_LP10 == 1) && !kCoop && !kCand3;
     constexpr bool kLazy3 = (MAXL == 10) && (CN_CAND_LP10 == 2) && !kCoop && !kCand3;  // register planar program, lazy fallback
+    // the 10-half-plane planar program on three lanes per agent (orca_device.h: lp_planar_tri) instead of lp_planar_reg<10>
+    constexpr bool kTri = (MAXL == 10) && (CN_TRI_LP10 != 0) && !kCoop && !kCand10;
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     // (COMPACT: the per-episode constants of the agent — goal, preferred speed, radius — are read from LDS where needed)
     const float max_speed = (L.a == 0) ? robot_max_speed : (float)(COMPACT ? (L.lane < P.nA ? s.vpref[L.lane] : 0.0) : r.vpref);
@@ -788,7 +796,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             s.rad[L.lane] = r.rad;
             s.hview[L.lane] = (float)(r.rad + 0.01 + step_param<COMPACT>(P, s, kParHSafety));
         }
-        if (kCoop || kPar || kCand10) {
+        if (kCoop || kPar || kCand10 || kTri) {
             float pref_x, pref_y;
             preferred(pref_x, pref_y);
             s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
@@ -1035,7 +1043,16 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         float rx = 0.0f, ry = 0.0f;
         int n = 0, fail = 0;
         const float4* mine = s.lines + L.lane * kLineStride;
-        if (solve) {
+        if (kTri) {
+            lp_planar_tri(s.lines, s.count, s.sol, s.res, P.nA, P.threads);  // every thread: lane = (agent, third of its half-planes)
+            block_sync(P);
+            if (solve) {
+                n = s.count[L.lane];
+                const float4 got = s.res[L.lane];
+                rx = got.x, ry = got.y;
+                fail = __float_as_int(got.z);
+            }
+        } else if (solve) {
             n = s.count[L.lane];
             float4 Lr[MAXL];
 #pragma unroll

@@ -282,7 +282,7 @@ typedef struct cn_sarl_config {
  * Layer widths are free (the shipped ones have register-resident kernels).  A sarl.ValueNetwork whose tile — one (env, action)
  * group's activations for all humans plus the pipelined side buffer, 4 x 64 x (H (ks_a + ks_b + ks_c + 4) + ks_b + 3 ks_a) bytes,
  * ks = the widest layer of each buffer in 4-column steps — exceeds the 160 KiB of LDS streams the humans through in chunks
- * instead (at 5 humans: a first mlp1 / mlp3 layer of 192 or more); under the `mixed` rule, whose one-tile kernel masks absent
+ * instead (at 5 humans: a first mlp1 / mlp3 layer wider than 160); under the `mixed` rule, whose one-tile kernel masks absent
  * humans, such a network is CN_ERR_UNSUPPORTED. */
 int cn_sarl_configure(cn_engine* e, const cn_sarl_config* cfg, const double* actions_host);
 /* replaces model.load_state_dict: params_host_array = HOST array of 22 DEVICE pointers to the float32 tensors of

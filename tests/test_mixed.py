@@ -251,9 +251,10 @@ def test_mixed_value_networks_need_five_slots():
 @pytest.mark.gpu
 def test_mixed_value_network_lds_limit_at_the_boundary_width():
     """under the mixed rule the one-tile SARL kernel must hold a tile's activations AND the pipelined side buffer
-    in 160 KiB of LDS (include/crowdnav_amd.h: cn_sarl_configure).  At 5 humans a first mlp1 layer of 176 still fits
-    (159 808 B), 192 does not (168 000 B, although the activations alone — 155 712 B — would): configured and run / refused
-    with a message that says why.  Outside the mixed rule the same 192-wide network streams through the chunked kernel."""
+    in 160 KiB of LDS (include/crowdnav_amd.h: cn_sarl_configure).  At 5 humans a first mlp1 layer of up to 160 fits (the
+    shipped 150 pads to it: 154 112 B), 176 does not (164 928 B, although the activations alone — 153 408 B — would): configured
+    and run / refused with a message that says why.  Outside the mixed rule the same 176-wide network streams through the
+    chunked kernel."""
     import torch
     import crowdnav_amd
     from crowdnav_amd.compat.sarl import ValueNetwork
@@ -278,10 +279,10 @@ def test_mixed_value_network_lds_limit_at_the_boundary_width():
                 want = net(eng.sarl_export('X').cpu().reshape(4 * 81, 5, 13)).reshape(4, 81).numpy()
             assert np.abs(eng.sarl_export('V').cpu().numpy() - want).max() <= 1e-5
 
-    run(engine(crowdnav_amd.MIXED), 176, False)
+    run(engine(crowdnav_amd.MIXED), 160, False)
     with pytest.raises(crowdnav_amd.CrowdNavAmdError) as ei:
-        engine(crowdnav_amd.MIXED).sarl_configure(actions=acts, mlp1_dims=(192, 100))
+        engine(crowdnav_amd.MIXED).sarl_configure(actions=acts, mlp1_dims=(176, 100))
     assert ei.value.status == -2  # CN_ERR_UNSUPPORTED
     assert '160 KiB' in str(ei.value) and 'side buffer' in str(ei.value)
-    run(engine(crowdnav_amd.CIRCLE_CROSSING), 176, True)   # one-tile kernel
-    run(engine(crowdnav_amd.CIRCLE_CROSSING), 192, True)   # chunked kernel: the same network, streamed
+    run(engine(crowdnav_amd.CIRCLE_CROSSING), 160, True)   # one-tile kernel
+    run(engine(crowdnav_amd.CIRCLE_CROSSING), 176, True)   # chunked kernel: the same network, streamed
