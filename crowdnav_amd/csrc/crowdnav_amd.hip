@@ -98,7 +98,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     P.kd = P.A > cn::kKdLeaf ? 1 : 0;  // a simulator of more than 10 agents splits its kd-tree: visiting order matters at ties
     P.sched = -1;
-    e->sched_min = env_int("CROWDNAV_AMD_SCHED_MIN_STEPS", CN_GEOM20_WAVES == 3 ? 48 : (1 << 30));
+    e->sched_min = env_int("CROWDNAV_AMD_SCHED_MIN_STEPS", 48);
     e->sched_force = env_int("CROWDNAV_AMD_SCHED_FORCE", 0) != 0;
     {
         hipDeviceProp_t prop;
@@ -107,7 +107,6 @@ int cn_create(const cn_config* c, cn_engine** out) {
     }
     P.kdl = cn::kd_layout(P.nA, P.A, P.E);
     e->smem = cn::smem_bytes(P.nA, P.pairs, e->maxl, P.A, P.E);
-    e->mt_in_lds = env_int("CROWDNAV_AMD_MT_IN_LDS", 0) != 0;
     e->gen_wave = env_int("CROWDNAV_AMD_WAVE_SCENARIOS", c->num_humans > 8 ? 1 : 0) != 0;
     P.robot_visible = c->robot_visible ? 1 : 0;
     P.robot_orca = c->robot_policy == CN_ROBOT_ORCA;
@@ -154,8 +153,8 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.mt_pos, (size_t)P.B)) || (rc = dev_alloc(e, &e->probe_key, (size_t)624)) ||
         (rc = dev_alloc(e, &S.ring_pos, n * P.ring_depth)) || (rc = dev_alloc(e, &S.ring_goal, n * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.ring_rv, n * P.ring_depth)) ||
-        (rc = dev_alloc(e, &S.ring_mt_key, (e->mt_in_lds || e->gen_wave) ? (size_t)64 : (size_t)624 * cn::kRedoLanes)) ||
-        (rc = dev_alloc(e, &S.redo_list, (e->mt_in_lds || e->gen_wave) ? (size_t)1 : (size_t)P.B * P.ring_depth)) ||
+        (rc = dev_alloc(e, &S.ring_mt_key, e->gen_wave ? (size_t)64 : (size_t)624 * cn::kRedoLanes)) ||
+        (rc = dev_alloc(e, &S.redo_list, e->gen_wave ? (size_t)1 : (size_t)P.B * P.ring_depth)) ||
         (rc = dev_alloc(e, &S.redo_count, (size_t)1)) ||
         (rc = dev_alloc(e, &e->summary_scratch, (size_t)cn::kSummaryBlocks * cn::kSummaryFields + 1)) ||
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
@@ -369,12 +368,9 @@ int cn_reset(cn_engine* e, const uint32_t* seeds, const uint8_t* mask, uint64_t*
     if (e->gen_wave)
         hipLaunchKernelGGL(cn::reset_wave_kernel, dim3(e->P.B), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, seeds, mask,
                            draws);
-    else if (e->mt_in_lds)
-        hipLaunchKernelGGL(cn::reset_kernel<true>, dim3(grid_lanes(e)), dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P,
-                           e->C, e->S, seeds, mask, draws);
     else
-        hipLaunchKernelGGL(cn::reset_kernel<false>, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S,
-                           seeds, mask, draws);
+        hipLaunchKernelGGL(cn::reset_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, seeds, mask,
+                           draws);
     CN_HIP(hipGetLastError());
     return CN_OK;
 }
@@ -463,12 +459,8 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     if (e->gen_wave)
         hipLaunchKernelGGL(cn::rollout_begin_wave_kernel, dim3(e->P.B), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
-    else if (e->mt_in_lds)
-        hipLaunchKernelGGL(cn::rollout_begin_kernel<true>, dim3(grid_lanes(e)), dim3(cn::kWave), cn::kMtLdsBytes, e->stream,
-                           e->P, e->C, e->S, R);
     else
-        hipLaunchKernelGGL(cn::rollout_begin_kernel<false>, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C,
-                           e->S, R);
+        hipLaunchKernelGGL(cn::rollout_begin_kernel, dim3(grid_lanes(e)), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     CN_HIP(hipGetLastError());
     e->steps_since_fill = -1;
     return CN_OK;
@@ -502,12 +494,9 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
     const dim3 fill_grid((fill_lanes + cn::kWave - 1) / cn::kWave);
     if (e->gen_wave) {
         hipLaunchKernelGGL(cn::ring_fill_wave_kernel, dim3(fill_lanes), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
-    } else if (e->mt_in_lds) {
-        hipLaunchKernelGGL(cn::ring_fill_kernel<true>, fill_grid, dim3(cn::kWave), cn::kMtLdsBytes, e->stream, e->P, e->C,
-                           e->S, R);
     } else {
         CN_HIP(hipMemsetAsync(e->S.redo_count, 0, sizeof(int), e->stream));
-        hipLaunchKernelGGL(cn::ring_fill_kernel<false>, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
+        hipLaunchKernelGGL(cn::ring_fill_kernel, fill_grid, dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
         hipLaunchKernelGGL(cn::ring_redo_kernel, dim3(cn::kRedoLanes / cn::kWave), dim3(cn::kWave), 0, e->stream, e->P, e->C,
                            e->S);
     }
@@ -540,8 +529,8 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
                                (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
     } else if (use_geom20 && e->maxl == 10 && !P.robot_unicycle && P.A == 21 && P.NC == 20 && P.E == 1 && P.threads == 64 &&
                P.orca.max_neighbors == 10 && P.kd) {
-        const size_t smem20 = CN_COMPACT20 != 0 ? cn::smem_bytes_compact(P.nA, P.pairs, P.A, P.E) : e->smem;
-        // Three resident waves per SIMD (CN_GEOM20_WAVES): 3072 one-wave workgroups fill the chip, so B = 4096 envs would run as
+        const size_t smem20 = cn::smem_bytes_compact(P.nA, P.pairs, P.A, P.E);
+        // Three resident waves per SIMD (step_kernels.h: kGeom20Waves): 3072 one-wave workgroups fill the chip, so B = 4096 envs would run as
         // a full round plus a third of one.  A call of 3 q + r steps becomes one launch of r steps over all envs (if r > 0) and
         // FOUR launches of q steps over 3 B / 4 workgroups each, sub-launch k leaving out env 3 - k of every group of four
         // (step_kernels.h: Params::sched): every env makes its steps in order, every launch is one round.
@@ -714,6 +703,16 @@ extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
         unsigned long long zero[16] = {};
         zero[13] = ~0ull;  // the fastest wave's total (atomicMin)
         if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_phase_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+#ifdef CN_PHASE_TIMING
+extern "C" int cn_debug_lazy_counts(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(cn::cn_lazy_counts), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_lazy_counts), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -69,7 +69,6 @@ struct cn_engine {
     uint32_t* probe_key;
     double* summary_scratch;  // records_summary_kernel: per-workgroup partials + ticket counter
     int maxl;          // half-planes held in VGPRs by the solve phase: 5 or 10
-    bool mt_in_lds;    // lane-per-scenario generators keep their MT19937 state in LDS instead of HBM
     bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
     size_t smem;       // dynamic LDS bytes per workgroup
     int sched_min, sched_slots;  // the 20-human shard kernel's 3-of-4 env schedule (launch_rollout): shortest call split, resident workgroups

@@ -7,11 +7,13 @@
 // contraction (the translation unit is built with -ffp-contract=off), correctly rounded / and sqrt
 // (hipcc default), vector / scalar = multiply by the reciprocal.
 //
-// Work decomposition inside one wave (see crowdnav_amd.hip): half-planes are built by one lane per
-// (agent, candidate neighbour) pair and parked in LDS as one float4 {point.x, point.y, dir.x, dir.y} per
-// slot; the agent's own lane then pulls its <= MAXL half-planes into VGPRs and runs the 2-D program fully
-// unrolled and predicated (no divergent trip counts, no dependent LDS chains).  Only the rare infeasible
-// case (3-D fallback) runs the generic loops below directly on the LDS copy.
+// Work decomposition inside one wave (step_kernels.h, rollout_fused.h): half-planes are built by one lane per (agent,
+// candidate neighbour) pair and parked in LDS as one float4 {point.x, point.y, dir.x, dir.y} per slot.  Crowds of up to 5
+// neighbours solve in CANDIDATE FORM (1-D solutions of all (agent, half-plane) pairs at once, a short scan per agent; the 3-D
+// fallback likewise on (agent, i, j) lanes); 10-half-plane programs run on three lanes per agent (lp_planar_tri) with the
+// fallback in lazily evaluated candidate form (lp_relaxed_lazy) or in shuffle rounds (lp_relaxed_coop).  What was tried and
+// rejected on the way (register-resident unrolled programs, all-lane cooperative planar programs, serial LDS walks) is
+// profiles/HISTORY.md.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -101,73 +103,13 @@ __device__ __forceinline__ void lp_start_point(float radius, float ox, float oy,
     }
 }
 
-// ------------------------------------------------------------------ register-resident 2-D program
-// 1-D program on half-plane K against the K earlier ones (Appendix A.5), optimising towards point (ox, oy).
-// K is a compile-time constant after unrolling, so L[] never leaves the VGPR file.
-template <int MAXL>
-__device__ __forceinline__ bool lp_on_line_reg(const float4 (&L)[MAXL], int k, float radius, float ox,
-                                               float oy, float& rx, float& ry) {
-    const float px = L[k].x, py = L[k].y, dx = L[k].z, dy = L[k].w;
-    const float dp = px * dx + py * dy;
-    const float disc = (dp * dp + radius * radius) - (px * px + py * py);
-    bool ok = !(disc < 0.0f);
-    const float root = sqrtf(disc);
-    float t_lo = -dp - root;
-    float t_hi = -dp + root;
-    // Branch-free form of RVO2's loop: a failed program keeps ok == false whatever follows, and the interval
-    // test is monotone (t_lo only grows, t_hi only shrinks), so evaluating it every iteration is equivalent.
-#pragma unroll
-    for (int i = 0; i < MAXL - 1; ++i) {
-        if (i < k) {
-            const float den = dx * L[i].w - dy * L[i].z;
-            const float num = L[i].z * (py - L[i].y) - L[i].w * (px - L[i].x);
-            const bool parallel = fabsf(den) <= kRvoEps;
-            const float t = num / den;
-            ok = ok && !(parallel && num < 0.0f);
-            const bool upper = !parallel && den >= 0.0f;
-            const bool lower = !parallel && !(den >= 0.0f);
-            t_hi = (upper && t < t_hi) ? t : t_hi;
-            t_lo = (lower && t_lo < t) ? t : t_lo;
-            ok = ok && !(t_lo > t_hi);
-        }
-    }
-    float t = dx * (ox - px) + dy * (oy - py);
-    t = (t < t_lo) ? t_lo : ((t > t_hi) ? t_hi : t);
-    rx = ok ? px + t * dx : rx;
-    ry = ok ? py + t * dy : ry;
-    return ok;
-}
-
-// 2-D program over the first n of MAXL register-resident half-planes; returns the first infeasible index or n.
-template <int MAXL>
-__device__ __forceinline__ int lp_planar_reg(const float4 (&L)[MAXL], int n, float radius, float ox, float oy,
-                                             float& rx, float& ry) {
-    lp_start_point(radius, ox, oy, rx, ry);
-    int fail = n;
-#pragma unroll
-    for (int i = 0; i < MAXL; ++i) {
-        if (i < fail) {
-            if (L[i].z * (L[i].y - ry) - L[i].w * (L[i].x - rx) > 0.0f) {
-                float nx = rx, ny = ry;
-                if (lp_on_line_reg<MAXL>(L, i, radius, ox, oy, nx, ny)) {
-                    rx = nx;
-                    ry = ny;
-                } else {
-                    fail = i;
-                }
-            }
-        }
-    }
-    return fail;
-}
-
 // ------------------------------------------------------------------ candidate form of the programs
 // RVO2's linearProgram1 on half-plane k (Appendix A.5) reads the half-planes 0..k, the speed disc and the optimisation
 // target — NOT the running result of linearProgram2: the running result only decides WHETHER half-plane k is violated, i.e.
 // whether the 1-D solution replaces it.  So the 1-D solutions ("candidates") of all half-planes of all agents can be
 // computed at once, one lane per (agent, half-plane), with the divisions of one candidate independent of each other; what
 // remains serial per agent is a scan of MAXL compare-and-select steps (lp_planar_scan).  Same operations on the same
-// operands in the same order as lp_on_line_reg, so the results are bit-identical; a half-plane the sequential program
+// operands in the same order as RVO2's own loop, so the results are bit-identical; a half-plane the sequential program
 // never reaches merely has an unused candidate.
 //   lk: half-plane k; prev: half-planes 0.. of the same program in LDS (NJ slots are read, j >= k ignored)
 //   returns (candidate.x, candidate.y, feasible ? 1 : 0, -)
@@ -226,24 +168,6 @@ __device__ __forceinline__ int lp_planar_scan(const float4* lines, const float4*
         const bool feasible = ck[k].z != 0.0f;
         rx = (viol & feasible) ? ck[k].x : rx;
         ry = (viol & feasible) ? ck[k].y : ry;
-        fail = (viol & !feasible) ? k : fail;
-    }
-    return fail;
-}
-
-// The same scan for 10 half-planes: the slots are requested as the scan reaches them (two at a time by the unroller), not
-// all 20 float4 up front — 80 VGPRs that the 10-half-plane kernels do not have.
-template <int MAXL>
-__device__ __forceinline__ int lp_planar_scan_stream(const float4* lines, const float4* cand, int n, float& rx, float& ry) {
-    int fail = n;
-#pragma unroll 2
-    for (int k = 0; k < MAXL; ++k) {
-        const float4 lk = lines[k], ck = cand[k];
-        const float det = lk.z * (lk.y - ry) - lk.w * (lk.x - rx);
-        const bool viol = (k < fail) & (det > 0.0f);
-        const bool feasible = ck.z != 0.0f;
-        rx = (viol & feasible) ? ck.x : rx;
-        ry = (viol & feasible) ? ck.y : ry;
         fail = (viol & !feasible) ? k : fail;
     }
     return fail;
@@ -359,141 +283,15 @@ __device__ __forceinline__ void lp3_outer_scan(const float4* lines, const float4
     }
 }
 
-// The same for any MAXL (the 10-half-plane kernels): 45 (i, j) projections and 45 (i, k) candidates per infeasible agent.
-//   slot of (i, k) = i (i - 1) / 2 + k;  lp3_program_of_n: the i of a slot
-template <int MAXL>
-__device__ __forceinline__ int lp3_program_of_n(int m) {
-    int i = 1;
-#pragma unroll
-    for (int t = 2; t < MAXL; ++t) i += (m >= t * (t - 1) / 2) ? 1 : 0;  // thresholds 1, 3, 6, 10, ...
-    return i;
-}
-template <int MAXL>
-__device__ __forceinline__ void lp3_scan_n(const float4* lines, const float4* proj, const float4* cand, int n, int begin,
-                                           float radius, float& rx, float& ry) {
-    float distance = 0.0f;
-#pragma unroll
-    for (int i = 0; i < MAXL; ++i) {
-        const float4 li = lines[i];
-        float4 pk[MAXL - 1], ck[MAXL - 1];  // program i's projected half-planes and their candidates: requested together
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-            pk[k] = proj[i * (i - 1) / 2 + k];
-            ck[k] = cand[i * (i - 1) / 2 + k];
-        }
-        const float viol_i = li.z * (li.y - ry) - li.w * (li.x - rx);
-        const bool active = (i >= begin) & (i < n) & (viol_i > distance);
-        float r2x = -li.w * radius, r2y = li.z * radius;  // linearProgram2, directionOpt: start at opt * radius
-        bool failed = false;
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-            const float det = pk[k].z * (pk[k].y - r2y) - pk[k].w * (pk[k].x - r2x);
-            const bool viol = !failed & (det > 0.0f);
-            const bool feasible = ck[k].z != 0.0f;
-            r2x = (viol & feasible) ? ck[k].x : r2x;
-            r2y = (viol & feasible) ? ck[k].y : r2y;
-            failed = failed | (viol & !feasible);
-        }
-        rx = (active & !failed) ? r2x : rx;
-        ry = (active & !failed) ? r2y : ry;
-        const float pen = li.z * (li.y - ry) - li.w * (li.x - rx);
-        distance = active ? pen : distance;
-    }
-}
-
-// ------------------------------------------------------------------ lane-cooperative 2-D program
-// The same program with one lane per (agent, half-plane): a wave holds kWave / MAXL agents (12 at MAXL = 5), lane
-// g * MAXL + l owns half-plane l of the g-th agent of the chunk.  Per round every agent advances to its next violated
-// half-plane i (ballot + first set bit of the agent's MAXL-bit field) and solves the 1-D program on it: lane l < i
-// contributes the one (numerator, denominator) pair of line l against line i, and the running interval
-// [t_lo, t_hi] is folded over the agent's lanes IN LINE ORDER with RVO2's strict comparisons, so ties (and signed
-// zeros) resolve exactly as in the sequential loop.  RVO2's early exits (parallel line with negative numerator,
-// t_lo > t_hi) are monotone — once true they stay true — so testing them after the fold is equivalent.
-// Rounds per step = the largest number of violated half-planes of any agent in the wave (<= MAXL), each ~100 VALU
-// on all lanes, instead of one fully unrolled, predicated program per agent lane on 12 of 64 lanes.
-//   lines [nA][kLineStride] half-planes, count [nA], sol [nA] = (pref.x, pref.y, maxSpeed, solve ? 1 : 0)
-//   res   [nA] = (result.x, result.y, int bits: first infeasible line or n, -)
-template <int MAXL>
-__device__ __forceinline__ void lp_planar_coop(const float4* lines, const int* count, const float4* sol, float4* res,
-                                               int nA) {
-    constexpr int G = kWave / MAXL;
-    const int wl = threadIdx.x & (kWave - 1);
-    const int g = wl / MAXL, l = wl - g * MAXL;
-    const int gbase = g * MAXL;
-    const int waves = ((int)blockDim.x + kWave - 1) / kWave;
-    const float inf = __builtin_inff();
-    for (int chunk = threadIdx.x / kWave; chunk * G < nA; chunk += waves) {
-        const int a = chunk * G + g;
-        const bool live = g < G && a < nA;
-        const float4 so = sol[live ? a : 0];
-        const float ox = so.x, oy = so.y, radius = so.z;
-        const int n = (live && so.w != 0.0f) ? count[a] : 0;
-        const float4 my = (l < n) ? lines[a * kLineStride + l] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float rx, ry;
-        lp_start_point(radius, ox, oy, rx, ry);
-        int cursor = 0;  // half-planes below the cursor are settled
-        int fail = n;
-        while (true) {
-            const bool viol = l >= cursor && l < n && (my.z * (my.y - ry) - my.w * (my.x - rx) > 0.0f);
-            const unsigned long long m = __ballot(viol);
-            if (m == 0ull) break;
-            const unsigned gm = (unsigned)(m >> gbase) & ((1u << MAXL) - 1u);
-            const bool act = gm != 0u;
-            const int i = act ? __ffs(gm) - 1 : 0;
-            const float4 li = lines[(live ? a : 0) * kLineStride + i];  // read-only here: plain LDS broadcast
-            const float px = li.x, py = li.y, dx = li.z, dy = li.w;
-            // this lane's line against line i
-            const float den = dx * my.w - dy * my.z;
-            const float num = my.z * (py - my.y) - my.w * (px - my.x);
-            const bool parallel = fabsf(den) <= kRvoEps;
-            const float t = num / den;
-            const bool mine = act && l < i;
-            const bool bad = mine && parallel && num < 0.0f;
-            const float c_hi = (mine && !parallel && den >= 0.0f) ? t : inf;
-            const float c_lo = (mine && !parallel && !(den >= 0.0f)) ? t : -inf;
-            const unsigned badm = (unsigned)(__ballot(bad) >> gbase) & ((1u << MAXL) - 1u);
-            // interval of line i inside the speed disc
-            const float dp = px * dx + py * dy;
-            const float disc = (dp * dp + radius * radius) - (px * px + py * py);
-            bool ok = !(disc < 0.0f) && badm == 0u;
-            const float root = sqrtf(disc);
-            float t_lo = -dp - root;
-            float t_hi = -dp + root;
-#pragma unroll
-            for (int j = 0; j < MAXL - 1; ++j) {  // the last line never constrains another one
-                const float hj = __shfl(c_hi, gbase + j);
-                const float lj = __shfl(c_lo, gbase + j);
-                t_hi = (hj < t_hi) ? hj : t_hi;
-                t_lo = (t_lo < lj) ? lj : t_lo;
-            }
-            ok = ok && !(t_lo > t_hi);
-            float tt = dx * (ox - px) + dy * (oy - py);
-            tt = (tt < t_lo) ? t_lo : ((tt > t_hi) ? t_hi : tt);
-            if (act) {
-                if (ok) {
-                    rx = px + tt * dx;
-                    ry = py + tt * dy;
-                    cursor = i + 1;
-                } else {  // linearProgram2 returns i with the previous result
-                    fail = i;
-                    cursor = n;
-                }
-            }
-        }
-        if (live && l == 0) res[a] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
-    }
-}
-
 // ------------------------------------------------------------------ 2-D program on three lanes per agent
 // linearProgram2 (Appendix A.4-A.5) for up to 10 half-planes with lane 3 g + m of a wave working for the g-th agent of a chunk of
 // 21: lane m keeps the CONSTRAINT half-planes 3 m .. 3 m + 2 of its agent in registers (half-plane 9 never constrains another
-// one; lane m = 2 merely watches it for violation), 12 + 4 registers instead of the 40 of lp_planar_reg<10>, 63 of 64 lanes
+// one; lane m = 2 merely watches it for violation), 12 + 4 registers instead of the 40 an unrolled per-lane program keeps, 63 of 64 lanes
 // busy instead of 21.  Per round every agent advances to its next violated half-plane i (the three lanes agree on it through
 // wave-shift DPP moves), each lane intersects its three half-planes with i — three divisions instead of nine — and folds them
 // into a private interval; the three private intervals are then folded IN LANE ORDER (= line order) onto the speed disc's
 // with RVO2's strict comparisons, which selects exactly the element the sequential loop keeps (the first one in line order
-// that attains the minimum / maximum; RVO2's early exits are monotone, so testing them after the fold is equivalent — as in
-// lp_on_line_reg and lp_planar_coop).  Rounds per step = the largest number of violated half-planes of any agent of the wave
+// that attains the minimum / maximum; RVO2's early exits are monotone, so testing them after the fold is equivalent).  Rounds per step = the largest number of violated half-planes of any agent of the wave
 // (1.5 on average per agent in the 20-human shard), ~150 instructions each, against ~1 500 fully unrolled, mostly masked-off
 // instructions per step.
 //   lines [nA][kLineStride], count [nA], sol [nA] = (pref.x, pref.y, maxSpeed, solve ? 1 : 0)
@@ -606,11 +404,10 @@ __device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* co
 
 // ------------------------------------------------------------------ lane-cooperative 3-D fallback
 // linearProgram3 (Appendix A.6) for the agents whose planar program was infeasible, with one lane per (agent, half-plane)
-// like lp_planar_coop.  The per-agent serial version (lp_relaxed_lds) walks LDS with a dependent load per inner
-// iteration while the other 60-odd lanes of the wave wait for it: 18 % of a step at 5 humans, 52 % at 20
-// (profiles/r01_phase_probe.txt).  Here, per outer round, every agent advances to its next half-plane i whose
+// (a per-agent serial walk of LDS with a dependent load per inner iteration, the other 60-odd lanes of the wave waiting, was
+// 52 % of a step at 20 humans: profiles/r01_phase_probe.txt).  Here, per outer round, every agent advances to its next half-plane i whose
 // violation exceeds the running distance; lane j < i projects half-plane j onto i (one division, one rsqrt — all j at
-// once), and the planar program over the projected lines (directionOpt) runs in rounds exactly like lp_planar_coop:
+// once), and the planar program over the projected lines (directionOpt) runs in ballot / fold rounds:
 // first violated projected line k, lanes j < k contribute their bound on k, fold in line order.  Projected lines that
 // RVO2 skips (parallel, same direction) simply hold no line; order and every arithmetic operation are RVO2's.
 //   res [nA] in: (result.x, result.y, int bits: first infeasible line), out: result
@@ -719,10 +516,10 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
 }
 
 // ------------------------------------------------------------------ 3-D fallback, candidate form evaluated lazily
-// linearProgram3 (Appendix A.6) for 10 half-planes.  The candidate form of lp3_scan_n computes the projections and 1-D
+// linearProgram3 (Appendix A.6) for 10 half-planes.  The all-pairs candidate form (lp3_scan at 5 half-planes) would compute the projections and 1-D
 // solutions of ALL 45 (i, j) pairs of an infeasible agent up front — at 5 half-planes (10 pairs) that is what makes the
 // fallback cheap, at 10 it costs as much as it saves, because the sequential program only ever visits the few outer
-// half-planes i whose violation exceeds the running distance (CN_CAND_LP3_10, rejected).  lp_relaxed_coop does visit only
+// half-planes i whose violation exceeds the running distance (built and rejected: profiles/HISTORY.md).  lp_relaxed_coop does visit only
 // those, but solves each projected planar program in ballot / shuffle rounds: one round per violated projected line, 18
 // ds_bpermute each.  This version keeps coop's outer structure — lane = (agent, half-plane), the agents of a pass advance
 // together to their next violated half-plane i — and solves the projected program of that ONE i in candidate form: lane l < i
@@ -735,6 +532,11 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
 //   agents that need the fallback, compacted (kWave / MAXL of them share a pass)
 //   GROUP_ROWS: proj holds one row of MAXL - 1 projected half-planes per lane GROUP of the wave (kWave / (MAXL - 1) rows: the
 //   compact LDS layout of the 20-human shard's kernel) instead of one row of kLineStride per agent
+#ifdef CN_PHASE_TIMING
+// profiling builds: [0] calls, [1] rounds that solved a projected program, [2] iterations that only handed agents out,
+// [3] agents taken, [4] clock ticks inside the function (wave 0 lane 0 of every workgroup)
+static __device__ unsigned long long cn_lazy_counts[8];
+#endif
 template <int MAXL, bool GROUP_ROWS = false>
 __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* proj, float4* cand, const int* count,
                                                 const float4* sol, float4* res, const int* todo, int n_todo, int threads) {
@@ -752,6 +554,10 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
     const int gbase = g * W;
     const int waves = (threads + kWave - 1) / kWave;
     float4* const crow = cand + ((tid / kWave) * G + (g < G ? g : 0)) * W;
+#ifdef CN_PHASE_TIMING
+    unsigned long long pt_rounds = 0ull, pt_hand = 0ull;
+    const unsigned long long pt_t0 = __builtin_readcyclecounter();
+#endif
     for (int chunk = tid / kWave; chunk * G < n_todo; chunk += waves) {
         const int hand_end = waves == 1 ? n_todo : (chunk * G + G < n_todo ? chunk * G + G : n_todo);  // agents this wave works off
         int next = chunk * G + G;                                                                     // ... the next one to hand out
@@ -793,10 +599,16 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
                     const int idx = next + __popcll(idle & ((1ull << gbase) - 1ull));
                     if (!act) take(idx);
                     next += __popcll(idle);
+#ifdef CN_PHASE_TIMING
+                    ++pt_hand;
+#endif
                     continue;
                 }
             }
             if ((m | mw) == 0ull) break;
+#ifdef CN_PHASE_TIMING
+            ++pt_rounds;
+#endif
             const int i = act ? __ffs(gm) - 1 : 0;
             const float4 li = lines[a * kLineStride + i];
             // my half-plane projected onto half-plane i (the ones RVO2 leaves out, and lanes l >= i, hold an inert line)
@@ -829,109 +641,15 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
         }
         if (waves == 1) break;
     }
-}
-
-// ------------------------------------------------------------------ generic programs on LDS half-planes
-// (used by the infeasible fallback only; same arithmetic as the register versions)
-__device__ inline bool lp_on_line_lds(const float4* L, int k, float radius, float ox, float oy, bool dir_opt,
-                                      float& rx, float& ry) {
-    const float4 lk = L[k];
-    const float px = lk.x, py = lk.y, dx = lk.z, dy = lk.w;
-    const float dp = px * dx + py * dy;
-    const float disc = (dp * dp + radius * radius) - (px * px + py * py);
-    if (disc < 0.0f) return false;
-    const float root = sqrtf(disc);
-    float t_lo = -dp - root;
-    float t_hi = -dp + root;
-    for (int i = 0; i < k; ++i) {
-        const float4 li = L[i];
-        const float den = dx * li.w - dy * li.z;
-        const float num = li.z * (py - li.y) - li.w * (px - li.x);
-        if (fabsf(den) <= kRvoEps) {
-            if (num < 0.0f) return false;
-            continue;
-        }
-        const float t = num / den;
-        if (den >= 0.0f) {
-            t_hi = (t < t_hi) ? t : t_hi;
-        } else {
-            t_lo = (t_lo < t) ? t : t_lo;
-        }
-        if (t_lo > t_hi) return false;
+#ifdef CN_PHASE_TIMING
+    if (tid == 0) {
+        atomicAdd(&cn_lazy_counts[0], 1ull);
+        atomicAdd(&cn_lazy_counts[1], pt_rounds);
+        atomicAdd(&cn_lazy_counts[2], pt_hand);
+        atomicAdd(&cn_lazy_counts[3], (unsigned long long)n_todo);
+        atomicAdd(&cn_lazy_counts[4], __builtin_readcyclecounter() - pt_t0);
     }
-    float t;
-    if (dir_opt) {
-        t = (ox * dx + oy * dy > 0.0f) ? t_hi : t_lo;
-    } else {
-        t = dx * (ox - px) + dy * (oy - py);
-        if (t < t_lo) {
-            t = t_lo;
-        } else if (t > t_hi) {
-            t = t_hi;
-        }
-    }
-    rx = px + t * dx;
-    ry = py + t * dy;
-    return true;
-}
-
-__device__ inline int lp_planar_lds(const float4* L, int n, float radius, float ox, float oy, bool dir_opt,
-                                    float& rx, float& ry) {
-    if (dir_opt) {
-        rx = ox * radius;
-        ry = oy * radius;
-    } else {
-        lp_start_point(radius, ox, oy, rx, ry);
-    }
-    for (int i = 0; i < n; ++i) {
-        const float4 li = L[i];
-        if (li.z * (li.y - ry) - li.w * (li.x - rx) > 0.0f) {
-            const float kx = rx, ky = ry;
-            if (!lp_on_line_lds(L, i, radius, ox, oy, dir_opt, rx, ry)) {
-                rx = kx;
-                ry = ky;
-                return i;
-            }
-        }
-    }
-    return n;
-}
-
-// Fallback when the planar program is infeasible: minimise the maximum penetration (Appendix A.6).
-// L: the agent's n half-planes, Pj: scratch for the projected ones (both LDS, float4 per slot).
-__device__ inline void lp_relaxed_lds(const float4* L, float4* Pj, int n, int begin, float radius, float& rx,
-                                      float& ry) {
-    float distance = 0.0f;
-    for (int i = begin; i < n; ++i) {
-        const float4 li = L[i];
-        if (li.z * (li.y - ry) - li.w * (li.x - rx) > distance) {
-            int m = 0;
-            for (int j = 0; j < i; ++j) {
-                const float4 lj = L[j];
-                const float d = li.z * lj.w - li.w * lj.z;
-                float qx, qy;
-                if (fabsf(d) <= kRvoEps) {
-                    if (li.z * lj.z + li.w * lj.w > 0.0f) continue;  // same direction: j adds nothing
-                    qx = 0.5f * (li.x + lj.x);
-                    qy = 0.5f * (li.y + lj.y);
-                } else {
-                    const float t = (lj.z * (li.y - lj.y) - lj.w * (li.x - lj.x)) / d;
-                    qx = li.x + t * li.z;
-                    qy = li.y + t * li.w;
-                }
-                const float ex = lj.z - li.z, ey = lj.w - li.w;
-                const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
-                Pj[m] = make_float4(qx, qy, ex * inv, ey * inv);
-                ++m;
-            }
-            const float kx = rx, ky = ry;
-            if (lp_planar_lds(Pj, m, radius, -li.w, li.z, true, rx, ry) < m) {
-                rx = kx;
-                ry = ky;
-            }
-            distance = li.z * (li.y - ry) - li.w * (li.x - rx);
-        }
-    }
+#endif
 }
 
 }  // namespace cn

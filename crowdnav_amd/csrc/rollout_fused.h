@@ -33,12 +33,9 @@ struct EpisodeRegs {  // replicated on every agent lane of the env
 // register allocator spilled that 16-dword block into VGPR lanes and re-read it with v_readlane five times per step (107
 // v_readlane of the loop's ~1 450 instructions: every one a VALU issue slot).  As VALU operands they are needed in VGPRs
 // anyway; the empty asm makes the copy explicit and opaque, so the values stay there (16 VGPRs; the kernel has room up to 168).
-// (CN_EXP_SGPR_PARAMS: the A/B build that leaves them where the compiler puts them.)
 template <typename T>
 __device__ __forceinline__ T in_vgpr(T x) {
-#ifndef CN_EXP_SGPR_PARAMS
     asm volatile("" : "+v"(x));
-#endif
     return x;
 }
 
@@ -69,26 +66,15 @@ __device__ __forceinline__ void preferred_velocity(const AgentRegs& r, float max
 
 // The fused kernel is ONE wave per workgroup: LDS instructions of a wave execute in order, so what the phases need between a
 // lane's write and another lane's read is only that the compiler keeps the accesses in program order — not s_barrier with
-// its s_waitcnt lgkmcnt(0) in front (the LDS queue drained five times per step).  -DCN_EXP_FUSED_BARRIER restores __syncthreads.
-#ifdef CN_EXP_FUSED_BARRIER
-#define CN_FUSED_SYNC() __syncthreads()
-#else
+// its s_waitcnt lgkmcnt(0) in front (the LDS queue drained five times per step).
 #define CN_FUSED_SYNC() wave_lds_sync()
-#endif
 
-// CN_FUSED_PRIO (compile time): a launch ends with its slowest wave, and in the short launches of the driver's shape (20
-// steps) that is a wave whose env sits in a jam and takes the 3-D fallback every step — 1.8 x the latency of a step without
-// it — while the wave it shares the SIMD with has slack.  1: the wave raises its issue priority (s_setprio) for the fallback
-// block; 2: it keeps the raised priority through the next step as well (a jam lasts many steps).  0: off.
-#ifndef CN_FUSED_PRIO
-#define CN_FUSED_PRIO 2
-#endif
-
-// CN_LP3_PAR (compile time, default on): the one-pass fallback runs the four planar programs of an infeasible agent on four
-// lanes (orca_device.h: lp3_inner_program / lp3_outer_scan) instead of all ten inner steps on the agent's own lane (lp3_scan).
-#ifndef CN_LP3_PAR
-#define CN_LP3_PAR 1
-#endif
+// Issue priority: a launch ends with its slowest wave, and that is a wave whose env sits in a jam and takes the 3-D fallback
+// every step — 1.6 x the latency of a step without it — while the wave it shares the SIMD with has slack.  A wave entering the
+// fallback raises its priority (s_setprio 3) and keeps it until the first step that does without (a jam lasts many steps):
+// nothing at 20 steps per launch, +3-5 % at 1000.
+// The one-pass fallback runs the four planar programs of an infeasible agent on four lanes (orca_device.h: lp3_inner_program /
+// lp3_outer_scan); the multi-pass form (more than six infeasible agents in a wave) keeps lp3_scan.
 
 // CN_WAVE_TRACE (profiling builds): every wave leaves four 100 MHz timestamps (kernel entry, step loop entry / exit, kernel
 // exit) and how many of its steps took the 3-D fallback / ended an episode: scripts/probes/wave_trace.py
@@ -200,14 +186,6 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
     stage_agent(P, s, L, r, c_hsafety);
     CN_FUSED_SYNC();
 
-#ifdef CN_EXP_DESYNC
-    {   // experiment: the waves in odd slots of a SIMD start the step loop CN_EXP_DESYNC x 64 clocks late, so that the two waves
-        // of a SIMD are not in the same phase (same stalls, same unit) from the first step on
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if (hw & 1u) __builtin_amdgcn_s_sleep(CN_EXP_DESYNC);
-    }
-#endif
 #ifdef CN_PHASE_TIMING
     PhaseClock clock = {};
     PhaseClock* clk = &clock;
@@ -288,12 +266,12 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
 #ifdef CN_PHASE_TIMING
         clock.acc[9] += __popcll(nm);
 #endif
-        if (CN_FUSED_PRIO == 2 && nm == 0ull) __builtin_amdgcn_s_setprio(0);
+        if (nm == 0ull) __builtin_amdgcn_s_setprio(0);
         if (nm != 0ull) {  // wave-uniform: some agent of this wave was infeasible
 #ifdef CN_WAVE_TRACE
             ++wt_fallbacks;
 #endif
-            if (CN_FUSED_PRIO != 0) __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(3);
             constexpr int kPairs = MAXL * (MAXL - 1) / 2;
             const int n_todo = __popcll(nm);
             bool one_pass_done = false;  // (wave-uniform)
@@ -321,16 +299,14 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                     s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, radius, -li.w, li.z, true);
                 }
                 CN_FUSED_SYNC();
-                if (CN_LP3_PAR != 0) {
-                    // the four planar programs of an infeasible agent side by side: the item lane of slot (i, 0) runs program i
-                    // and leaves its solution in the agent's cand2 row (free since the planar scan above), slot i
-                    if (item && m == base)
-                        s.cand2[a * kLineStride + i] = lp3_inner_program(s.proj + a * kLineStride, s.cand3 + a * kLineStride, i, li, radius);
-                    CN_FUSED_SYNC();
-                    if (need)
-                        lp3_outer_scan(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, fail, s.sol[L.lane].z, rx, ry);
-                    one_pass_done = true;
-                }
+                // the four planar programs of an infeasible agent side by side: the item lane of slot (i, 0) runs program i
+                // and leaves its solution in the agent's cand2 row (free since the planar scan above), slot i
+                if (item && m == base)
+                    s.cand2[a * kLineStride + i] = lp3_inner_program(s.proj + a * kLineStride, s.cand3 + a * kLineStride, i, li, radius);
+                CN_FUSED_SYNC();
+                if (need)
+                    lp3_outer_scan(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, fail, s.sol[L.lane].z, rx, ry);
+                one_pass_done = true;
             } else {
                 if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
                 CN_FUSED_SYNC();
@@ -356,7 +332,6 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             if (need && !one_pass_done)
                 lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
                          fail, s.sol[L.lane].z, rx, ry);
-            if (CN_FUSED_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         }
         CN_TICK(clk, 8);
 

@@ -21,19 +21,11 @@ namespace cn {
 // (8 per 624-word block of the generator).
 __device__ __forceinline__ void wave_sync() { wave_lds_sync(); }
 
-// CN_GEN_PREFILTER (compile time, default on): the conservative float32 prefilter of the circle-crossing rejection loop
-#ifndef CN_GEN_PREFILTER
-#define CN_GEN_PREFILTER 1
-#endif
-
-// CN_GEN_WINDOW (compile time, default on): without randomised attributes every human's attempts look the same — the
-// stream continues right behind the accepted attempt, same radius, same noise scale — so the 64 attempts a wave has
-// evaluated are not thrown away when one of them is accepted: the lanes behind it ARE the next human's first attempts, and
-// all they still have to clear is the human just placed (two exact distance tests).  An easy scenario (20 humans on the
-// 12 m circle: one or two candidates per human) costs two or three window evaluations instead of twenty.
-#ifndef CN_GEN_WINDOW
-#define CN_GEN_WINDOW 1
-#endif
+// Window reuse (circle crossing, fixed attributes): every human's attempts look the same — the stream continues right behind
+// the accepted attempt, same radius, same noise scale — so the 64 attempts a wave has evaluated are not thrown away when one of
+// them is accepted: the lanes behind it ARE the next human's first attempts, and all they still have to clear is the human just
+// placed (two exact distance tests).  An easy scenario (20 humans on the 12 m circle: one or two candidates per human) costs two
+// or three window evaluations instead of twenty.
 
 struct WaveRng {
     uint32_t* key;   // [624] generator state (LDS)
@@ -200,7 +192,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
         rv[base] = make_double2(c.robot_radius, c.robot_v_pref);
     }
     wave_sync();
-    // window state of the CN_GEN_WINDOW path (circle crossing, fixed attributes): lane l holds the attempt at stream position
+    // window state of the window-reuse path (circle crossing, fixed attributes): lane l holds the attempt at stream position
     // rng.cursor + 6 l once `win` is set; lanes below wstart belong to humans already placed
     bool win = false, w_collide = true;
     int wstart = 0;
@@ -215,7 +207,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
         }
         unsigned long long attempts = 0;
         const float vpf = (float)v_pref;
-        if (c.rule == 0 && !c.randomize && CN_GEN_WINDOW != 0) {
+        if (c.rule == 0 && !c.randomize) {
             // the reference examines attempts until one is free (crowd_sim.py:159-175); this generator gives up after N of them,
             // counted per human in passes of 64 like the loop below (attempt N - 64 is taken then, and the error flagged)
             const unsigned long long N = ((c.max_attempts + 63ull) / 64ull) * 64ull;
@@ -231,7 +223,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
                     rng.ensure(6 * 64, lane);
                     const uint32_t at = rng.cursor + 6u * lane;
                     bool inside = false;
-                    if (CN_GEN_PREFILTER) {
+                    {
                         const float frac = (float)(rng.word(at) >> 5) * 0x1p-27f;
                         float sn, cs;
                         sincosf(frac * 6.2831855f, &sn, &cs);
@@ -325,7 +317,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
             for (;;) {
                 rng.ensure(6 * 64, lane);
                 const uint32_t at = rng.cursor + 6u * lane;
-                if (CN_GEN_PREFILTER) {
+                {
                     const float frac = (float)(rng.word(at) >> 5) * 0x1p-27f;
                     float sn, cs;
                     sincosf(frac * 6.2831855f, &sn, &cs);

@@ -26,23 +26,11 @@
 
 namespace cn {
 
-// CN_CAND_LP10 (compile time, default on): MAXL = 10 solves in candidate form too — the planar program's 1-D solutions on
-// (agent, half-plane) lanes + a streaming scan per agent (instead of lp_planar_reg<10>: 10 half-planes in 40 VGPRs, ~1 500
-// fully unrolled instructions), and the 3-D fallback as lp_relaxed_lazy (orca_device.h) instead of lp_relaxed_coop's shuffle
-// rounds.  Less code (the step loop of the 20-human kernel was ~45 KB: instruction-cache bound) and far fewer live registers.
-// Measured at 20 humans (4096 envs, radius 12): planar program 7.8 k -> 15.1 k clock ticks per wave-step in candidate form (210
-// candidate lanes x 9 divisions: twice the work of the register program, which skips what it does not need), fallback
-// 25.7 k -> 18.5 k.  So the default, CN_CAND_LP10 = 2, keeps lp_planar_reg for the planar program and takes only the fallback
-// (lp_relaxed_lazy); 1 = both in candidate form; 0 = the round-2 kernels (lp_relaxed_coop).
-#ifndef CN_CAND_LP10
-#define CN_CAND_LP10 2
-#endif
-// CN_TRI_LP10 (compile time, default on): the 10-half-plane kernels solve the planar program on three lanes per agent
-// (lp_planar_tri: 63 of 64 lanes, rounds over the violated half-planes) instead of one unrolled, predicated program per agent
-// lane (lp_planar_reg<10>: 21 of 64 lanes, ~1 500 instructions, 40 registers of half-planes).
-#ifndef CN_TRI_LP10
-#define CN_TRI_LP10 1
-#endif
+// How the 10-half-plane kernels (crowds of 6+ humans) solve an agent's ORCA program — what was measured on the way is
+// profiles/HISTORY.md: the planar program runs on three lanes per agent (orca_device.h: lp_planar_tri), RVO2's 3-D fallback for
+// the infeasible agents as lp_relaxed_lazy (one-wave workgroups with room for its candidate rows in d2) or lp_relaxed_coop
+// (several waves per workgroup, tiny crowds).  The 5-half-plane kernels solve in candidate form (lp_line_candidate /
+// lp_planar_scan, lp3_project / lp3_scan).
 
 constexpr int kMaxBlock = 512;  // threads per workgroup of the transition kernels (1..8 waves)
 
@@ -144,27 +132,12 @@ struct Smem {
 
 constexpr int kCompactScratchDoubles = 16;  // COMPACT: Smem::disc holds the step parameters and the robot lane's bookkeeping instead
 constexpr int kMaxDiscount = 256;  // steps per episode the LDS copy of the discount table covers
-// CN_CAND_LP3_10 (compile time, default off): the 10-half-plane kernels run the 3-D fallback in candidate form like the
-// 5-half-plane ones (lp3_project / lp_line_candidate on (agent, i, j) lanes, then lp3_scan_n per agent) instead of
-// lp_relaxed_coop's rounds.  Built, bit-identical on the whole GPU suite, and REJECTED on speed at 20 humans: 45 projections
-// + 45 candidates per infeasible agent (each candidate a loop over up to 8 earlier lines) cost as much as the cooperative
-// rounds (27.1 k vs 25.8 k ticks per wave-step) and the 8.6 KB of chunk buffers take a resident workgroup per CU
-// (67.7 -> 51.6 M env-steps/s).
-#ifndef CN_CAND_LP3_10
-#define CN_CAND_LP3_10 0
-#endif
-// its chunk: agents per pass (45 projections + 45 candidates each, in `proj`)
-constexpr int kLp3Agents = 6;
-constexpr int kLp3Pairs10 = 45;
-__host__ __device__ inline size_t proj_bytes(int nA, int maxl) {
-    const size_t rows = (size_t)16 * kLineStride * nA, lp3 = (size_t)16 * 2 * kLp3Pairs10 * kLp3Agents;
-    return (CN_CAND_LP3_10 != 0 && maxl == 10 && lp3 > rows) ? lp3 : rows;
-}
+__host__ __device__ inline size_t proj_bytes(int nA, int /*maxl*/) { return (size_t)16 * kLineStride * nA; }
 
 // maxl: the 5-half-plane kernels have two candidate-form buffers (cand2, cand3); the 10-half-plane kernels none (their lazy
-// fallback's candidate rows live in d2) unless built all-candidate-form (CN_CAND_LP10 == 1)
+// fallback's candidate rows live in d2)
 __host__ __device__ inline size_t smem_bytes(int nA, int pairs, int maxl, int A = 0, int E = 1) {
-    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 || CN_CAND_LP10 == 1 ? 3 : 1) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + proj_bytes(nA, maxl) +
+    return (size_t)nA * (16 + 16 + 16 + (maxl == 5 ? 3 : 1) * 16 * kLineStride + 16 + 16 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + proj_bytes(nA, maxl) +
            (size_t)pairs * 8 + 64 + 8 + 16 + 16 + sizeof(double) * kMaxDiscount + (A > kKdLeaf ? 16 + kd_lds_bytes(nA, A, E) : 0);
 }
 
@@ -203,9 +176,6 @@ __device__ __forceinline__ Smem carve(const Params& P) {
     s.proj = reinterpret_cast<float4*>(p), p += COMPACT ? (size_t)16 * kLazyRows : proj_bytes(nA, MAXL);
     s.cand2 = s.cand3 = nullptr;
     if (MAXL == 5) {
-        s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
-        s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
-    } else if (CN_CAND_LP10 == 1) {  // the all-candidate-form build of the 10-half-plane kernels
         s.cand2 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
         s.cand3 = reinterpret_cast<float4*>(p), p += 16 * kLineStride * nA;
     }
@@ -734,32 +704,6 @@ struct PhaseClock {};
     } while (0)
 #endif
 
-// CN_COOP_LP5 / CN_COOP_LP10 (compile time): solve the 2-D program with one lane per (agent, half-plane)
-// (lp_planar_coop) instead of one unrolled program per agent lane (lp_planar_reg), for MAXL = 5 / 10.
-#ifndef CN_COOP_LP5
-#define CN_COOP_LP5 0
-#endif
-#ifndef CN_COOP_LP10
-#define CN_COOP_LP10 0
-#endif
-// CN_COOP_LP3_5 / CN_COOP_LP3_10 (compile time): the infeasible-program fallback with one lane per (agent, half-plane)
-// (lp_relaxed_coop) instead of a serial LDS walk on the agent's own lane (lp_relaxed_lds).  Measured
-// (profiles/r01_coop_lp_ab.txt): H = 20 +12 % (48.3 -> 54.1 -> 61.2 M env-steps/s with the infeasible agents compacted); H = 5 neutral at 4096 envs and -8 % at
-// 32 768 envs (127 -> 153 VGPRs costs a resident wave per SIMD), hence on for MAXL = 10 only.
-#ifndef CN_COOP_LP3_5
-#define CN_COOP_LP3_5 0
-#endif
-#ifndef CN_COOP_LP3_10
-#define CN_COOP_LP3_10 1
-#endif
-
-// CN_PAR_LP5 (compile time): MAXL = 5 solves in candidate form (orca_device.h: lp_line_candidate / lp_planar_scan, and
-// lp3_project / lp3_scan for the infeasible agents): the 1-D solutions of every (agent, half-plane) on their own lanes, then
-// a short scan per agent, instead of one unrolled, predicated program per agent lane with its serial LDS-walking fallback.
-#ifndef CN_PAR_LP5
-#define CN_PAR_LP5 1
-#endif
-
 // KD (compile time): the instantiation carries the kd-tree bookkeeping of simulators with more than 10 agents (kd_order.h);
 // crowds of at most 9 humans run the one without it.
 template <int MAXL, bool KD, bool COMPACT = false>
@@ -767,14 +711,6 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                                             float robot_max_speed, bool solve, float& out_vx, float& out_vy,
                                             PhaseClock* clk = nullptr) {
     (void)clk;
-    constexpr bool kCoop = (MAXL == 5) ? (CN_COOP_LP5 != 0) : (CN_COOP_LP10 != 0);
-    constexpr bool kCand3 = (MAXL == 10) && (CN_CAND_LP3_10 != 0);  // candidate-form fallback, chunks of kLp3Agents agents
-    constexpr bool kCoop3 = !kCand3 && ((MAXL == 5) ? (CN_COOP_LP3_5 != 0) : (CN_COOP_LP3_10 != 0));
-    constexpr bool kPar = (MAXL == 5) && (CN_PAR_LP5 != 0) && !kCoop;
-    constexpr bool kCand10 = (MAXL == 10) && (CN_CAND_LP10 == 1) && !kCoop && !kCand3;
-    constexpr bool kLazy3 = (MAXL == 10) && (CN_CAND_LP10 == 2) && !kCoop && !kCand3;  // register planar program, lazy fallback
-    // the 10-half-plane planar program on three lanes per agent (orca_device.h: lp_planar_tri) instead of lp_planar_reg<10>
-    constexpr bool kTri = (MAXL == 10) && (CN_TRI_LP10 != 0) && !kCoop && !kCand10;
     // preferred velocity: towards the goal, unit length once farther than 1 m (orca.py:113-115)
     // (COMPACT: the per-episode constants of the agent — goal, preferred speed, radius — are read from LDS where needed)
     const float max_speed = (L.a == 0) ? robot_max_speed : (float)(COMPACT ? (L.lane < P.nA ? s.vpref[L.lane] : 0.0) : r.vpref);
@@ -796,13 +732,9 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             s.rad[L.lane] = r.rad;
             s.hview[L.lane] = (float)(r.rad + 0.01 + step_param<COMPACT>(P, s, kParHSafety));
         }
-        if (kCoop || kPar || kCand10 || kTri) {
-            float pref_x, pref_y;
-            preferred(pref_x, pref_y);
-            s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
-        } else if (kCoop3 || kCand3 || kLazy3) {
-            s.sol[L.lane] = make_float4(0.0f, 0.0f, max_speed, solve ? 1.0f : 0.0f);
-        }
+        float pref_x, pref_y;
+        preferred(pref_x, pref_y);
+        s.sol[L.lane] = make_float4(pref_x, pref_y, max_speed, solve ? 1.0f : 0.0f);
         if (KD) {
             const KdSmem k = kd_view(P, s);
             k.tie[L.lane] = 0;
@@ -924,7 +856,9 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
     CN_TICK(clk, 2);
 
     out_vx = 0.0f, out_vy = 0.0f;
-    if (kPar) {
+    float rx = 0.0f, ry = 0.0f;
+    int n = 0, fail = 0;
+    if (MAXL == 5) {
         // candidates: lane = (agent, half-plane)
         for (int p = L.lane; p < P.nA * MAXL; p += P.threads) {
             const int q = p / MAXL, k = p - q * MAXL;
@@ -938,27 +872,39 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             }
         }
         block_sync(P);
-        float rx = 0.0f, ry = 0.0f;
-        int n = 0, fail = 0;
         if (solve) {
             n = s.count[L.lane];
             const float4 start = s.res[L.lane];
             rx = start.x, ry = start.y;
             fail = lp_planar_scan<MAXL>(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, rx, ry);
         }
-        CN_TICK(clk, 3);
-        const bool need = solve && fail < n;
+    } else {
+        lp_planar_tri(s.lines, s.count, s.sol, s.res, P.nA, P.threads);  // every thread: lane = (agent, third of its half-planes)
+        block_sync(P);
+        if (solve) {
+            n = s.count[L.lane];
+            const float4 got = s.res[L.lane];
+            rx = got.x, ry = got.y;
+            fail = __float_as_int(got.z);
+        }
+    }
+    CN_TICK(clk, 3);
+    const bool need = solve && fail < n;
 #ifdef CN_PHASE_TIMING
-        if (clk) clk->acc[9] += __popcll(__ballot(need));
+    if (clk) clk->acc[9] += __popcll(__ballot(need));  // agents in the fallback
 #endif
-        if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
-            if (L.lane < kWave) {
-                const unsigned long long nm = __ballot(need);
-                if (need) s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
-                if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
+    if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
+        if (L.lane < kWave) {  // (agent lanes live in wave 0)
+            const unsigned long long nm = __ballot(need);
+            if (need) {
+                if (MAXL == 10) s.res[L.lane] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
+                s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
             }
-            block_sync(P);
-            constexpr int kPairs = MAXL * (MAXL - 1) / 2;
+            if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
+        }
+        block_sync(P);
+        if (MAXL == 5) {
+            constexpr int kPairs = 10;  // MAXL (MAXL - 1) / 2 projections and as many candidates per infeasible agent
             const int items = s.todo[P.nA] * kPairs;
             for (int p = L.lane; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
                 const int t = p / kPairs, m = p - t * kPairs;
@@ -974,166 +920,28 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
                 const int i = lp3_program_of(m), base = i * (i - 1) / 2;
                 const float4 li = s.lines[a * kLineStride + i];
                 const float4* pa = s.proj + a * kLineStride + base;
-                s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
+                s.cand3[a * kLineStride + m] = lp_line_candidate<3>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
             }
             block_sync(P);
             if (need)
-                lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n,
-                         fail, max_speed, rx, ry);
-        }
-        out_vx = rx, out_vy = ry;
-    } else if (kCand10) {
-        // candidates of the planar program: lane = (agent, half-plane), four passes of a wave at 21 agents
-        for (int p = L.lane; p < P.nA * MAXL; p += P.threads) {
-            const int q = p / MAXL, k = p - q * MAXL;
-            const float4 so = s.sol[q];
-            const float4* lq = s.lines + q * kLineStride;
-            s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
-            if (k == 0) {
-                float sx, sy;
-                lp_start_point(so.z, so.x, so.y, sx, sy);
-                s.res[q] = make_float4(sx, sy, 0.0f, 0.0f);
-            }
-        }
-        block_sync(P);
-        float rx = 0.0f, ry = 0.0f;
-        int n = 0, fail = 0;
-        if (solve) {
-            n = s.count[L.lane];
-            const float4 start = s.res[L.lane];
-            rx = start.x, ry = start.y;
-            fail = lp_planar_scan_stream<MAXL>(s.lines + L.lane * kLineStride, s.cand2 + L.lane * kLineStride, n, rx, ry);
-        }
-        CN_TICK(clk, 3);
-        const bool need = solve && fail < n;
-#ifdef CN_PHASE_TIMING
-        if (clk) clk->acc[9] += __popcll(__ballot(need));
-#endif
-        if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
-            if (L.lane < kWave) {
-                const unsigned long long nm = __ballot(need);
-                if (need) {
-                    s.res[L.lane] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
-                    s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
-                }
-                if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
-            }
-            block_sync(P);
-            lp_relaxed_lazy<MAXL>(s.lines, s.proj, s.cand3, s.count, s.sol, s.res, s.todo, s.todo[P.nA], P.threads);
+                lp3_scan(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, s.cand3 + L.lane * kLineStride, n, fail,
+                         max_speed, rx, ry);
+        } else {
+            // (the lazy fallback's candidate rows — 7 agents x 9 float4 per wave — live in d2, free after the pair phases: enough
+            // for one wave of a crowd of 12+ agents; otherwise the shuffle-round form)
+            if (P.threads == kWave && P.pairs * 4 >= (kWave / (MAXL - 1)) * (MAXL - 1) * 16)
+                lp_relaxed_lazy<10, COMPACT>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
+                                             s.todo[P.nA], P.threads);
+            else
+                lp_relaxed_coop<10>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
             block_sync(P);
             if (need) {
                 const float4 got = s.res[L.lane];
                 rx = got.x, ry = got.y;
             }
         }
-        out_vx = rx, out_vy = ry;
-    } else if (kCoop) {
-        lp_planar_coop<MAXL>(s.lines, s.count, s.sol, s.res, P.nA);
-        block_sync(P);
-        if (solve) {
-            const int n = s.count[L.lane];
-            const float4 got = s.res[L.lane];
-            float rx = got.x, ry = got.y;
-            const int fail = __float_as_int(got.z);
-            if (fail < n)
-                lp_relaxed_lds(s.lines + L.lane * kLineStride, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
-            out_vx = rx, out_vy = ry;
-        }
-    } else {
-        float rx = 0.0f, ry = 0.0f;
-        int n = 0, fail = 0;
-        const float4* mine = s.lines + L.lane * kLineStride;
-        if (kTri) {
-            lp_planar_tri(s.lines, s.count, s.sol, s.res, P.nA, P.threads);  // every thread: lane = (agent, third of its half-planes)
-            block_sync(P);
-            if (solve) {
-                n = s.count[L.lane];
-                const float4 got = s.res[L.lane];
-                rx = got.x, ry = got.y;
-                fail = __float_as_int(got.z);
-            }
-        } else if (solve) {
-            n = s.count[L.lane];
-            float4 Lr[MAXL];
-#pragma unroll
-            for (int k = 0; k < MAXL; ++k) Lr[k] = (k < n) ? mine[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float pref_x, pref_y;
-            preferred(pref_x, pref_y);
-            fail = lp_planar_reg<MAXL>(Lr, n, max_speed, pref_x, pref_y, rx, ry);
-        }
-        CN_TICK(clk, 3);
-        const bool need = solve && fail < n;
-#ifdef CN_PHASE_TIMING
-        if (clk) clk->acc[9] += __popcll(__ballot(need));  // agents in the fallback
-#endif
-        if (kCand3) {
-            if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible: compact them
-                int my_t = 0;
-                if (L.lane < kWave) {
-                    const unsigned long long nm = __ballot(need);
-                    my_t = __popcll(nm & ((1ull << L.lane) - 1ull));
-                    if (need) s.todo[my_t] = L.lane;
-                    if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
-                }
-                block_sync(P);
-                constexpr int kPairs = MAXL * (MAXL - 1) / 2;
-                static_assert(MAXL != 10 || kPairs == kLp3Pairs10, "proj_bytes() sizes the chunk buffers");
-                float4* const projc = s.proj;                          // [kLp3Agents][kPairs] projected half-planes
-                float4* const candc = s.proj + kLp3Agents * kPairs;    // ... and their candidates
-                const int n_todo = s.todo[P.nA];
-                for (int t0 = 0; t0 < n_todo; t0 += kLp3Agents) {
-                    const int nt = n_todo - t0 < kLp3Agents ? n_todo - t0 : kLp3Agents;
-                    const int items = nt * kPairs;
-                    for (int p = L.lane; p < items; p += P.threads) {  // projections: lane = (agent, i, j)
-                        const int t = p / kPairs, m = p - t * kPairs;
-                        const int a = s.todo[t0 + t];
-                        const int i = lp3_program_of_n<MAXL>(m), j = m - i * (i - 1) / 2;
-                        const float4* la = s.lines + a * kLineStride;
-                        projc[p] = lp3_project(la[i], la[j]);
-                    }
-                    block_sync(P);
-                    for (int p = L.lane; p < items; p += P.threads) {  // their candidates: lane = (agent, i, k)
-                        const int t = p / kPairs, m = p - t * kPairs;
-                        const int a = s.todo[t0 + t];
-                        const int i = lp3_program_of_n<MAXL>(m), base = i * (i - 1) / 2;
-                        const float4 li = s.lines[a * kLineStride + i];
-                        const float4* pa = projc + t * kPairs + base;
-                        candc[p] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, s.sol[a].z, -li.w, li.z, true);
-                    }
-                    block_sync(P);
-                    if (need && my_t >= t0 && my_t < t0 + nt)
-                        lp3_scan_n<MAXL>(mine, projc + (my_t - t0) * kPairs, candc + (my_t - t0) * kPairs, n, fail, max_speed, rx, ry);
-                    block_sync(P);  // the next chunk overwrites the buffers
-                }
-            }
-        } else if (kCoop3 || kLazy3) {
-            if (block_sync_or(P, need ? 1 : 0)) {  // some agent of this workgroup was infeasible
-                if (L.lane < kWave) {  // agent lanes live in wave 0: compact the infeasible ones
-                    const unsigned long long nm = __ballot(need);
-                    if (need) {
-                        s.res[L.lane] = make_float4(rx, ry, __int_as_float(fail), 0.0f);
-                        s.todo[__popcll(nm & ((1ull << L.lane) - 1ull))] = L.lane;
-                    }
-                    if (L.lane == 0) s.todo[P.nA] = __popcll(nm);
-                }
-                block_sync(P);
-                // (its candidate rows — 7 agents x 9 float4 per wave — live in d2, free after the pair phases: enough for one wave)
-                if (kLazy3 && P.threads == kWave && P.pairs * 4 >= (kWave / (MAXL - 1)) * (MAXL - 1) * 16)
-                    lp_relaxed_lazy<MAXL, COMPACT>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
-                                                   s.todo[P.nA], P.threads);
-                else
-                    lp_relaxed_coop<MAXL>(s.lines, s.count, s.sol, s.res, s.todo, s.todo[P.nA]);
-                block_sync(P);
-                if (need) {
-                    const float4 got = s.res[L.lane];
-                    rx = got.x, ry = got.y;
-                }
-            }
-        } else if (need) {
-            lp_relaxed_lds(mine, s.proj + L.lane * kLineStride, n, fail, max_speed, rx, ry);
-        }
-        out_vx = rx, out_vy = ry;
     }
+    out_vx = rx, out_vy = ry;
     CN_TICK(clk, 8);
 }
 
@@ -1348,32 +1156,9 @@ __global__ __launch_bounds__(kMaxBlock) void step_kernel(Params P, StateView S, 
 // Everything below — scenario generation, rollout bookkeeping, the rollout kernels — belongs to the env translation unit
 // (crowdnav_amd.hip).  sarl_abi.hip includes this header for orca_kernel / step_kernel's types only and defines CN_SARL_TU.
 #ifndef CN_SARL_TU
-// The 624-word MT19937 state of the scenario a lane is generating lives in LDS, word-major ([624][64 lanes]:
-// conflict-free, ~30 cycles per draw instead of a dependent L2 round trip).  One 64-lane workgroup takes
-// 624 * 64 * 4 = 159 744 B, i.e. one generator wave per CU — what makes the reference's heavy-tailed rejection
-// sampling (H = 20, R = 4: 28 k draws per scenario on average) affordable.
-constexpr size_t kMtLdsBytes = 624 * kWave * sizeof(uint32_t);
-
-// Generator state placement: LDS (one generator wave per CU, fast draws: long rejection chains, H > 8) or HBM
-// word-major scratch (any number of waves per CU: short chains, where the 624-step seeding of many scenarios in
-// parallel is what matters).
-template <bool IN_LDS>
-__device__ __forceinline__ Mt19937 make_rng(uint32_t* hbm_column, int hbm_stride) {
-    if (IN_LDS) {
-        extern __shared__ uint32_t mt_lds[];
-        return Mt19937{mt_lds + threadIdx.x, kWave, 0};
-    }
-    return Mt19937{hbm_column, hbm_stride, 0};
-}
-
-// keep the env's generator state in HBM (the stream np.random continues with after reset)
-__device__ __forceinline__ void persist_mt(const Mt19937& rng, uint32_t* dst, int stride) {
-    for (int i = 0; i < 624; ++i) dst[(size_t)i * stride] = rng.key[(size_t)i * rng.stride];
-}
-
 // Lane-per-scenario generation: try the register-only head generator first (no memory traffic), redo the scenario
-// with the memory-backed one in the rare case its 227 words do not suffice.  Returns random() calls consumed.
-template <bool IN_LDS>
+// with the memory-backed one (word-major HBM scratch: any number of waves per CU) in the rare case its 227 words do not
+// suffice.  Returns random() calls consumed.
 __device__ __forceinline__ uint64_t generate_scenario_lane(const ScenarioCfg& C, uint32_t seed, size_t base,
                                                            double2* pos, double2* vel, double2* goal, double2* rv,
                                                            uint32_t* hbm_column, int hbm_stride, bool keep_state,
@@ -1383,23 +1168,19 @@ __device__ __forceinline__ uint64_t generate_scenario_lane(const ScenarioCfg& C,
         const uint64_t n = generate_scenario(C, head, seed, base, pos, vel, goal, rv);
         if (!head.dead()) return n;
     }
-    Mt19937 rng = make_rng<IN_LDS>(hbm_column, hbm_stride);
+    Mt19937 rng{hbm_column, hbm_stride, 0};
     const uint64_t n = generate_scenario(C, rng, seed, base, pos, vel, goal, rv);
-    if (keep_state) {
-        if (IN_LDS) persist_mt(rng, hbm_column, hbm_stride);
-        if (pos_out) *pos_out = rng.pos;
-    }
+    if (keep_state && pos_out) *pos_out = rng.pos;
     return n;
 }
 
 // np.random.seed(seed) + scenario of one env per lane (lane = env)
-template <bool IN_LDS>
 __global__ __launch_bounds__(kWave) void reset_kernel(Params P, ScenarioCfg C, StateView S, const uint32_t* seeds,
                                                      const uint8_t* mask, uint64_t* draws) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
     if (mask && !mask[b]) return;
-    const uint64_t n = generate_scenario_lane<IN_LDS>(C, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv,
+    const uint64_t n = generate_scenario_lane(C, seeds[b], (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv,
                                                       S.mt_key + b, P.B, true, &S.mt_pos[b]);
     S.gtime[b] = 0.0;
     S.theta[b] = 1.5707963267948966;  // robot.set(..., np.pi / 2)
@@ -1435,7 +1216,6 @@ __device__ __forceinline__ uint32_t episode_seed(const cn_rollout_io& io, int64_
 }
 
 // (re)start bookkeeping: env b begins its episode ordinal 0
-template <bool IN_LDS>
 __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
@@ -1454,7 +1234,7 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, Scenario
     if (P.kd)
         for (int a = 1; a < P.A; ++a) S.kd_valid[(size_t)b * P.A + a] = 0;
     if (!on) return;
-    generate_scenario_lane<IN_LDS>(C, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv, S.mt_key + b,
+    generate_scenario_lane(C, episode_seed(io, c0), (size_t)b * P.A, S.pos, S.vel, S.goal, S.rv, S.mt_key + b,
                                    P.B, false, nullptr);
     S.mt_pos[b] = -1;
     S.gtime[b] = 0.0;
@@ -1462,11 +1242,10 @@ __global__ __launch_bounds__(kWave) void rollout_begin_kernel(Params P, Scenario
 
 // Scenario ring fill: one lane per (env, ring slot) generates the episode whose ordinal maps to that slot
 // if it has not been generated yet, so that ordinals [next, next + D) are resident when the rollout
-// launch that follows needs them.  HBM flavour (IN_LDS = false): the lane runs the register-only head generator; the
+// launch that follows needs them.  The lane runs the register-only head generator; the
 // rare scenario whose rejection chain outruns its 227 words is queued in redo_list and regenerated by ring_redo_kernel
 // with a memory-backed generator from a small fixed pool (624 x kRedoLanes words, not 624 x B x D).
 constexpr int kRedoLanes = 4096;
-template <bool IN_LDS>
 __global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int D = P.ring_depth;
@@ -1484,13 +1263,9 @@ __global__ __launch_bounds__(kWave) void ring_fill_kernel(Params P, ScenarioCfg 
     if (io->episode_limit >= 0 && c >= io->episode_limit) return;
     const uint32_t seed = episode_seed(*io, c);
     const size_t base = ((size_t)b * D + slot) * P.A;
-    if (IN_LDS) {
-        generate_scenario_lane<true>(C, seed, base, S.ring_pos, nullptr, S.ring_goal, S.ring_rv, nullptr, 0, false, nullptr);
-    } else {
-        Mt19937Head head;
-        generate_scenario(C, head, seed, base, S.ring_pos, nullptr, S.ring_goal, S.ring_rv);
-        if (head.dead()) S.redo_list[atomicAdd(S.redo_count, 1)] = make_int2(idx, (int)seed);
-    }
+    Mt19937Head head;
+    generate_scenario(C, head, seed, base, S.ring_pos, nullptr, S.ring_goal, S.ring_rv);
+    if (head.dead()) S.redo_list[atomicAdd(S.redo_count, 1)] = make_int2(idx, (int)seed);
 }
 
 // The scenarios ring_fill_kernel<false> queued: a fixed grid of kRedoLanes lanes strides over the list, each lane with
@@ -1800,22 +1575,12 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
 
 // Up to n_steps transitions per running env in one launch; state lives in VGPRs between steps, finished envs
 // take their next scenario from the ring.
-// CN_MAXL10_WAVES (compile time, experiments): resident waves per SIMD the 10-half-plane rollout kernel is compiled
-// for (its register-resident program wants ~190 VGPRs = 2 waves; 3 caps it at 168, 4 at 128 with spills).  Measured
-// at H = 20: 54.1 (unconstrained) / 51.7 / 47.2 M env-steps/s — occupancy is not the limiter.
-#ifndef CN_MAXL10_WAVES
-#define CN_MAXL10_WAVES 1
-#endif
-// CN_COMPACT20 (compile time, default on): the 20-human shard's kernel uses the compact LDS layout (carve<.., COMPACT>)
-#ifndef CN_COMPACT20
-#define CN_COMPACT20 1
-#endif
-// CN_GEOM20_WAVES: resident waves per SIMD the shard's kernel (HEADLINE instantiation of rollout_kernel<10>) is compiled for
-#ifndef CN_GEOM20_WAVES
-#define CN_GEOM20_WAVES 3
-#endif
+// The shard's kernel (HEADLINE instantiation of rollout_kernel<10>) is compiled for THREE resident waves per SIMD (<= 168
+// VGPRs) and uses the compact LDS layout (carve<.., COMPACT>: 12 workgroups per CU); the generic 10-half-plane instantiations are
+// left to the register allocator (two waves).
+constexpr int kGeom20Waves = 3;
 template <int MAXL, bool UNI, bool HEADLINE = false, bool KD = false>
-__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVES : CN_MAXL10_WAVES) : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
+__global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                             RolloutView R, int n_steps, const double* ext_action) {
     // The ~20 state pointers are needed before and after the step loop and when an episode ends, never inside a step: they
     // are re-read from the engine's device copy of the StateView there (scalar loads) instead of holding 40 SGPRs — spilled
@@ -1835,7 +1600,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 ? (HEADLINE ? CN_GEOM20_WAVE
         P.orca.max_neighbors = 10;
         P.kdl = kd_layout(21, 21, 1);
     }
-    constexpr bool COMPACT = HEADLINE && MAXL == 10 && CN_COMPACT20 != 0;  // the shard kernel's LDS layout (carve)
+    constexpr bool COMPACT = HEADLINE && MAXL == 10;  // the shard kernel's LDS layout (carve)
     // the float64 parameters of a step as VALU operands live in VGPRs (rollout_fused.h: in_vgpr): as SGPR kernel arguments the
     // 16-dword block was spilled into VGPR lanes and re-read with v_readlane several times per step (COMPACT: in LDS instead)
     if (!COMPACT) {

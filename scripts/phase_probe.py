@@ -37,6 +37,10 @@ def main():
     eng.rollout(500)
     eng.sync()
     assert probe(None, 1) == 0
+    lazy = getattr(lib, 'cn_debug_lazy_counts', None)
+    if lazy is not None:
+        lazy.restype, lazy.argtypes = C.c_int, [C.c_void_p, C.c_int]
+        lazy(None, 1)
     t0 = time.perf_counter()
     done = 0
     while done < a.steps:
@@ -56,6 +60,13 @@ def main():
         print('  %-34s %8.0f  %5.1f %%' % (n, c, 100 * c / per.sum()))
     print('  agents in the 3-D fallback per wave-step: %.3f (of %d agent lanes)' % (out[9] / out[15] / 500, eng.A * max(1, a.envs // int(waves))))
     print('  transitions', int(bufs['transitions'].cpu()[0]))
+    if lazy is not None:
+        lz = (C.c_ulonglong * 8)()
+        lazy(lz, 0)
+        if lz[0]:
+            print('  lazy fallback (10 half-planes): %d calls, %.2f agents, %.2f solve rounds + %.2f hand-out iterations per call, '
+                  '%.0f ticks per call, %.0f per round' % (lz[0], lz[3] / lz[0], lz[1] / lz[0], lz[2] / lz[0], lz[4] / lz[0],
+                                                           lz[4] / max(1, lz[1] + lz[2])))
 
 
 if __name__ == '__main__':
