@@ -98,8 +98,12 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->maxl = ((P.NC < c->max_neighbors ? P.NC : c->max_neighbors) <= 5) ? 5 : 10;
     P.kd = P.A > cn::kKdLeaf ? 1 : 0;  // a simulator of more than 10 agents splits its kd-tree: visiting order matters at ties
     P.sched = -1;
-    e->sched_min = env_int("CROWDNAV_AMD_SCHED_MIN_STEPS", 48);
+    e->sched_min = env_int("CROWDNAV_AMD_SCHED_MIN_STEPS", 24);  // shortest call that runs under a schedule (static: at least 48)
     e->sched_force = env_int("CROWDNAV_AMD_SCHED_FORCE", 0) != 0;
+    e->sched_reserve = env_int("CROWDNAV_AMD_DYN_RESERVE", 0);  // slots left free beside a dynamic launch under the asynchronous fill
+    e->sched_dynamic = env_int("CROWDNAV_AMD_SCHED_DYNAMIC", 1) != 0;
+    e->dyn_visits = env_int("CROWDNAV_AMD_DYN_VISITS", 0);  // 0: by call length (launch_rollout)
+    P.dyn_visits = 3;
     {
         hipDeviceProp_t prop;
         const bool ok = hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0;
@@ -160,7 +164,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_filled_in, (size_t)P.B)) || (rc = dev_alloc(e, &S.ring_filled_out, (size_t)P.B)) ||
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
-        (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) ||
+        (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) || (rc = dev_alloc(e, &S.dyn_queue, (size_t)P.B + 1)) ||
         (rc = dev_alloc(e, &S.kd_order, P.kd ? n * cn::kd_row_bytes(P.A) : (size_t)4)) ||
         (rc = dev_alloc(e, &S.kd_valid, P.kd ? n : (size_t)4)) ||
         (rc = dev_alloc(e, &S.wg_partial, (size_t)P.B * (CN_SUMMARY_FIELDS + 1))) ||
@@ -541,8 +545,38 @@ static void launch_rollout(cn_engine* e, const cn::RolloutView& R, int n_steps, 
         cn::Params Pk = e->P;
         Pk.sched = -1;
         const int slots = e->sched_slots;
+        // Dynamic schedule (step_kernels.h: kSchedDynamic): ONE launch of persistent workgroups taking (env, visit) items from a
+        // device queue — wherever thirds of a call balance the chip better than whole calls (ceil(3 B / G) < 3 ceil(B / G)), and
+        // always beside the asynchronous scenario fill, whose generator workgroups must find room WITHOUT sending a step workgroup
+        // to a second round: the grid then leaves `sched_reserve` of the resident slots free (CROWDNAV_AMD_DYN_RESERVE).  Callers that
+        // want the in-kernel summary / record blocks get the static 3-of-4 schedule below.
+        {
+            const bool use_dynamic = e->sched_dynamic;
+            const int reserve = e->async_fill ? e->sched_reserve : 0;
+            const int G = P.B < slots - reserve ? P.B : slots - reserve;
+            // visits per env and call: ~56 steps each (measured at 4096 envs on the 12 m circle: 999-step calls 129 / 137 / 141 /
+            // 143 / 143 / 136 / 110 M env-steps/s at 3 / 6 / 9 / 18 / 27 / 54 / 108 visits, 500-step calls 125 / 137 / 136 / 126 M
+            // at 3 / 9 / 18 / 36 — shorter visits balance better until the per-visit prologue and the release / acquire of the
+            // env's state show), at least three
+            int visits = e->dyn_visits > 0 ? e->dyn_visits : (n_steps + 28) / 56;
+            if (visits < 3) visits = 3;
+            if (visits > n_steps) visits = n_steps;
+            Pk.dyn_visits = visits;
+            // work-conserving: worth it whenever the envs do not all fit at once (a plain launch then runs ceil(B / G) rounds)
+            const bool helps = e->sched_force || e->async_fill || P.B > G;
+            if (use_dynamic && G > 0 && n_steps >= e->sched_min && action == nullptr && helps && !e->io_host.summary &&
+                !e->io_host.blocks) {
+                (void)hipMemsetAsync(e->S.dyn_queue, 0, sizeof(int) * ((size_t)P.B + 1), e->stream);
+                Pk.sched = cn::kSchedDynamic;
+                e->launch_counts[CN_COUNT_ROLLOUT_KERNELS] += 1;
+                e->launch_counts[CN_COUNT_SCHEDULED_KERNELS] += 1;
+                hipLaunchKernelGGL((cn::rollout_kernel<10, false, true, true>), dim3(G), dim3(64), smem20, e->stream, Pk,
+                                   (const cn::StateView*)e->S_dev, (const int*)e->S.ring_filled_in, R, n_steps, action);
+                return;
+            }
+        }
         const int rounds_plain = (P.B + slots - 1) / slots, rounds_sched = (P.B / 4 * 3 + slots - 1) / slots;
-        const bool sched = P.B % 4 == 0 && n_steps >= e->sched_min && action == nullptr &&
+        const bool sched = P.B % 4 == 0 && n_steps >= (e->sched_min > 48 ? e->sched_min : 48) && action == nullptr &&
                            (e->sched_force || 4 * rounds_sched < 3 * rounds_plain);
         const int q = sched ? n_steps / 3 : 0, rest = n_steps - 3 * q;
         e->launch_counts[CN_COUNT_ROLLOUT_KERNELS] += (rest > 0 ? 1 : 0) + (q > 0 ? 4 : 0);

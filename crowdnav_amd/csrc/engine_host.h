@@ -71,8 +71,8 @@ struct cn_engine {
     int maxl;          // half-planes held in VGPRs by the solve phase: 5 or 10
     bool gen_wave;     // wave-per-scenario generators (64 rejection attempts at a time): long chains, H > 8
     size_t smem;       // dynamic LDS bytes per workgroup
-    int sched_min, sched_slots;  // the 20-human shard kernel's 3-of-4 env schedule (launch_rollout): shortest call split, resident workgroups
-    bool sched_force;
+    int sched_min, sched_slots, sched_reserve, dyn_visits;  // the 20-human shard kernel's schedules (launch_rollout): shortest call split, resident workgroups, slots left free beside the asynchronous fill
+    bool sched_force, sched_dynamic;
     uint64_t launch_counts[CN_LAUNCH_COUNTERS];  // cn_launch_counts: what the host enqueued since cn_create
     // Device memory comes from a few large slabs, not one hipMalloc per buffer: an engine has ~60 device buffers, most of them a
     // few KiB; one 32 MiB slab (plus one per buffer larger than that) is 2-4 mappings to create and - each hipFree being a device

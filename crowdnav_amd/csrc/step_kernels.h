@@ -47,7 +47,9 @@ struct Params {
     int robot_visible, robot_orca;
     int robot_unicycle;  // external robot actions are ActionRot(v, r) (agent.py:115-135)
     int async_fill;      // CN_FLAG_ASYNC_SCENARIO_FILL: ring slots are published one by one (StateView::ring_ready)
-    int sched;           // the 20-human shard's kernel: sub-launch 0..3 of the 3-of-4 env schedule (launch_rollout), -1 = all envs
+    int sched;           // the 20-human shard's kernel: sub-launch 0..3 of the 3-of-4 env schedule (launch_rollout), -1 = all envs,
+                         // kSchedDynamic = persistent workgroups taking (env, visit) items from a device queue
+    int dyn_visits;      // ... visits per env and call under the dynamic schedule (launch_rollout: ~56 steps per visit)
     int kd;              // A > 10: some rvo2 simulator of an env holds more than 10 agents and splits its kd-tree (kd_order.h)
     KdLayout kdl;        // ... and where its bookkeeping lives in LDS (offsets from Smem::kd_off)
     double dt, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
@@ -80,6 +82,7 @@ struct StateView {
     int* ring_claim;        // [B*D] async fill: ordinal + 1 some fill launch is generating (or has generated) for the slot
     uint8_t* kd_order;      // [B*A][kd_row_bytes(A)] the permutation each agent's rvo2 simulator partitions in place (kd_order.h)
     uint8_t* kd_valid;      // [B*A] 0 = a freshly built simulator (identity order)
+    int* dyn_queue;         // [1 + B] dynamic schedule of the shard kernel: [0] next (env, visit) item, [1 + env] visits env has COMPLETED
     int* ep_word;           // [B] (episodes finished << 2) | io.active state, ONE word stored by the rollout kernels next to the
                             // two io arrays: the asynchronous fill reads it for a consistent (state, ep_count) snapshot
     // launch epilogue of the rollout kernels (rollout_epilogue): arrival tickets and partial sums
@@ -279,14 +282,14 @@ __device__ __forceinline__ int pair_info(const Params& P, const Smem& s, int p) 
 }
 
 template <bool COMPACT = false>
-__device__ __forceinline__ void build_pairs(const Params& P, const Smem& s) {
+__device__ __forceinline__ void build_pairs(const Params& P, const Smem& s, bool every_env_exists = false) {
     for (int p = threadIdx.x; p < P.pairs; p += P.threads) {
         const int q = p / P.NC;
         const int c = p - q * P.NC;
         const int el = q / P.A;
         const int a = q - el * P.A;
         int j;
-        bool exists = ((int)blockIdx.x * P.E + el) < P.B;
+        bool exists = every_env_exists || ((int)blockIdx.x * P.E + el) < P.B;
         if (a == 0) {
             j = c + 1;
         } else {
@@ -1579,6 +1582,16 @@ __device__ __forceinline__ void rollout_epilogue(const Params& P, const StateVie
 // VGPRs) and uses the compact LDS layout (carve<.., COMPACT>: 12 workgroups per CU); the generic 10-half-plane instantiations are
 // left to the register allocator (two waves).
 constexpr int kGeom20Waves = 3;
+// DYNAMIC SCHEDULE of the shard's kernel (Params::sched == kSchedDynamic; round 5).  The static 3-of-4 schedule needs every
+// workgroup of a sub-launch resident in ONE round: a single slot held by somebody else — a scenario-generator workgroup of the
+// asynchronous fill that runs for milliseconds — sends a step workgroup to a second round and doubles the sub-launch.  Here the
+// grid is a set of PERSISTENT workgroups (at most the resident slots) that take (env, visit)
+// items from a device queue: a call of n steps is V = Params::dyn_visits visits of n / V steps per env, queued visit-major (all
+// envs' visit 0, then all visit 1, ...), so the chip is busy for V B / G "rounds" of n / V steps whatever G is, with no launch
+// boundary (and no slowest-wave tail) in between; short visits (~56 steps) also even out the envs that sit in a jam.  An env's
+// visits must run in order: a workgroup that takes visit k of an env waits until dyn_queue[1 + env] == k (release / acquire at agent scope around the env's state in HBM).  No deadlock: an
+// item's predecessor was dequeued earlier, i.e. is held by a workgroup that is running.
+constexpr int kSchedDynamic = 100;
 template <int MAXL, bool UNI, bool HEADLINE = false, bool KD = false>
 __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves : 1)) void rollout_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                             RolloutView R, int n_steps, const double* ext_action) {
@@ -1624,6 +1637,36 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
         s.disc[kParCollision] = P.collision_penalty, s.disc[kParDDist] = P.discomfort_dist;
         s.disc[kParDFactor] = P.discomfort_factor, s.disc[kParHSafety] = P.human_safety;
     }
+    constexpr bool kDyn = HEADLINE && MAXL == 10;
+    const bool dynamic = kDyn && P.sched == kSchedDynamic;
+    unsigned int dyn_transitions = 0u;  // (lane 0) transitions of all the visits this workgroup ran
+    const int n_steps_call = n_steps;
+    for (int visit_iter = 0; dynamic || visit_iter == 0; ++visit_iter) {
+    int dyn_env = 0, dyn_k = 0;
+    if (kDyn && dynamic) {
+        __syncthreads();  // (the previous visit's last LDS reads are done)
+        if (threadIdx.x == 0) {
+            int* const queue = Sd->dyn_queue;
+            const int v = atomicAdd(queue, 1);
+            if (v < P.dyn_visits * P.B) {  // wait for the env's previous visit: its state is in memory once the flag says so
+                const int env = v % P.B, k = v / P.B;
+                int spins = 0;
+                while (__hip_atomic_load(queue + 1 + env, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < k && spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(16);
+                    ++spins;
+                }
+            }
+            s.flag[1] = v;
+        }
+        __syncthreads();
+        const int v = s.flag[1];
+        if (v >= P.dyn_visits * P.B) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: what the previous visit's workgroup wrote is visible
+        dyn_env = v % P.B, dyn_k = v / P.B;
+        env_block = dyn_env;
+        const int q = n_steps_call / P.dyn_visits, rem = n_steps_call - q * P.dyn_visits;
+        n_steps = q + (dyn_k < rem ? 1 : 0);
+    }
     const Lane L = lane_of(P, env_block);
     AgentRegs r = {};
     float robot_max_speed = 0.0f;
@@ -1638,7 +1681,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
         if (KD) kd_load(P, S, s, L);
         if (robot) theta = S.theta[L.env];
     }
-    build_pairs<COMPACT>(P, s);
+    if (visit_iter == 0) build_pairs<COMPACT>(P, s, dynamic);
     if (robot) {
         const StateView S = *Sd;
         const cn_rollout_io io = *R.io;
@@ -1804,7 +1847,31 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
         if (io.cur_danger_dmin_sum) io.cur_danger_dmin_sum[L.env] = cur_dsum;
         S.ep_word[L.env] = (ep_count << 2) | state;
     }
+    if (kDyn && dynamic) {
+        if (robot) {
+            const cn_rollout_io io = *R.io;
+            if (io.env_transitions) io.env_transitions[L.env] += (uint64_t)transitions;
+            dyn_transitions += transitions;
+        }
+        // release: this env's state, bookkeeping and kd rows are in memory before its next visit may start anywhere
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(Sd->dyn_queue + 1 + dyn_env, dyn_k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+    }
     rollout_epilogue(P, S, *R.io, L, robot, transitions, ep_count, reinterpret_cast<double*>(s.lines), extra_env);
+    }  // visits
+    if (kDyn && dynamic) {
+        // the job-wide transitions counter, if the caller keeps one (per-env counters were added visit by visit; the in-kernel
+        // summary / record blocks are not offered under the dynamic schedule: launch_rollout falls back to the static one)
+        __syncthreads();
+        cn_rollout_io io = *R.io;
+        io.blocks = nullptr, io.summary = nullptr, io.env_transitions = nullptr;
+        Lane Le;
+        Le.lane = threadIdx.x, Le.env = (int)blockIdx.x, Le.a = threadIdx.x == 0 ? 0 : 1, Le.ebase = 0, Le.valid = true, Le.gi = 0;
+        rollout_epilogue(P, *Sd, io, Le, threadIdx.x == 0, dyn_transitions, 0, reinterpret_cast<double*>(s.lines));
+    }
 }
 
 #endif  // CN_SARL_TU

@@ -208,15 +208,20 @@ int cn_set_gamma(cn_engine* e, double gamma);
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io);
 /* replaces the `while not done: action = robot.act(ob); env.step(action)` loop of
  * Explorer.run_k_episodes (explorer.py:41-48) for an on-device robot policy (robot_policy ==
- * CN_ROBOT_ORCA): n_steps transitions per active env in ONE call, with in-kernel auto-reset.  A call is one kernel launch,
- * except on the 20-human shard geometry (20 humans + robot, max_neighbors 10, holonomic) when the 3-of-4 env schedule saves
- * rounds of the chip: with S = 12 x CUs resident one-wave workgroups, a call of n >= 48 steps is split when num_envs % 4 == 0
- * and 4 ceil(0.75 B / S) < 3 ceil(B / S) (on 256 CUs: B = 4096 yes; 2048, 3072, 6144 no; CROWDNAV_AMD_SCHED_FORCE=1 splits
- * any multiple of four, CROWDNAV_AMD_SCHED_MIN_STEPS moves the 48) into one launch of n % 3 steps over all envs and four
- * launches of n / 3 steps over three envs of every four — every env makes its n transitions in order.  Per-env state, the
- * per-env counters and the episode records are bit-identical to an unsplit call; the float64 SUMS of io.summary (nav time,
- * return) are accumulated in a different workgroup order under the schedule and may differ from an unsplit call's, and from
- * cn_records_summary's, in the last bits (counts are exact).  cn_launch_counts reports whether a call was split. */
+ * CN_ROBOT_ORCA): n_steps transitions per active env in ONE call, with in-kernel auto-reset.  A call is one kernel launch
+ * over all envs, except on the 20-human shard geometry (20 humans + robot, max_neighbors 10, holonomic), whose kernel keeps S =
+ * 12 x CUs one-wave workgroups resident: when B > S (or beside the asynchronous scenario fill, or with
+ * CROWDNAV_AMD_SCHED_FORCE=1) a call of n >= 24 steps (CROWDNAV_AMD_SCHED_MIN_STEPS; the static form: 48) runs under a SCHEDULE:
+ *   - dynamic (default): ONE launch of min(B, S) persistent workgroups that take (env, visit) items from a device queue — a call
+ *     is max(3, n / 56) visits per env (CROWDNAV_AMD_DYN_VISITS), an env's visits in order (release / acquire on a per-env word):
+ *     the chip stays full whatever B / S is, and nothing waits at a launch boundary for the slowest wave of a round;
+ *   - static (CROWDNAV_AMD_SCHED_DYNAMIC=0, and whenever io.summary or io.blocks is set; needs B % 4 == 0 and
+ *     4 ceil(0.75 B / S) < 3 ceil(B / S)): one launch of n % 3 steps over all envs and four launches of n / 3 steps over three
+ *     envs of every four (the in-kernel statistics cover every env: the last sub-launch reports for the env it leaves out).
+ * Every env makes its n transitions in order either way: per-env state, per-env counters and episode records are bit-identical
+ * to an unscheduled call; the float64 SUMS of io.summary (nav time, return) are accumulated in a different workgroup order under
+ * the static schedule and may differ from an unscheduled call's, and from cn_records_summary's, in the last bits (counts are
+ * exact).  cn_launch_counts reports what a call launched. */
 int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
 
 /* (ABI v7) what the HOST has enqueued for this engine since cn_create — counts_host: HOST uint64 [CN_LAUNCH_COUNTERS], indexed
@@ -225,7 +230,8 @@ int cn_rollout(cn_engine* e, const cn_rollout_io* io, int n_steps);
  * last one exceed the ring depth) and whether the 20-human shard's 3-of-4 env schedule was taken — instead of inferring it. */
 enum {
     CN_COUNT_ROLLOUT_KERNELS = 0,   /* transition kernels launched by cn_rollout / cn_rollout_step */
-    CN_COUNT_SCHEDULED_KERNELS = 1, /* ... of which sub-launches of the 3-of-4 env schedule (four per split call) */
+    CN_COUNT_SCHEDULED_KERNELS = 1, /* ... of which launches of the shard kernel's schedules: one per call under the dynamic
+                                       schedule, four per call (sub-launches) under the static 3-of-4 one */
     CN_COUNT_RING_FILLS = 2,        /* synchronous scenario-ring fills (one per cn_rollout call that needed one) */
     CN_COUNT_ASYNC_FILLS = 3        /* fill launches on the side streams (CN_FLAG_ASYNC_SCENARIO_FILL: one per call) */
 };

@@ -7,9 +7,10 @@ per episode), OpenMP over envs — seconds on the GPU box's host:
       seeds 2000 + c, launches of 200 / 5 / 20 steps, ABI-v6 arrangement (per-env transition counters, no in-kernel summary,
       ONE record per env) -> rollout_fused_kernel<true>; the shard-boundary numbers (cn_rollout_summary) against
       explorer.py:74-90 computed from the ORACLE's records.
-  (b) configs[3]'s shard with the 3-of-4 env schedule engaging BY ITSELF (no CROWDNAV_AMD_SCHED_FORCE): 4096 envs x 20 humans,
-      12 m circle, launches of 150 / 49 / 3 steps -> rollout_kernel<10, false, true, true> over 3072 workgroups; the engine's
-      launch counters prove the split path ran.
+  (b) configs[3]'s shard with its schedule engaging BY ITSELF (no CROWDNAV_AMD_SCHED_FORCE): 4096 envs x 20 humans, 12 m circle,
+      launches of 150 / 49 / 3 steps -> rollout_kernel<10, false, true, true> as persistent workgroups on a device queue of
+      (env, visit) items (the default) and as the static 3-of-4 sub-launches over 3072 workgroups; the engine's launch counters
+      prove which path ran.
   (c) the same shard on the reference's own 4 m circle with CN_FLAG_ASYNC_SCENARIO_FILL: timing decides when an env pauses,
       never what it plays — every finished episode is the oracle's, in order.
 Integer results bit-exact, float64 sums / states to 1e-9 (scenario generation: device sincos vs libm, <= 1e-12 per reset)."""
@@ -129,18 +130,25 @@ def _shard20(amd, oracle_mod, radius, flags, seed, launches, K):
     return ora, total, rec, cur, eng, bufs, counts
 
 
-def test_configs3_shard_schedule_engages_by_itself_vs_oracle(amd, oracle_mod, monkeypatch):
+@pytest.mark.parametrize('dynamic', [True, False])
+def test_configs3_shard_schedule_engages_by_itself_vs_oracle(amd, oracle_mod, monkeypatch, dynamic):
+    """dynamic: ONE launch of persistent workgroups taking (env, visit) items from a device queue (the default since round 5);
+    static (CROWDNAV_AMD_SCHED_DYNAMIC=0, and whenever the caller asks for in-kernel statistics): the 3-of-4 sub-launches."""
     monkeypatch.delenv('CROWDNAV_AMD_SCHED_FORCE', raising=False)
     monkeypatch.delenv('CROWDNAV_AMD_SCHED_MIN_STEPS', raising=False)
+    monkeypatch.setenv('CROWDNAV_AMD_SCHED_DYNAMIC', '1' if dynamic else '0')
     import torch
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip('the round arithmetic of the 3-of-4 schedule is stated for 256 CUs')
     launches, K = [150, 49, 3], 16
     ora, total, rec, cur, eng, bufs, counts = _shard20(amd, oracle_mod, 12.0, 0, (1000, 500), launches, K)
     d = [{k: b[k] - a[k] for k in a} for a, b in zip(counts, counts[1:])]
-    # 150 = 3 x 50: four sub-launches; 49 = 3 x 16 + 1: one launch over all envs + four; 3 < 48: one plain launch
-    assert [x['rollout_kernels'] for x in d] == [4, 5, 1]
-    assert [x['scheduled_kernels'] for x in d] == [4, 4, 0]
+    if dynamic:  # one persistent launch per call of 24+ steps; 3 steps: a plain launch over all envs
+        assert [x['rollout_kernels'] for x in d] == [1, 1, 1]
+        assert [x['scheduled_kernels'] for x in d] == [1, 1, 0]
+    else:  # 150 = 3 x 50: four sub-launches; 49 = 3 x 16 + 1: one launch over all envs + four; 3 < 48: one plain launch
+        assert [x['rollout_kernels'] for x in d] == [4, 5, 1]
+        assert [x['scheduled_kernels'] for x in d] == [4, 4, 0]
     steps = sum(launches)
     assert int(_np(bufs['transitions'])[0]) == total == 4096 * steps
     assert np.array_equal(_np(bufs['ep_count']), rec['count']) and rec['count'].min() >= 1
