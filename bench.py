@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
-PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r05_traffic.json')
 REFERENCE_PYTHON_PROFILE = os.path.join(ROOT, 'profiles', 'r05_reference_python.json')
 
 

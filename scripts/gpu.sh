@@ -69,29 +69,27 @@ sarl)
     ( export CROWDNAV_AMD_LIB=$lib; timeout 200 python scripts/sarl_bench.py ${CN_SARL_ARGS} ) 2>&1 | grep -v amdgpu.ids | tail -n 6 | sed "s/^/$n: /" | tee -a $OUT/sarl_bench.txt
   done ;;
 trace)
-  prof trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary
-  prof trace_driver --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5
+  prof trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition
+  prof trace_driver --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --steps 20 --warmup 5
   prof trace_sarl --kernel-trace --stats --output-format csv -d $OUT/trace_sarl -o trace -- python $REPO/scripts/sarl_bench.py
   prof trace_om_sarl --kernel-trace --stats --output-format csv -d $OUT/trace_om_sarl -o trace -- python $REPO/scripts/sarl_bench.py --om 1
-  prof trace_h20 --kernel-trace --stats --output-format csv -d $OUT/trace_h20 -o trace -- python $REPO/bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1500 --warmup 500 --chunk 500
+  prof trace_h20 --kernel-trace --stats --output-format csv -d $OUT/trace_h20 -o trace -- python $REPO/bench.py --no-cpu-baseline --no-r3-definition --humans 20 --circle-radius 12 --steps 2997 --warmup 999 --chunk 999
   for t in default driver sarl om_sarl h20; do python scripts/prof_summary.py $OUT/trace_$t | head -8; done ;;
 pmc)
   SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"
   SQ2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU"
   MF="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   declare -A CMD
-  CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary"
-  CMD[driver]="$REPO/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5"
-  # (h20 counters: one dispatch per call - the 3-of-4 env schedule off - so that a dispatch is 4096 envs x 501 steps)
-  CMD[h20]="$REPO/bench.py --no-cpu-baseline --humans 20 --circle-radius 12 --steps 1503 --warmup 501 --chunk 501"
+  CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition"
+  CMD[driver]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --steps 20 --warmup 5"
+  # (h20 counters: the dynamic schedule is ONE dispatch per call: 4096 envs x 999 steps, the shape of stage benchh20)
+  CMD[h20]="$REPO/bench.py --no-cpu-baseline --no-r3-definition --humans 20 --circle-radius 12 --steps 2997 --warmup 999 --chunk 999"
   for shape in ${CN_PMC_SHAPES:-default driver h20}; do
-    [ $shape = h20 ] && export CROWDNAV_AMD_SCHED_MIN_STEPS=1000000000 || unset CROWDNAV_AMD_SCHED_MIN_STEPS
     prof pmc_${shape}_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${shape}_fetch -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${shape}_write -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_sq1 --pmc $SQ1 --output-format csv -d $OUT/pmc_${shape}_sq1 -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_sq2 --pmc $SQ2 --output-format csv -d $OUT/pmc_${shape}_sq2 -o p -- python ${CMD[$shape]}
   done
-  unset CROWDNAV_AMD_SCHED_MIN_STEPS
   for v in sarl om_sarl; do
     a=""; [ $v = om_sarl ] && a="--om 1"
     prof pmc_${v}_mfma --pmc $MF --output-format csv -d $OUT/pmc_${v}_mfma -o p -- python $REPO/scripts/sarl_bench.py --iters 3 $a
@@ -102,7 +100,7 @@ pmc)
   P="python scripts/pmc_to_traffic.py $OUT/${TAG}_traffic.json"
   $P 4096 5 1000 rollout_fused_kernel tail $OUT/pmc_default_fetch $OUT/pmc_default_write $OUT/pmc_default_sq1 $OUT/pmc_default_sq2 > /dev/null
   $P 4096 5 20 rollout_fused_kernel 2 $OUT/pmc_driver_fetch $OUT/pmc_driver_write $OUT/pmc_driver_sq1 $OUT/pmc_driver_sq2 > /dev/null
-  CN_PMC_RADIUS=12 $P 4096 20 501 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 > /dev/null
+  CN_PMC_RADIUS=12 $P 4096 20 999 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 > /dev/null
   python scripts/prof_summary.py $OUT/pmc_sarl_mfma | tail -n 4; python scripts/prof_summary.py $OUT/pmc_om_sarl_mfma | tail -n 4
   head -c 1500 $OUT/${TAG}_traffic.json ;;
 h20ab)
