@@ -605,7 +605,7 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
     s = [float(v) for v in summary.cpu().tolist()]
     event_spans = [(e0.elapsed_time(e1) / 1e3, n) for e0, e1, n in events]
     fill_s = None
-    if fill_probe and not args.async_fill:
+    if fill_probe and not args.async_fill and not args.no_fill_probe:
         fill_s = measure_fill_seconds(eng, ring_depth())
     per_rank = comm.all_gather({'rank': rank, 'transitions': transitions, 'seconds': elapsed, 'boundary_seconds': boundary})
     # the slowest rank's K steps, the slowest rank's boundary; transitions of every shard (they differ by the few ring-dry pauses)
@@ -736,6 +736,9 @@ def main():
                          'summary of one engine and of gathered shards is the same statistic at every world size')
     ap.add_argument('--no-r3-definition', action='store_true',
                     help='skip the second measurement (value_r3_definition: in-kernel job-wide statistics, rounds 1-3)')
+    ap.add_argument('--no-fill-probe', action='store_true',
+                    help='skip fill_ms / value_amortised_fill (3 x 49 one-step launches after the timed region: profiling runs '
+                         'that average per-dispatch counters of the rollout kernel want only the launches of the named shape)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the configs[2] / configs[3] measurements that follow the headline at N=1')

@@ -69,21 +69,21 @@ sarl)
     ( export CROWDNAV_AMD_LIB=$lib; timeout 200 python scripts/sarl_bench.py ${CN_SARL_ARGS} ) 2>&1 | grep -v amdgpu.ids | tail -n 6 | sed "s/^/$n: /" | tee -a $OUT/sarl_bench.txt
   done ;;
 trace)
-  prof trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition
-  prof trace_driver --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --steps 20 --warmup 5
+  prof trace_default --kernel-trace --stats --output-format csv -d $OUT/trace_default -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --no-fill-probe
+  prof trace_driver --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o trace -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --no-fill-probe --steps 20 --warmup 5
   prof trace_sarl --kernel-trace --stats --output-format csv -d $OUT/trace_sarl -o trace -- python $REPO/scripts/sarl_bench.py
   prof trace_om_sarl --kernel-trace --stats --output-format csv -d $OUT/trace_om_sarl -o trace -- python $REPO/scripts/sarl_bench.py --om 1
-  prof trace_h20 --kernel-trace --stats --output-format csv -d $OUT/trace_h20 -o trace -- python $REPO/bench.py --no-cpu-baseline --no-r3-definition --humans 20 --circle-radius 12 --steps 2997 --warmup 999 --chunk 999
+  prof trace_h20 --kernel-trace --stats --output-format csv -d $OUT/trace_h20 -o trace -- python $REPO/bench.py --no-cpu-baseline --no-r3-definition --no-fill-probe --humans 20 --circle-radius 12 --steps 2997 --warmup 999 --chunk 999
   for t in default driver sarl om_sarl h20; do python scripts/prof_summary.py $OUT/trace_$t | head -8; done ;;
 pmc)
   SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"
   SQ2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU"
   MF="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   declare -A CMD
-  CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition"
-  CMD[driver]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --steps 20 --warmup 5"
+  CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --no-fill-probe"
+  CMD[driver]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --no-fill-probe --steps 20 --warmup 5"
   # (h20 counters: the dynamic schedule is ONE dispatch per call: 4096 envs x 999 steps, the shape of stage benchh20)
-  CMD[h20]="$REPO/bench.py --no-cpu-baseline --no-r3-definition --humans 20 --circle-radius 12 --steps 2997 --warmup 999 --chunk 999"
+  CMD[h20]="$REPO/bench.py --no-cpu-baseline --no-r3-definition --no-fill-probe --humans 20 --circle-radius 12 --steps 2997 --warmup 999 --chunk 999"
   for shape in ${CN_PMC_SHAPES:-default driver h20}; do
     prof pmc_${shape}_fetch --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${shape}_fetch -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${shape}_write -o p -- python ${CMD[$shape]}
