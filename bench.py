@@ -301,9 +301,18 @@ def measure_h20(B, local_rank):
     import crowdnav_amd
     H = 20
 
-    def one(radius, flags, seed_base, seed_mod, warm, lengths, refill_before_each=False):
-        sim = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA, robot_visible=1,
-                                           device=local_rank, circle_radius=radius, flags=flags)
+    def one(radius, flags, seed_base, seed_mod, warm, lengths, refill_before_each=False, scenario_cache=True):
+        # (cn_create reads the switch: the scenario cache of the wave generators, on by default for seed sets of <= 4096 values)
+        old = os.environ.get('CROWDNAV_AMD_SCENARIO_CACHE')
+        os.environ['CROWDNAV_AMD_SCENARIO_CACHE'] = '1' if scenario_cache else '0'
+        try:
+            sim = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=H, robot_policy=crowdnav_amd.ROBOT_ORCA, robot_visible=1,
+                                               device=local_rank, circle_radius=radius, flags=flags)
+        finally:
+            if old is None:
+                os.environ.pop('CROWDNAV_AMD_SCENARIO_CACHE', None)
+            else:
+                os.environ['CROWDNAV_AMD_SCENARIO_CACHE'] = old
         bufs = sim.rollout_begin(seed_base=seed_base, seed_mod=seed_mod, episode_limit=-1, record_capacity=4)
         for n in warm:
             sim.rollout(n)
@@ -347,19 +356,26 @@ def measure_h20(B, local_rank):
     # 1024 of rounds 2-3 (4096 = 4 x 1024) every env replayed ONE scenario for ever, and the envs that drew a hard one (up to
     # 13 M random() calls) were paused most of the time - the paused share measured the seed table, not the engine
     seeds = (1000, 1021)
+    ASYNC = crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL
     return {
         'workload': '%d envs x %d humans per GPU, ORCA humans + ORCA robot, cn::rollout_kernel<10>' % (B, H),
-        'r4_async_fill': one(4.0, crowdnav_amd.FLAG_ASYNC_SCENARIO_FILL, seeds[0], seeds[1], [501], [999] * 6),
+        # the reference's own geometry, resets INCLUDED.  The episode seeds are the bounded 'test' set (the reference's rejection
+        # sampling terminates on it), so the wave generators' scenario cache applies: every seed is generated once per rollout
+        'r4': one(4.0, 0, seeds[0], seeds[1], [999], [999] * 3),
+        'r4_async_fill': one(4.0, ASYNC, seeds[0], seeds[1], [501], [999] * 6),
+        # ... and with the cache switched off: every scenario generated afresh (rounds 2-4's figure; generator-throughput-bound)
+        'r4_async_fill_no_scenario_cache': one(4.0, ASYNC, seeds[0], seeds[1], [501], [999] * 6, scenario_cache=False),
         'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47] * 30, refill_before_each=True),
-        # (launch lengths divisible by three: the shard kernel's 3-of-4 env schedule splits a call of 3 q + r steps into four
-        # launches of q steps and one of r over all envs, crowdnav_amd.hip: launch_rollout)
         'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [201, 999], [999, 999, 999]),
         'episode_seeds_r4': '%d + c %% %d' % seeds,
-        'note': 'r4_async_fill: resets included, six 999-step launches back to back under one event pair (envs whose next '
-                'scenario is not ready pause: paused_env_steps); '
-                'r4_resets_excluded: HIP events around 47-step launches that stay inside the ring budget, so the timed launch '
-                'is the transition kernel alone (the synchronous fill runs in the untimed 1-step launch before it); r12: '
-                'resets included, cheap at that radius',
+        'note': 'r4: 4 m circle (env.config), resets included, synchronous ring fill, three 999-step calls under one event pair; '
+                'r4_async_fill: the same with CN_FLAG_ASYNC_SCENARIO_FILL, six calls (envs whose next scenario is not ready pause: '
+                'paused_env_steps).  Both with the scenario cache (a rollout whose episode seeds come from <= 4096 values '
+                'generates each scenario once: the 1021 seeds here are all cached after the warm-up call); '
+                'r4_async_fill_no_scenario_cache: CROWDNAV_AMD_SCENARIO_CACHE=0, every scenario generated afresh (28 k random() calls '
+                'on average, 60 % of all attempts in the ten hardest seeds) — what an UNBOUNDED seed set costs; '
+                'r4_resets_excluded: HIP events around 47-step calls that stay inside the ring budget (the fill runs in the untimed '
+                '1-step call before each); r12: 12 m circle, unbounded seeds 2000 + c, resets included (cheap at that radius)',
     }
 
 
@@ -846,6 +862,7 @@ def main():
                                     'ring (ring budget rule); calls of the timed region that carried one: %d of %d'
                                     % (m['ring_depth'], fills, launches),
                    'fills_in_timed_region': fills,
+                   'scenario_cache': (H > 8 and args.seed_mod <= 4096 and os.environ.get('CROWDNAV_AMD_SCENARIO_CACHE', '1') != '0'),
                    'preroll_steps': args.preroll,
                    'parallelism': 'env-axis shards x%d, no collective on the step path; the job-wide statistics (record blocks, '
                                   'their all-gather on several GPUs, summary kernel) once when a run ends (boundary_ms)' % world,

@@ -102,6 +102,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->sched_force = env_int("CROWDNAV_AMD_SCHED_FORCE", 0) != 0;
     e->sched_reserve = env_int("CROWDNAV_AMD_DYN_RESERVE", 0);  // slots left free beside a dynamic launch under the asynchronous fill
     e->sched_dynamic = env_int("CROWDNAV_AMD_SCHED_DYNAMIC", 1) != 0;
+    e->scenario_cache = env_int("CROWDNAV_AMD_SCENARIO_CACHE", 1) != 0;
     e->dyn_visits = env_int("CROWDNAV_AMD_DYN_VISITS", 0);  // 0: by call length (launch_rollout)
     P.dyn_visits = 3;
     {
@@ -165,6 +166,10 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) || (rc = dev_alloc(e, &S.dyn_queue, (size_t)P.B + 1)) ||
+        (rc = dev_alloc(e, &S.cache_pos, e->gen_wave ? (size_t)cn::kScenarioCacheMax * P.A : (size_t)1)) ||
+        (rc = dev_alloc(e, &S.cache_goal, e->gen_wave ? (size_t)cn::kScenarioCacheMax * P.A : (size_t)1)) ||
+        (rc = dev_alloc(e, &S.cache_rv, e->gen_wave ? (size_t)cn::kScenarioCacheMax * P.A : (size_t)1)) ||
+        (rc = dev_alloc(e, &S.cache_state, (size_t)cn::kScenarioCacheMax)) ||
         (rc = dev_alloc(e, &S.kd_order, P.kd ? n * cn::kd_row_bytes(P.A) : (size_t)4)) ||
         (rc = dev_alloc(e, &S.kd_valid, P.kd ? n : (size_t)4)) ||
         (rc = dev_alloc(e, &S.wg_partial, (size_t)P.B * (CN_SUMMARY_FIELDS + 1))) ||
@@ -461,6 +466,10 @@ int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     if (rc) return rc;
     if ((rc = check_io(e, io)) || (rc = drain_fill_streams(e)) || (rc = upload_io(e, io))) return rc;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
+    // scenario cache (step_kernels.h: cached_scenario_wave): on for the wave generators when the episode seeds come from a small
+    // set; a new rollout may number its seeds differently, so it starts empty
+    e->S.cache_n = (e->gen_wave && e->scenario_cache && io->seed_mod <= (uint32_t)cn::kScenarioCacheMax) ? (int)io->seed_mod : 0;
+    if (e->gen_wave) CN_HIP(hipMemsetAsync(e->S.cache_state, 0, sizeof(int) * cn::kScenarioCacheMax, e->stream));
     if (e->gen_wave)
         hipLaunchKernelGGL(cn::rollout_begin_wave_kernel, dim3(e->P.B), dim3(cn::kWave), 0, e->stream, e->P, e->C, e->S, R);
     else

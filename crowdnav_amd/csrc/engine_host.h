@@ -73,6 +73,7 @@ struct cn_engine {
     size_t smem;       // dynamic LDS bytes per workgroup
     int sched_min, sched_slots, sched_reserve, dyn_visits;  // the 20-human shard kernel's schedules (launch_rollout): shortest call split, resident workgroups, slots left free beside the asynchronous fill
     bool sched_force, sched_dynamic;
+    bool scenario_cache;  // wave generators keep the scenarios of a small seed set (CROWDNAV_AMD_SCENARIO_CACHE)
     uint64_t launch_counts[CN_LAUNCH_COUNTERS];  // cn_launch_counts: what the host enqueued since cn_create
     // Device memory comes from a few large slabs, not one hipMalloc per buffer: an engine has ~60 device buffers, most of them a
     // few KiB; one 32 MiB slab (plus one per buffer larger than that) is 2-4 mappings to create and - each hipFree being a device

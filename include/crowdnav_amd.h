@@ -204,7 +204,10 @@ typedef struct cn_rollout_io {
 int cn_set_gamma(cn_engine* e, double gamma);
 
 /* (re)start episode bookkeeping: every env b with b < episode_limit is reset to its episode j=0 scenario
- * and the per-env counters of io are zeroed. */
+ * and the per-env counters of io are zeroed.  Crowds of more than 8 humans (the wave-cooperative generators): when io.seed_mod <=
+ * 4096 — the episode seeds come from a small set, as in the reference's 'val' / 'test' phases (crowd_sim.py:272-283) — the rollout
+ * keeps every scenario it has generated and copies it when the same seed comes round again (a seeded scenario is a pure function
+ * of its seed; CROWDNAV_AMD_SCENARIO_CACHE=0 switches this off).  Same scenarios, same episodes. */
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io);
 /* replaces the `while not done: action = robot.act(ob); env.step(action)` loop of
  * Explorer.run_k_episodes (explorer.py:41-48) for an on-device robot policy (robot_policy ==

@@ -41,14 +41,16 @@ for l in open('$OUT/bench_driver.log'):
         for k in ('cadrl', 'lstm_rl'):
             if k in s: print(k, 'select ms', round(s[k]['roofline']['select_ms'], 3), 'mfma frac', round(s[k]['roofline']['frac'], 3))
         for k, v in (s.get('h20') or {}).items():
-            if isinstance(v, dict): print('h20', k, round(v['value'] / 1e6, 2), 'M env-steps/s, paused', v['paused_env_steps'])
+            if isinstance(v, dict) and 'value' in v: print('h20', k, round(v['value'] / 1e6, 2), 'M env-steps/s, paused', v['paused_env_steps'])
         print('cpu', {k: (round(v) if isinstance(v, float) else v) for k, v in (d.get('cpu_baseline') or {}).items() if k in ('value', 'cores', 'single_core_value')})
 PY
   ;;
 bench32k) bench bench_32k -- --no-cpu-baseline --no-secondary --envs 32768 --steps 4000 ;;
 benchh20)
   bench bench_h20_r12 -- --no-cpu-baseline --humans 20 --circle-radius 12 --steps 3996 --warmup 999 --chunk 999
-  bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill ;;
+  bench bench_h20_r4 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 999 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021
+  bench bench_h20_r4_async -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill
+  bench bench_h20_r4_async_nocache CROWDNAV_AMD_SCENARIO_CACHE=0 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill ;;
 ab)
   for lib in "" $REPO/build/exp/lib_ab_*.so; do
     n=$(basename "${lib:-intree}" .so)

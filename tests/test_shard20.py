@@ -115,3 +115,49 @@ def test_shard_kernel_with_external_robot_actions(amd, oracle_mod):
         k = len(rec_steps[b])
         assert got_steps[b, :k].tolist() == rec_steps[b] and got_out[b, :k].tolist() == rec_outcome[b]
     assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+
+
+@pytest.mark.parametrize('async_fill', [False, True])
+def test_scenario_cache_of_a_small_seed_set_changes_nothing(amd, oracle_mod, monkeypatch, async_fill):
+    """Round 5: the wave generators keep the scenarios of a rollout whose episode seeds come from a small set (seed_mod <=
+    4096; step_kernels.h: cached_scenario_wave) — here SEVEN seeds on the reference's 4 m circle, so nearly every auto-reset is
+    a cache copy.  Episodes, records, counters and end states are the oracle's (which generates every scenario afresh), and
+    equal bit for bit to a run with the cache switched off (CROWDNAV_AMD_SCENARIO_CACHE=0)."""
+    import torch
+    B, K, launches = 16, 64, [60, 120, 90]
+    cfg = dict(num_humans=20, circle_radius=4.0, robot_visible=1)
+    o = oracle_mod.CrowdOracle(num_envs=B, robot_policy=1, **cfg)
+    o.reset(1000 + np.arange(B) % 7)
+    total, rec, cur = o.rollout_full(sum(launches), 1000, 7, K)
+
+    def run(cache):
+        monkeypatch.setenv('CROWDNAV_AMD_SCENARIO_CACHE', '1' if cache else '0')
+        eng = amd.BatchedCrowdSim(num_envs=B, robot_policy=amd.ROBOT_ORCA, flags=amd.FLAG_ASYNC_SCENARIO_FILL if async_fill else 0,
+                                  **cfg)
+        bufs = eng.rollout_begin(seed_base=1000, seed_mod=7, episode_limit=-1, record_capacity=K)
+        for n in launches:
+            eng.rollout(n)
+            if async_fill:
+                eng.sync()  # (drains the fill streams: every env finds its scenarios, the two runs stay comparable)
+        eng.sync()
+        return eng, bufs
+
+    def check(eng, bufs):
+        cnt = _np(bufs['ep_count'])
+        assert cnt.min() >= 2 and cnt.sum() > 7 * 6 and (cnt <= rec['count']).all()  # far more episodes than seeds
+        if not async_fill:  # (with the asynchronous fill an env may wait for a scenario: behind the oracle, never ahead)
+            assert int(_np(bufs['transitions'])[0]) == total
+            assert np.array_equal(cnt, rec['count'])
+            assert np.abs(_np(eng.get_state()[0]) - o.get_state()[0]).max() <= 1e-9
+        live = np.arange(K)[None, :] < cnt[:, None]
+        for key, name in (('ep_outcome', 'outcome'), ('ep_steps', 'steps'), ('ep_time', 'time'), ('ep_danger', 'danger')):
+            assert np.array_equal(np.where(live, _np(bufs[key]), 0), np.where(live, rec[name], 0)), key
+
+    eng, bufs = run(True)
+    check(eng, bufs)
+    eng2, bufs2 = run(False)
+    check(eng2, bufs2)
+    if not async_fill:  # the same bits with and without the cache
+        for k in bufs:
+            assert torch.equal(bufs[k], bufs2[k]), k
+        assert torch.equal(eng.get_state()[0], eng2.get_state()[0])
