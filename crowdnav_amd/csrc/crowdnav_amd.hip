@@ -180,6 +180,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
         cn_destroy(e);
         return rc;
     }
+    e->S.error = e->C.error;
     if (hipMemcpy(e->S_dev, &e->S, sizeof(cn::StateView), hipMemcpyHostToDevice) != hipSuccess) {
         cn_destroy(e);
         return fail(CN_ERR_HIP, "cn_create: state view upload failed");
@@ -237,6 +238,11 @@ int cn_sync(cn_engine* e) {
     CN_HIP(hipMemcpy(&gen_error, e->C.error, sizeof(int), hipMemcpyDeviceToHost));
     if (gen_error) {
         CN_HIP(hipMemset(e->C.error, 0, sizeof(int)));
+        if (gen_error & 4)
+            return fail(CN_ERR_HIP,
+                        "the shard kernel's dynamic schedule: a workgroup waited ~2 s for an env's previous visit and went on "
+                        "without it (results of this rollout are not to be trusted); CROWDNAV_AMD_SCHED_DYNAMIC=0 selects the "
+                        "static schedule");
         if (gen_error & 2)
             return fail(CN_ERR_INVALID,
                         "cn_sarl_explore needs each env's numpy stream: (re)start the episodes with cn_reset (the scenario "

@@ -89,6 +89,7 @@ struct StateView {
     double2* cache_rv;
     int* cache_state;       // [kScenarioCacheMax] 0 = empty, 1 = complete (release / acquire at agent scope)
     int cache_n;            // seeds cached by the current rollout (io.seed_mod), 0 = off
+    int* error;             // [1] the engine's error word (ScenarioCfg::error): bit 2 = a visit of the dynamic schedule gave up waiting
     int* dyn_queue;         // [1 + B] dynamic schedule of the shard kernel: [0] next (env, visit) item, [1 + env] visits env has COMPLETED
     int* ep_word;           // [B] (episodes finished << 2) | io.active state, ONE word stored by the rollout kernels next to the
                             // two io arrays: the asynchronous fill reads it for a consistent (state, ep_count) snapshot
@@ -1697,6 +1698,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
                     __builtin_amdgcn_s_sleep(16);
                     ++spins;
                 }
+                if (spins == (1 << 22)) atomicOr(Sd->error, 4);  // ~2 s: never in a healthy run; cn_sync reports it
             }
             s.flag[1] = v;
         }
