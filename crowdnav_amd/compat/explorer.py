@@ -340,18 +340,18 @@ class Explorer(object):
                                  z((B,), torch.uint8), z((B,), torch.uint8), z((B, 2), torch.float64))
             _, traj, rew, inf, dmn, act, alive, done, action = self._rl_hist
             alive.fill_(1)
+            done.zero_()
             T = 0
             lap('weights + reset')
-            # Per step: the engine's kernels and ONE torch kernel — every result lands in its row of the histories (the dozen
-            # torch copies / compares per step this loop used to issue cost as much host time as the step costs device time:
-            # 158 us per step at one env, BASELINE configs[4]'s sampling)
+            # Per step: ONE library call (cn_sarl_sample_step: three launches at one env) and no torch kernel — every result
+            # lands in its row of the histories, and an env leaves `alive` at the start of the step after its episode ended
+            # (so "somebody still samples" is alive & ~done here)
             step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
-            done_b, eps = done.view(torch.bool), float(policy.epsilon)
+            eps = float(policy.epsilon)
             for t in range(max_steps):
                 step(t, eps)
-                alive.masked_fill_(done_b, 0)
                 T = t + 1
-                if t % 8 == 7 and not bool(alive.any().item()):
+                if t % 8 == 7 and not bool((alive > done).any().item()):
                     break
             eng.sync()
             lap('steps')

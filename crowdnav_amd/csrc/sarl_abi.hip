@@ -35,6 +35,11 @@ struct cn_sarl {
     float* om_w;        // kRegSarlPre: mlp1.0's occupancy-map columns [48][160 slots] and its bias [160] (sarl_om_weights_kernel)
     float* om_term;     // kRegSarlPre: b + W[:, 13:61] om per (env, human), [B * H][160] in accumulator order
     int n_cus;
+    // sarl_narrow_kernel: a few decisions (train.py's single-episode sampling) on tiles of 16 / H groups, one per workgroup
+    bool narrow;
+    size_t narrow_tiles, narrow_lds;
+    int* narrow_counter;  // cn_sarl_sample_step: workgroups of sarl_narrow_kernel that have written their V
+    double* narrow_value; // ... and reward + gamma V per (env, action), each written by the tile that computed V
 };
 
 void cn_sarl_release(cn_engine* e) {
@@ -267,14 +272,28 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
 
     s->n_groups = (size_t)C.B * C.n_actions;
     s->n_tiles = (s->n_groups + cn::kSarlGroups - 1) / cn::kSarlGroups;
+    // Few decisions: 16-row tiles of whole groups, one per workgroup, X built in the kernel (sarl_narrow_kernel) — while the
+    // whole launch is at most two workgroups per CU; beyond that the one-tile kernel's 16-group tiles do ~1.5 x less matrix
+    // work per group.  CROWDNAV_AMD_SARL_NARROW: 0 never, 1 (default) by size, 2 whenever the configuration allows it.
+    {
+        const int narrow_mode = env_int("CROWDNAV_AMD_SARL_NARROW", 1);
+        const size_t per_tile = (size_t)(cn::kSarlGroups / (H < 1 ? 1 : H));
+        s->narrow_tiles = per_tile ? (s->n_groups + per_tile - 1) / per_tile : 0;
+        s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
+        s->narrow = !cadrl && !lstm && !s->chunked && !s->reg_mlp && in_dim == 13 && !C.sort_lookahead && H >= 1 &&
+                    H <= cn::kSarlMaxHumans && e->cfg.scenario_rule != CN_MIXED && s->narrow_lds <= 160 * 1024 &&
+                    (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)2 * s->n_cus));
+    }
     const size_t nA = (size_t)C.B * (H + 1);
     if ((rc = dev_alloc(e, &s->actions, (size_t)2 * C.n_actions)) || (rc = dev_alloc(e, &s->orca_vel, 2 * nA)) ||
         (rc = dev_alloc(e, &s->next_obs, (size_t)C.B * H * 5)) ||
         (rc = dev_alloc(e, &s->om, (size_t)C.B * H * (extra > 0 ? extra : 1))) ||
         (rc = dev_alloc(e, &s->reward, s->n_groups)) || (rc = dev_alloc(e, &s->V, s->n_tiles * cn::kSarlGroups)) ||
         (rc = dev_alloc(e, &s->X, s->n_tiles * H * net.ks_x * 64)) ||
-        (rc = dev_alloc(e, &s->hcount, s->n_tiles * cn::kSarlGroups)))
+        (rc = dev_alloc(e, &s->hcount, s->n_tiles * cn::kSarlGroups)) || (rc = dev_alloc(e, &s->narrow_counter, 1)) ||
+        (rc = dev_alloc(e, &s->narrow_value, s->n_groups)))
         return rc;
+    CN_HIP(hipMemset(s->narrow_counter, 0, sizeof(int)));
     if (e->cfg.scenario_rule == CN_MIXED && s->chunked) {
         if (H <= cn::kSarlMaxHumans && !cadrl && !lstm)  // the network, not the crowd, is too large for one tile
             return fail(CN_ERR_UNSUPPORTED,
@@ -452,6 +471,15 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
     // the humans' next observable states: their own kernel only where something is built on them per (env, human) — occupancy
     // maps, LSTM-RL's re-ordering; otherwise the feature kernel derives them itself.  The reward of every (env, action) is
     // evaluated inside sarl_select_kernel.  (Each small kernel less is ~7 us of a 70 us single-env decision.)
+    if (s->narrow) {  // X never leaves the network kernel's LDS
+        hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
+                           e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
+                           s->next_obs, s->V, cn::SarlDecide{});
+        hipLaunchKernelGGL(cn::sarl_select_kernel, dim3((C.B + 3) / 4), dim3(256), 0, e->stream, C, e->S.pos, e->S.vel,
+                           e->S.goal, e->S.rv, e->S.gtime, e->S.theta, s->actions, s->reward, s->V, values, best, action);
+        CN_HIP(hipGetLastError());
+        return CN_OK;
+    }
     const bool lookahead = C.with_om || C.sort_lookahead;
     if (lookahead)
         hipLaunchKernelGGL(cn::sarl_lookahead_kernel, dim3((C.B * H + 255) / 256), dim3(256), 0, e->stream, C, e->S.pos,
@@ -584,6 +612,41 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
     return CN_OK;
 }
 
+int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
+                        int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin) {
+    int rc = bind(e);
+    if (rc) return rc;
+    cn_sarl* s = e->sarl;
+    if (!s || !s->weights_set) return fail(CN_ERR_INVALID, "cn_sarl_sample_step: configure and set weights first");
+    if (!alive || !best || !action || !reward || !done || !info)
+        return fail(CN_ERR_INVALID, "cn_sarl_sample_step: alive, best, action, reward, done and info must not be NULL");
+    if (!(epsilon >= 0.0 && epsilon <= 1.0)) return fail(CN_ERR_INVALID, "cn_sarl_sample_step: epsilon must be in [0, 1]");
+    if (e->P.robot_orca) return fail(CN_ERR_INVALID, "cn_sarl_sample_step: the robot must be CN_ROBOT_EXTERNAL");
+    const cn::SarlCfg& C = s->C;
+    const int64_t row = (int64_t)C.H * s->net.in_dim;
+    if (env_stride == 0) env_stride = row;
+    if (state_out && env_stride < row)
+        return fail(CN_ERR_INVALID, "cn_sarl_sample_step: env_stride %lld < %lld", (long long)env_stride, (long long)row);
+    if (s->narrow) {
+        // three launches: the humans' ORCA velocities, the value network with the decision behind it, the transition
+        if (!C.const_vel) cn_launch_orca(e, s->orca_vel);
+        cn::SarlDecide D{};
+        D.counter = s->narrow_counter, D.epsilon = epsilon, D.alive = alive, D.done = done, D.best = best, D.action = action;
+        D.state_out = state_out, D.env_stride = env_stride, D.sort_humans = sort_humans ? 1 : 0, D.in_dim = s->net.in_dim;
+        D.reward = s->reward, D.value = s->narrow_value, D.gtime = e->S.gtime, D.mt_key = e->S.mt_key, D.mt_pos = e->S.mt_pos, D.error = e->C.error;
+        hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
+                           e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
+                           s->next_obs, s->V, D);
+        CN_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(cn::sarl_alive_kernel, dim3((C.B + 255) / 256), dim3(256), 0, e->stream, C.B, alive, done);
+        if ((rc = cn_sarl_select(e, nullptr, best, action)) || (rc = cn_sarl_explore(e, epsilon, alive, best, action, nullptr)))
+            return rc;
+        if (state_out && (rc = cn_sarl_transform(e, state_out, env_stride, sort_humans))) return rc;
+    }
+    return cn_step(e, action, 1, reward, done, info, dmin, nullptr, nullptr, nullptr);
+}
+
 int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes) {
     int rc = bind(e);
     if (rc) return rc;
@@ -598,6 +661,13 @@ int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes) {
         case 2: src = s->next_obs, have = sizeof(double) * C.B * C.H * 5; break;
         case 3: src = s->om, have = sizeof(float) * C.B * C.H * (s->net.in_dim - 13); break;
         case 4:
+            if (s->narrow) {  // the network kernel built X in LDS: the same rows, for the caller who asks to see them
+                const size_t rows = s->n_tiles * cn::kSarlGroups * C.H;
+                hipLaunchKernelGGL(cn::sarl_feature_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, e->stream, C,
+                                   s->net.in_dim, s->net.ks_x, e->S.pos, e->S.goal, e->S.rv, e->S.theta, s->actions, s->next_obs,
+                                   s->om, s->X, s->n_tiles, s->hcount, 1, e->S.vel, (const float*)s->orca_vel);
+                CN_HIP(hipGetLastError());
+            }
             if (sarl_om_direct(s)) {
                 const size_t rows = s->n_tiles * cn::kSarlGroups * C.H;
                 hipLaunchKernelGGL(cn::sarl_om_columns_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, e->stream, C,

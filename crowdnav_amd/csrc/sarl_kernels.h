@@ -419,39 +419,12 @@ __global__ void sarl_om_columns_kernel(SarlCfg C, int in_dim, int ks_x, const fl
     for (int n = in_dim; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
 }
 
-// X row of (env b, action a, human h): CADRL.rotate of the float32 joint row
-// [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written straight in the MLP
-// kernel's LDS order: group G = b * K + a -> tile G / 16, g = G % 16, row tile = h;
-// X[((tile * H + h) * ks_x + n / 4) * 64 + (n % 4) * 16 + g] = feature n.  Lanes run over g fastest, so every
-// store instruction writes 16 consecutive words per (tile, h).
-__global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
-                                    const double2* rv, const double* theta, const double* actions,
-                                    double* next_obs, const float* om, float* X, size_t n_tiles,
-                                    int* hcount /*[n_tiles * 16] humans present per group*/,
-                                    int om_cols = 1 /* 0: the consumer reads the occupancy maps from `om` itself (they do
-                                    not depend on the action: written into X they are 81 copies, 48 of every 61 floats);
-                                    only k-steps 0..3 — the 13 rotated features and map values 0..2 — are written */,
-                                    const double2* vel = nullptr, const float* orca_vel = nullptr /* not null: no lookahead kernel ran */) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_tiles * C.H * kSarlGroups) return;
-    const int g = (int)(idx % kSarlGroups);
-    const int h = (int)((idx / kSarlGroups) % C.H);
-    const size_t tile = idx / ((size_t)kSarlGroups * C.H);
-    const size_t G = tile * kSarlGroups + g;
-    float* x = X + ((tile * C.H + h) * ks_x) * 64 + g;
-    if (G >= (size_t)C.B * C.n_actions) {  // padding groups of the last tile: finite zeros
-        for (int n = 0; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
-        if (h == 0) hcount[tile * kSarlGroups + g] = C.H;
-        return;
-    }
-    if (h == 0) {  // len(state.human_states): under the `mixed` rule the env's absent humans are parked behind the present ones
-        const size_t e0 = (G / C.n_actions) * (size_t)(C.H + 1);
-        int present = 0;
-        for (int j = 0; j < C.H; ++j) present += is_parked(pos[e0 + 1 + j]) ? 0 : 1;
-        hcount[tile * kSarlGroups + g] = present;
-    }
-    const int a = (int)(G % C.n_actions);
-    const int b = (int)(G / C.n_actions);
+// The 13 rotated features of X row (env b, action a, human h): CADRL.rotate of the float32 joint row
+// [propagate(self, action) (9) | next human state (5)] — shared by sarl_feature_kernel (X in HBM) and sarl_narrow_kernel (X
+// built in LDS by the kernel that consumes it).
+__device__ __forceinline__ void sarl_feature_row(const SarlCfg& C, int b, int a, int h, const double2* pos, const double2* goal,
+                                                 const double2* rv, const double* theta, const double* actions,
+                                                 double* next_obs, const double2* vel, const float* orca_vel, float* f) {
     const size_t g0 = (size_t)b * (C.H + 1);
     // propagate(self_state, action) in float64 (cadrl.py:113-118), then torch.Tensor([...]) narrows to float32
     double ax = actions[2 * a], ay = actions[2 * a + 1];
@@ -485,8 +458,44 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
         for (int k = 0; k < 5; ++k) o[k] = src[k];
     }
     const float px1 = (float)o[0], py1 = (float)o[1], vx1 = (float)o[2], vy1 = (float)o[3], radius1 = (float)o[4];
-    float f[13];
     rotate_row(px, py, vx, vy, radius, gx, gy, v_pref, theta_f, C.unicycle, px1, py1, vx1, vy1, radius1, f);
+}
+
+// X row of (env b, action a, human h): CADRL.rotate of the float32 joint row
+// [propagate(self, action) (9) | next human state (5)] (+ the human's occupancy map), written straight in the MLP
+// kernel's LDS order: group G = b * K + a -> tile G / 16, g = G % 16, row tile = h;
+// X[((tile * H + h) * ks_x + n / 4) * 64 + (n % 4) * 16 + g] = feature n.  Lanes run over g fastest, so every
+// store instruction writes 16 consecutive words per (tile, h).
+__global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const double2* pos, const double2* goal,
+                                    const double2* rv, const double* theta, const double* actions,
+                                    double* next_obs, const float* om, float* X, size_t n_tiles,
+                                    int* hcount /*[n_tiles * 16] humans present per group*/,
+                                    int om_cols = 1 /* 0: the consumer reads the occupancy maps from `om` itself (they do
+                                    not depend on the action: written into X they are 81 copies, 48 of every 61 floats);
+                                    only k-steps 0..3 — the 13 rotated features and map values 0..2 — are written */,
+                                    const double2* vel = nullptr, const float* orca_vel = nullptr /* not null: no lookahead kernel ran */) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_tiles * C.H * kSarlGroups) return;
+    const int g = (int)(idx % kSarlGroups);
+    const int h = (int)((idx / kSarlGroups) % C.H);
+    const size_t tile = idx / ((size_t)kSarlGroups * C.H);
+    const size_t G = tile * kSarlGroups + g;
+    float* x = X + ((tile * C.H + h) * ks_x) * 64 + g;
+    if (G >= (size_t)C.B * C.n_actions) {  // padding groups of the last tile: finite zeros
+        for (int n = 0; n < ks_x * 4; ++n) x[(n >> 2) * 64 + (n & 3) * 16] = 0.0f;
+        if (h == 0) hcount[tile * kSarlGroups + g] = C.H;
+        return;
+    }
+    if (h == 0) {  // len(state.human_states): under the `mixed` rule the env's absent humans are parked behind the present ones
+        const size_t e0 = (G / C.n_actions) * (size_t)(C.H + 1);
+        int present = 0;
+        for (int j = 0; j < C.H; ++j) present += is_parked(pos[e0 + 1 + j]) ? 0 : 1;
+        hcount[tile * kSarlGroups + g] = present;
+    }
+    const int a = (int)(G % C.n_actions);
+    const int b = (int)(G / C.n_actions);
+    float f[13];
+    sarl_feature_row(C, b, a, h, pos, goal, rv, theta, actions, next_obs, vel, orca_vel, f);
 #pragma unroll
     for (int k = 0; k < 13; ++k) x[(k >> 2) * 64 + (k & 3) * 16] = f[k];
     const int extra = in_dim - 13;
@@ -502,12 +511,9 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
 // state of every env: rotate(float32 [self_state (9) | human h (5)]) (+ human h's occupancy map among the current
 // human states) -> out[b][h][0..in_dim): the state a train-phase predict() leaves in policy.last_state and
 // Explorer.update_memory pushes into the replay memory.  lane = (env, position in the joint state).
-__global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, const double2* pos, const double2* vel,
-                                      const double2* goal, const double2* rv, const double* theta,
-                                      float* out /*[B][H][in_dim]*/, int64_t env_stride /*floats between envs*/) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C.B * C.H) return;
-    const int b = idx / C.H, h = idx - b * C.H;
+__device__ __forceinline__ void sarl_transform_row(const SarlCfg& C, int in_dim, int sort_humans, const double2* pos,
+                                                   const double2* vel, const double2* goal, const double2* rv,
+                                                   const double* theta, float* out, int64_t env_stride, int b, int h) {
     const size_t g0 = (size_t)b * (C.H + 1);
     // perm[p] = human at position p of the joint state.  LSTM-RL (sort_humans): LstmRL.predict re-orders the humans by
     // DEcreasing distance to the robot before MultiHumanRL.predict runs (lstm_rl.py:96-103; python's sorted(...,
@@ -561,6 +567,14 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
         occupancy_map(C, h, state_of, x + 13);
     }
 }
+__global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, const double2* pos, const double2* vel,
+                                      const double2* goal, const double2* rv, const double* theta,
+                                      float* out /*[B][H][in_dim]*/, int64_t env_stride /*floats between envs*/) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C.B * C.H) return;
+    const int b = idx / C.H;
+    sarl_transform_row(C, in_dim, sort_humans, pos, vel, goal, rv, theta, out, env_stride, b, idx - b * C.H);
+}
 
 // The epsilon-greedy branch of MultiHumanRL.predict (multi_human_rl.py:28-31), on each env's OWN numpy stream — the
 // one cn_reset seeded (np.random.seed in CrowdSim.reset, crowd_sim.py:272-276), continued after the scenario draws:
@@ -568,13 +582,11 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
 // np.random.choice(K) of the legacy RandomState is randint(0, K): 32-bit draws masked to the next power of two minus
 // one, rejected while > K - 1.  An env already at its goal (best == -1) returned before the draw (:22-23).
 // lane = env.  explored (optional) receives 1 where the random action replaced the greedy one.
-__global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos, const double* actions,
-                                    const uint8_t* mask, int32_t* best, double* action, uint8_t* explored,
-                                    int* error) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__device__ __forceinline__ void sarl_explore_env(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos,
+                                                 const double* actions, bool masked_out, int32_t* best, double* action,
+                                                 uint8_t* explored, int* error, int b) {
     if (explored) explored[b] = 0;
-    if (mask && !mask[b]) return;
+    if (masked_out) return;
     if (best[b] == -1) return;
     if (mt_pos[b] < 0) {  // the env was not (re)started by cn_reset: there is no stream to continue
         atomicOr(error, 2);
@@ -593,6 +605,13 @@ __global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_k
         if (explored) explored[b] = 1;
     }
     mt_pos[b] = rng.pos;
+}
+__global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos, const double* actions,
+                                    const uint8_t* mask, int32_t* best, double* action, uint8_t* explored,
+                                    int* error) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    sarl_explore_env(B, K, epsilon, mt_key, mt_pos, actions, mask && !mask[b], best, action, explored, error, b);
 }
 
 // ------------------------------------------------------------------------------------ value network
@@ -761,7 +780,7 @@ __device__ __forceinline__ void zero_lds(float* lds, size_t words, int tid) {
 // joint state of tile t is written — self features from registers, weighted sum, zero padding — only in tile t's last slot,
 // after the side chain has consumed the previous one.  The last tile's head runs after the loop on all waves.
 __device__ __forceinline__ void value_head_on_one_wave(const PackedLinear& P, const float* in, float* V, size_t tile,
-                                                       int n_groups, int lane) {
+                                                       int n_groups, int lane, int groups_per_tile = kSarlGroups) {
     const int row = lane & 15, slice = lane >> 4;  // 4 k slices of the 16 rows
     float sum = 0.0f;
     for (int s = slice; s < P.ksteps; s += 4) {
@@ -772,8 +791,8 @@ __device__ __forceinline__ void value_head_on_one_wave(const PackedLinear& P, co
     float v = as_global(P.bias)[0];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v += __shfl(sum, row + 16 * j);
-    const size_t G = tile * kSarlGroups + row;
-    if (slice == 0 && G < (size_t)n_groups) V[G] = v;
+    const size_t G = tile * groups_per_tile + row;
+    if (slice == 0 && row < groups_per_tile && G < (size_t)n_groups) V[G] = v;
 }
 
 template <int H>
@@ -897,6 +916,7 @@ __global__ __launch_bounds__(kSarlThreads) void sarl_mlp_pipe_kernel(SarlNetRef 
     }
 }
 __host__ inline size_t sarl_mlp_pipe_extra_lds_bytes(const SarlNet& net) { return sizeof(float) * 64 * (size_t)net.ks_a; }
+
 
 // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row, then the minimum over the humans
 // of a group (cadrl.py:162-163).  Layers live in L[kL_mlp3_0 .. kL_mlp3_6]; buffers as in the SARL kernel.
@@ -1280,26 +1300,11 @@ __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
 // ------------------------------------------------------------------------------------ action selection
 // value = reward + pow(gamma, time_step * v_pref) * V (multi_human_rl.py:52); the first strict maximum wins (:54);
 // a robot already at its goal stops (:22-23, policy.py:43-49).  best = -1 encodes that stop action.
-__global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* goal, const double2* rv,
-                                   const double* gtime, const double* theta, const double* actions, double* reward,
-                                   const float* V, double* values, int* best, double* action_out) {
-    // one wave per env: lanes stride over the actions, then a butterfly keeps the largest value, lowest index on ties
-    // (= the first strict maximum of the reference's loop; NaN and -inf never win: `value > max_value` is false)
-    const int b = blockIdx.x * (blockDim.x / kWaveSize) + (threadIdx.x / kWaveSize);
-    const int lane = threadIdx.x & (kWaveSize - 1);
-    if (b >= C.B) return;
-    double bv = -__builtin_inf();
-    int bi = -1;
-    for (int a = lane; a < C.n_actions; a += kWaveSize) {
-        const double r = sarl_reward_of(C, pos, vel, goal, rv, gtime, theta, actions, b, a);  // onestep_lookahead's reward
-        reward[(size_t)b * C.n_actions + a] = r;                                              // (kept for cn_sarl_export)
-        const double v = r + C.gamma_bar * (double)V[(size_t)b * C.n_actions + a];
-        if (values) values[(size_t)b * C.n_actions + a] = v;
-        if (v > bv) {
-            bv = v;
-            bi = a;
-        }
-    }
+// The wave's best (value, action) -> best / action_out of env b: a butterfly keeps the largest value, lowest index on ties
+// (= the first strict maximum of the reference's loop; NaN and -inf never win: `value > max_value` is false)
+__device__ __forceinline__ void sarl_pick_env(const SarlCfg& C, const double2* pos, const double2* goal, const double2* rv,
+                                              const double* actions, int* best, double* action_out, int b, int lane, double bv,
+                                              int bi) {
 #pragma unroll
     for (int off = kWaveSize / 2; off > 0; off >>= 1) {
         const double ov = __shfl_xor(bv, off);
@@ -1317,6 +1322,360 @@ __global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2*
     best[b] = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
     action_out[2 * b] = arg >= 0 ? actions[2 * arg] : 0.0;
     action_out[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
+}
+__device__ __forceinline__ void sarl_select_env(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
+                                                const double2* rv, const double* gtime, const double* theta,
+                                                const double* actions, double* reward, const float* V, double* values,
+                                                int* best, double* action_out, int b, int lane) {
+    // one wave per env: lanes stride over the actions
+    double bv = -__builtin_inf();
+    int bi = -1;
+    for (int a = lane; a < C.n_actions; a += kWaveSize) {
+        const double r = sarl_reward_of(C, pos, vel, goal, rv, gtime, theta, actions, b, a);  // onestep_lookahead's reward
+        reward[(size_t)b * C.n_actions + a] = r;                                              // (kept for cn_sarl_export)
+        const double v = r + C.gamma_bar * (double)V[(size_t)b * C.n_actions + a];
+        if (values) values[(size_t)b * C.n_actions + a] = v;
+        if (v > bv) {
+            bv = v;
+            bi = a;
+        }
+    }
+    sarl_pick_env(C, pos, goal, rv, actions, best, action_out, b, lane, bv, bi);
+}
+__global__ void sarl_select_kernel(SarlCfg C, const double2* pos, const double2* vel, const double2* goal, const double2* rv,
+                                   const double* gtime, const double* theta, const double* actions, double* reward,
+                                   const float* V, double* values, int* best, double* action_out) {
+    const int b = blockIdx.x * (blockDim.x / kWaveSize) + (threadIdx.x / kWaveSize);
+    if (b >= C.B) return;
+    sarl_select_env(C, pos, vel, goal, rv, gtime, theta, actions, reward, V, values, best, action_out, b,
+                    threadIdx.x & (kWaveSize - 1));
+}
+
+
+// cn_sarl_sample_step outside the narrow route: the previous step's episode ends leave the set of sampling envs
+__global__ void sarl_alive_kernel(int B, uint8_t* alive, const uint8_t* done) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && done[b]) alive[b] = 0;
+}
+
+// What cn_sarl_sample_step adds behind the network (counter == nullptr: nothing).
+struct SarlDecide {
+    int* counter;        // workgroups that have written their V (zero between launches)
+    double epsilon;
+    uint8_t* alive;      // [B] in/out
+    const uint8_t* done; // [B] the previous step's episode-end flags
+    int32_t* best;       // [B]
+    double* action;      // [B][2]
+    float* state_out;    // [B][H][in_dim] at env_stride floats between envs (may be null)
+    int64_t env_stride;
+    int sort_humans, in_dim;
+    double* reward;      // [B][K]
+    double* value;       // [B][K] reward + gamma^(dt v_pref) V, written by the tile that computed V
+    const double* gtime; // [B]
+    uint32_t* mt_key;
+    int* mt_pos;
+    int* error;
+};
+// The same network for a FEW decisions (the single-episode sampling of train.py:156-170: one env, 81 groups = 6 tiles): the
+// one-tile kernels above put a decision on 6 of 256 CUs for ~40 us.  Here a tile is ONE 16-row MFMA tile holding
+// 16 / H whole groups — row r = (group r / H, human r % H), 3 groups x 5 humans + 1 idle row at the shipped size — so one
+// decision spreads over 27 workgroups, each with a fifth of the matrix work behind the same chain of layers.  X is built in
+// LDS by the workgroup that consumes it (sarl_feature_row: no feature kernel, nothing materialised); the mean over a group's
+// humans, the softmax and the weighted feature sum run over ROWS of the tile instead of over row tiles, in the order and
+// with the partial-sum slicing of sarl_mlp_pipe_kernel / dense_vec1<H>, so V is bit-identical to that kernel's.
+// With one row tile a k-step is ONE MFMA, so a layer is bound by the latency of its weights, not by the matrix pipe: a wave
+// holds the B fragments of a whole column tile in registers (up to kNarrowK k-steps, 8 waves x 256 VGPRs) and requests the
+// NEXT layer's before it starts this layer's MFMAs — one L2 round trip per layer, hidden behind the previous layer, instead
+// of one per five k-steps.  No `mixed` rule (every group has H humans), no occupancy maps, H <= 8.
+constexpr int kNarrowWaves = 8, kNarrowThreads = kNarrowWaves * 64;
+constexpr int kNarrowK = 40;  // k-steps of a column tile held in registers (K = 150 is 38 -> kpad 40); longer layers loop on
+struct BTile {
+    float b[kNarrowK];
+    float bias;
+};
+__device__ __forceinline__ BTile narrow_fetch(const PackedLinear& P, int ct, int lane) {
+    BTile t;
+    const bool mine = ct < P.ctiles;  // (wave-uniform: a wave without a column tile of this layer requests nothing)
+    const int c = mine ? ct : 0;
+    const gfloat_p w = as_global(P.w) + (size_t)c * P.kpad * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < kNarrowK / kSarlKChunk; ++g) {
+        if (mine && g * kSarlKChunk < P.kpad) {
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j) t.b[g * kSarlKChunk + j] = w[(g * kSarlKChunk + j) * 64];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSarlKChunk; ++j) t.b[g * kSarlKChunk + j] = 0.0f;
+        }
+    }
+    t.bias = mine ? as_global(P.bias)[c * 16 + (lane & 15)] : 0.0f;
+    return t;
+}
+// out[r][n] = act(bias[n] + extra[r][n] + sum_k in[r][k] W[n][k]) for the 16 rows of the tile: dense_mfma<1>'s arithmetic
+// (k-steps in order into one accumulator from zero, bias + extra added last).  `first` = the fragments of column tile `wave`.
+// The k loop is straight-line code of G x 5 k-steps, G = 3 / 5 / 8 by the layer's length (fragments past kpad are zero in
+// registers and meet finite LDS words: + 0.0f), so that the A reads from LDS and the MFMAs pipeline without a branch between.
+template <int G>
+__device__ __forceinline__ f32x4 narrow_k_loop(const float* afrag, const BTile& t) {
+    float a[G * kSarlKChunk];
+#pragma unroll
+    for (int k = 0; k < G * kSarlKChunk; ++k) a[k] = afrag[k * 64];
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < G * kSarlKChunk; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], t.b[k], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void dense_narrow(const PackedLinear& P, const float* in, float* out, bool relu, const float* extra,
+                                             int wave, int lane, const BTile& first) {
+    const int col = lane & 15, quad = lane >> 4;
+    BTile t = first;
+    for (int ct = wave; ct < P.ctiles; ct += kNarrowWaves) {
+        const bool more = ct + kNarrowWaves < P.ctiles;  // (150-wide layers: ten column tiles on eight waves)
+        BTile t2;
+        if (more) t2 = narrow_fetch(P, ct + kNarrowWaves, lane);
+        const int frag_off = ((ct * 4 + (col >> 2)) * 64) + (col & 3) * 16 + quad * 4;
+        f32x4 addend = {t.bias, t.bias, t.bias, t.bias};
+        if (extra) addend += *reinterpret_cast<const f32x4*>(extra + frag_off);
+        const float* afrag = in + lane;
+        f32x4 acc;
+        if (P.kpad <= 3 * kSarlKChunk) acc = narrow_k_loop<3>(afrag, t);
+        else if (P.kpad <= 5 * kSarlKChunk) acc = narrow_k_loop<5>(afrag, t);
+        else acc = narrow_k_loop<kNarrowK / kSarlKChunk>(afrag, t);
+        if (P.kpad > kNarrowK) {  // wider than the shipped layers: the rest of the k loop straight from L2
+            const gfloat_p w = as_global(P.w) + (size_t)ct * P.kpad * 64 + lane;
+            for (int k = kNarrowK; k < P.kpad; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[k * 64], w[k * 64], acc, 0, 0, 0);
+        }
+        f32x4 v = acc + addend;
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + frag_off) = v;
+        if (more) t = t2;
+    }
+}
+
+// The decision behind the network (cn_sarl_sample_step), by the last workgroup of sarl_narrow_kernel: one wave per env.  Not
+// inlined: its float64 reward / rotation code (registers, the libm's private arrays) stays out of the network's allocation.
+__device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel,
+                                           const double2* goal, const double2* rv, const double* theta, int wave, int lane,
+                                           const double* actions) {
+    for (int b = wave; b < C.B; b += kNarrowWaves) {
+        double bv = -__builtin_inf();
+        int bi = -1;
+        for (int a = lane; a < C.n_actions; a += kWaveSize) {
+            const double v = D.value[(size_t)b * C.n_actions + a];
+            if (v > bv) {
+                bv = v;
+                bi = a;
+            }
+        }
+        sarl_pick_env(C, pos, goal, rv, actions, D.best, D.action, b, lane, bv, bi);
+        if (lane == 0) {
+            // alive: envs still sampling.  The episode-end flags of the PREVIOUS step are folded in here (explorer.py:56-65's
+            // `while not done` per env) rather than by a kernel of their own behind cn_step.
+            const bool keep = D.alive[b] && !(D.done && D.done[b]);
+            D.alive[b] = keep ? 1 : 0;
+            sarl_explore_env(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, actions, !keep, D.best, D.action, nullptr, D.error, b);
+        }
+        if (D.state_out && lane < C.H)
+            sarl_transform_row(C, D.in_dim, D.sort_humans, pos, vel, goal, rv, theta, D.state_out, D.env_stride, b, lane);
+    }
+}
+// onestep_lookahead's reward of one (env, action) group, for the tile that holds it (not inlined: float64, the libm's arrays)
+__device__ __noinline__ double narrow_reward(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
+                                             const double2* rv, const double* gtime, const double* theta, const double* actions,
+                                             int b, int a) {
+    return sarl_reward_of(C, pos, vel, goal, rv, gtime, theta, actions, b, a);
+}
+
+__global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef net, SarlCfg C, const double2* pos, const double2* vel,
+                                                                     const double2* goal, const double2* rv, const double* theta,
+                                                                     const double* actions, const float* orca_vel, double* next_obs,
+                                                                     float* V, SarlDecide D) {
+    extern __shared__ float lds[];
+    float* xs = lds;                          // [ks_x][64]  X of the tile
+    float* bufA = xs + net.ks_x * 64;         // [ks_a][64]  wide hidden layers
+    float* bufB = bufA + net.ks_a * 64;       // [ks_b][64]  mlp1 output (h2), then attention.2
+    float* bufC = bufB + net.ks_b * 64;       // [ks_c][64]  mlp2 output (per-human feature)
+    float* gbuf = bufC + net.ks_c * 64;       // [ks_b][64]  per row: the mean of h2 over the humans of the row's group
+    float* jbuf = gbuf + net.ks_b * 64;       // [ks_a][64]  joint state (row = group) / value-head ping
+    float* kbuf = jbuf + net.ks_a * 64;       // [ks_a][64]  global attention term
+    float* mbuf = kbuf + net.ks_a * 64;       // [ks_a][64]  value-head pong
+    float* sbuf = mbuf + net.ks_a * 64;       // [64]        attention scores -> weights (row r at word r)
+    float* vbuf = sbuf + 64;                  // [kSarlThreads] partial sums of attention.4
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int H = C.H, GT = kSarlGroups / H, rows = GT * H;
+    const int n_groups = C.B * C.n_actions;
+    const size_t tile = blockIdx.x;
+    const SarlNetRef* n = &net;
+    CN_SARL_CLOCK_BEGIN();
+    BTile cur = narrow_fetch(layer_of(*n, kL_mlp1_0), wave, lane);
+    // every word of LDS starts finite (k padding meets zero weights); meanwhile the tile's rows of X in registers
+    {
+        f32x4* z = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < (int)(vbuf - lds) / 4; i += kNarrowThreads) z[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    double my_reward = 0.0;
+    const bool head_lane = wave == kNarrowWaves - 1 && lane < GT && tile * GT + lane < (size_t)n_groups;
+    float f[13];
+    bool row_valid = false;
+    if (tid < rows) {
+        const int g = tid / H, h = tid - g * H;
+        const size_t G = tile * GT + g;
+        row_valid = G < (size_t)n_groups;
+        if (row_valid)
+            sarl_feature_row(C, (int)(G / C.n_actions), (int)(G % C.n_actions), h, pos, goal, rv, theta, actions, next_obs, vel,
+                             orca_vel, f);
+    }
+    lds_barrier();
+    CN_SARL_TICK(0);
+    if (row_valid) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) xs[(k >> 2) * 64 + (k & 3) * 16 + tid] = f[k];
+    }
+    BTile nxt = narrow_fetch(layer_of(*n, kL_mlp1_2), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(1);
+    // self_state = state[:, 0, :6] (sarl.py:36): the first human's row of the group
+    float self_val = 0.0f;
+    const int sg = tid & 15, sf = tid >> 4;
+    if (tid < kSarlGroups * 6 && sg < GT) self_val = xs[(sf >> 2) * 64 + (sf & 3) * 16 + sg * H];
+    dense_narrow(layer_of(*n, kL_mlp1_0), xs, bufA, true, nullptr, wave, lane, cur);
+    cur = narrow_fetch(layer_of(*n, kL_mlp2_0), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(2);
+    dense_narrow(layer_of(*n, kL_mlp1_2), bufA, bufB, true, nullptr, wave, lane, nxt);  // h2
+    // cn_sarl_sample_step: the reward of the tile's groups on the lanes that will hold their V — the value head's wave, which
+    // has no column tile of the 100-wide layers: this float64 chain runs beside mlp1.2's MFMAs.  The decision behind the
+    // network then only compares reward + gamma V.
+    if (D.counter && head_lane) {
+        const size_t G = tile * GT + lane;
+        my_reward = narrow_reward(C, pos, vel, goal, rv, D.gtime, theta, actions, (int)(G / C.n_actions), (int)(G % C.n_actions));
+        D.reward[G] = my_reward;
+    }
+    nxt = narrow_fetch(layer_of(*n, kL_mlp2_2), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(3);
+    if (n->with_global) {
+        for (int i = tid; i < n->ks_b * 64; i += kNarrowThreads) {
+            const int r = i & 15, first = (i & ~15) + (r / H) * H;
+            float sum = 0.0f;
+            for (int h = 0; h < H; ++h) sum += bufB[first + h];
+            gbuf[i] = r < rows ? sum / (float)H : 0.0f;  // (row 15 of 3 x 5: reads past the tile's rows, result unused)
+        }
+    }
+    dense_narrow(layer_of(*n, kL_mlp2_0), bufB, bufA, true, nullptr, wave, lane, cur);
+    cur = narrow_fetch(layer_of(*n, kL_att0_global), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(4);
+    dense_narrow(layer_of(*n, kL_mlp2_2), bufA, bufC, false, nullptr, wave, lane, nxt);  // features
+    nxt = narrow_fetch(layer_of(*n, kL_att0_local), wave, lane);
+    if (n->with_global) dense_narrow(layer_of(*n, kL_att0_global), gbuf, kbuf, false, nullptr, wave, lane, cur);
+    cur = narrow_fetch(layer_of(*n, kL_att_2), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(5);
+    dense_narrow(layer_of(*n, kL_att0_local), bufB, bufA, true, n->with_global ? kbuf : nullptr, wave, lane, nxt);
+    nxt = narrow_fetch(layer_of(*n, kL_mlp3_0), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(6);
+    dense_narrow(layer_of(*n, kL_att_2), bufA, bufB, true, nullptr, wave, lane, cur);
+    cur = narrow_fetch(layer_of(*n, kL_mlp3_2), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(7);
+    {   // attention.4 (one output) as dense_vec1<H> slices it: kSarlThreads / (16 H) k slices per row, summed in slice order
+        const PackedLinear P = layer_of(*n, kL_att_4);
+        const int slices = kSarlThreads / (H * 16);
+        for (int i = tid; i < slices * 16; i += kNarrowThreads) {
+            const int row = i & 15, slice = i >> 4;
+            float sum = 0.0f;
+            for (int s = slice; s < P.ksteps; s += slices) {
+                const gfloat_p w = as_global(P.w) + s * 64;
+                const float* x = bufB + s * 64 + row;
+                sum += (x[0] * w[0] + x[16] * w[16]) + (x[32] * w[32] + x[48] * w[48]);
+            }
+            vbuf[slice * 16 + row] = sum;
+        }
+        lds_barrier();
+        CN_SARL_TICK(8);
+        if (wave == 0) {  // lane = row: its score, then the softmax without max subtraction over the group's humans (sarl.py:52-53)
+            const int r = lane & 15;
+            float v = as_global(P.bias)[0];
+            for (int s = 0; s < slices; ++s) v += vbuf[s * 16 + r];
+            const float e = expf(v) * (v != 0.0f ? 1.0f : 0.0f);
+            const int g0 = (r / H) * H;
+            float total = 0.0f;
+            for (int h = 0; h < H; ++h) total += __shfl(e, (g0 + h) & 15);  // (row 15 of 3 x 5 wraps: unused)
+            if (lane < 16) sbuf[lane] = e / total;
+        }
+    }
+    lds_barrier();
+    CN_SARL_TICK(9);
+    // the joint state, row = group: self features, weighted feature sum (sarl.py:60); everything else of jbuf is zero
+    if (tid < kSarlGroups * 6 && sg < GT) jbuf[(sf >> 2) * 64 + (sf & 3) * 16 + sg] = self_val;
+    const int nf = n->nf;
+    for (int i = tid; i < kSarlGroups * nf; i += kNarrowThreads) {
+        const int g = i & 15, c = i >> 4;
+        if (g >= GT) continue;
+        const int src = (c >> 2) * 64 + (c & 3) * 16 + g * H;
+        float sum = 0.0f;
+        for (int h = 0; h < H; ++h) sum += sbuf[g * H + h] * bufC[src + h];
+        const int f = 6 + c;
+        jbuf[(f >> 2) * 64 + (f & 3) * 16 + g] = sum;
+    }
+    lds_barrier();
+    CN_SARL_TICK(10);
+    dense_narrow(layer_of(*n, kL_mlp3_0), jbuf, mbuf, true, nullptr, wave, lane, nxt);
+    nxt = narrow_fetch(layer_of(*n, kL_mlp3_4), wave, lane);
+    lds_barrier();
+    CN_SARL_TICK(11);
+    dense_narrow(layer_of(*n, kL_mlp3_2), mbuf, jbuf, true, nullptr, wave, lane, cur);
+    lds_barrier();
+    CN_SARL_TICK(12);
+    dense_narrow(layer_of(*n, kL_mlp3_4), jbuf, mbuf, true, nullptr, wave, lane, nxt);
+    lds_barrier();
+    CN_SARL_TICK(13);
+    int arrived = 0;
+    if (wave == kNarrowWaves - 1) {  // mlp3.6 as value_head_on_one_wave: 4 k slices of the 16 rows, summed in slice order
+        const PackedLinear P = layer_of(*n, kL_mlp3_6);
+        const int row = lane & 15, slice = lane >> 4;
+        float sum = 0.0f;
+        for (int s = slice; s < P.ksteps; s += 4) {
+            const gfloat_p w = as_global(P.w) + s * 64;
+            const float* x = mbuf + s * 64 + row;
+            sum += (x[0] * w[0] + x[16] * w[16]) + (x[32] * w[32] + x[48] * w[48]);
+        }
+        float v = as_global(P.bias)[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += __shfl(sum, row + 16 * j);
+        if (head_lane) {
+            const size_t G = tile * GT + lane;
+            V[G] = v;
+            if (D.counter) D.value[G] = my_reward + C.gamma_bar * (double)v;  // multi_human_rl.py:52, as sarl_select_env
+        }
+        if (D.counter) {
+            __threadfence();  // this tile's values, device-wide, before it counts as arrived
+            if (lane == 0) arrived = atomicAdd(D.counter, 1) + 1;
+        }
+    }
+    CN_SARL_TICK(14);
+    CN_SARL_CLOCK_END();
+    if (!D.counter) return;  // cn_sarl_select: the network only
+    // ---- cn_sarl_sample_step: the workgroup that finishes LAST decides for every env, one wave per env — arg-max of reward +
+    // gamma V, the epsilon-greedy draw on the env's own stream (sarl_explore_env), the joint state for the replay memory
+    // (sarl_transform_row) — instead of three more launches behind this one.
+    int* last = reinterpret_cast<int*>(sbuf);
+    if (wave == kNarrowWaves - 1 && lane == 0) {
+        *last = arrived == (int)gridDim.x ? 1 : 0;
+        if (*last) atomicExch(D.counter, 0);  // ready for the next launch
+    }
+    __syncthreads();
+    if (!*last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    narrow_decide(C, D, pos, vel, goal, rv, theta, wave, lane, actions);
+}
+__host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net) {
+    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads);
 }
 
 }  // namespace cn

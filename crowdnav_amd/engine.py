@@ -416,11 +416,11 @@ def _sarl_transform(self, out=None, env_stride=0, sort_humans=None):
 
 
 def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
-    """The train-phase decision + step of every env as ONE Python call per step: step(t, epsilon) runs
-    cn_sarl_select -> cn_sarl_explore (mask = alive) -> cn_sarl_transform -> cn_step with row t of the caller's histories
-    (traj [B, T, H, D] float32; rew / dmin [T, B] float64; info [T, B] uint8; act [T, B] int32: the chosen action index) as
-    outputs, addresses precomputed — the four wrappers above cost ~45 us of Python per step between them (tensor views,
-    pointer objects, checks), as much as the step costs the device at one env."""
+    """The train-phase decision + step of every env as ONE call per step: step(t, epsilon) is cn_sarl_sample_step —
+    alive &= ~done (the previous step's episode ends; zero `done` before an episode's first step), then cn_sarl_select ->
+    cn_sarl_explore (mask = alive) -> cn_sarl_transform -> cn_step — with row t of the caller's histories (traj [B, T, H, D]
+    float32; rew / dmin [T, B] float64; info [T, B] uint8; act [T, B] int32: the chosen action index) as outputs, addresses
+    precomputed.  For a few envs the library runs it in three launches (include/crowdnav_amd.h)."""
     B, T, H, D = traj.shape
     if B != self.B or H != self.H:
         raise ValueError('traj is [%d, T, %d, D]; the engine holds %d envs x %d humans' % (B, H, self.B, self.H))
@@ -446,11 +446,8 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
         eng = alive_engine()
         if eng is None or eng._h is not h or not h.value:
             raise RuntimeError('sarl_sampler: the engine has been closed')
-        best = V(p_act + 4 * B * t)
-        check(lib.cn_sarl_select(h, None, best, p_action))
-        check(lib.cn_sarl_explore(h, epsilon, p_alive, best, p_action, None))
-        check(lib.cn_sarl_transform(h, V(p_traj + 4 * H * D * t), stride, sort))
-        check(lib.cn_step(h, p_action, 1, V(p_rew + 8 * B * t), p_done, V(p_inf + B * t), V(p_dmn + 8 * B * t), None, None, None))
+        check(lib.cn_sarl_sample_step(h, epsilon, p_alive, V(p_act + 4 * B * t), p_action, V(p_traj + 4 * H * D * t), stride, sort,
+                                      V(p_rew + 8 * B * t), p_done, V(p_inf + B * t), V(p_dmn + 8 * B * t)))
     step.keep = keep  # the tensors live as long as the step function does
     return step
 

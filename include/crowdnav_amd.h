@@ -324,6 +324,23 @@ int cn_sarl_explore(cn_engine* e, double epsilon, const uint8_t* mask, int32_t* 
  * LstmRL.predict re-orders them before it stores last_state (lstm_rl.py:96-103; stable for equal distances) — the RL
  * phase; 0 = env order, which is what imitation learning stores (explorer.py:99 transforms the ORCA robot's own state). */
 int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_humans);
+/* (ABI v8) replaces ONE iteration of the train-phase sampling loop, Explorer.run_k_episodes' `while not done: action =
+ * robot.act(ob); ob, reward, done, info = env.step(action)` (explorer.py:56-65) with MultiHumanRL.predict behind robot.act
+ * (multi_human_rl.py:11-63) — for every env, in this order and with these results:
+ *   alive[b] &= !done[b]                              (the previous call's episode ends: an env samples until its episode is over;
+ *                                                      the caller zeroes done before an episode's first call)
+ *   cn_sarl_select(e, NULL, best, action)
+ *   cn_sarl_explore(e, epsilon, alive, best, action, NULL)
+ *   cn_sarl_transform(e, state_out, env_stride, sort_humans)      (state_out == NULL: skipped)
+ *   cn_step(e, action, 1, reward, done, info, dmin, NULL, NULL, NULL)
+ * as one call.  For a FEW envs without occupancy maps (CN_MODEL_SARL, up to 8 humans, not the `mixed` rule, at most two
+ * workgroups per CU: 18 envs of 5 humans x 81 actions — BASELINE configs[4]'s one episode at a time, train.py:156-170) that is
+ * three launches instead of eight: ORCA for the humans' next velocities; the value network on tiles of 16 / num_humans whole
+ * (env, action) groups, one per workgroup — a decision spread over 27 CUs instead of 6, its input rows built in LDS — whose
+ * last workgroup takes the arg-max, draws epsilon-greedy and writes the replay-memory state; the transition.  Same bits as
+ * the five calls above in either case (tests/test_rl_pipeline.py).  CROWDNAV_AMD_SARL_NARROW=0 keeps the one-tile kernels. */
+int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
+                        int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin);
 /* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):
  *   0 reward f64 [B][K] · 1 V f32 [B*K] · 2 next human states f64 [B][H][5] · 3 occupancy maps f32 [B][H][cells*ch]
  *   4 X f32 in MLP tile order (see sarl_kernels.h) */

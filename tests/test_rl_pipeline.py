@@ -186,6 +186,61 @@ def test_transform_matches_host_transform(with_om):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,humans', [(1, 5), (3, 5), (16, 5), (2, 3), (40, 5)])
+def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
+    """cn_sarl_sample_step (ABI v8) = alive &= ~done; cn_sarl_select; cn_sarl_explore(mask = alive); cn_sarl_transform;
+    cn_step.  Three engines on the same seeds and weights for 104 steps (every episode ends, envs leave `alive`, the epsilon-greedy
+    draws continue each env's numpy stream): (a) the one call on the narrow-tile route (three launches; 40 envs are too many
+    for it and take the general route inside the call), (b) the one call with CROWDNAV_AMD_SARL_NARROW=0, (c) the five calls
+    by hand on the one-tile kernels.  Every history is the same bits."""
+    import ctypes as C
+    import crowdnav_amd
+    from crowdnav_amd._lib import check
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(21)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    space, _, _ = build_action_space(1.0)
+    T, D = 104, 13
+
+    def run(narrow, one_call):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=0)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+        eng.sarl_set_weights(net.state_dict())
+        eng.reset(7000 + np.arange(B))
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
+        traj, rew, inf, dmn = z((B, T, humans, D), torch.float32), z((T, B), torch.float64), z((T, B), torch.uint8), z((T, B), torch.float64)
+        act, alive, done, action = z((T, B), torch.int32), z((B,), torch.uint8), z((B,), torch.uint8), z((B, 2), torch.float64)
+        alive.fill_(1)
+        alive_hist = []
+        if one_call:
+            step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
+            for t in range(T):
+                step(t, 0.3)
+                alive_hist.append(alive.clone())
+        else:
+            lib, h, V = eng._lib, eng._h, C.c_void_p
+            for t in range(T):
+                alive.masked_fill_(done.view(torch.bool), 0)
+                best = V(act.data_ptr() + 4 * B * t)
+                check(lib.cn_sarl_select(h, None, best, V(action.data_ptr())))
+                check(lib.cn_sarl_explore(h, 0.3, V(alive.data_ptr()), best, V(action.data_ptr()), None))
+                check(lib.cn_sarl_transform(h, V(traj.data_ptr() + 4 * humans * D * t), T * humans * D, 0))
+                check(lib.cn_step(h, V(action.data_ptr()), 1, V(rew.data_ptr() + 8 * B * t), V(done.data_ptr()), V(inf.data_ptr() + B * t),
+                                  V(dmn.data_ptr() + 8 * B * t), None, None, None))
+                alive_hist.append(alive.clone())
+        eng.sync()
+        out = [x.cpu().numpy() for x in (traj, rew, inf, dmn, act, torch.stack(alive_hist), eng.get_state()[0], action)]
+        eng.close()
+        return out
+
+    a, b, c = run('1', True), run('0', True), run('0', False)
+    assert (a[5][-1] == 0).all() and (a[5][0] == 1).all()   # every episode ended (time_limit / time_step = 100 steps at the latest)
+    for x, y, w in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, w)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', RL_FIXTURES)
 @pytest.mark.parametrize('device_memory', [False, True])
 def test_batched_rl_sampling_reproduces_the_reference_memory(name, device_memory):

@@ -108,6 +108,38 @@ def test_sarl_mlp_vs_torch_fp32_random_inputs(humans, with_om):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans,B', [(5, 1), (5, 3), (5, 16), (1, 2), (2, 3), (3, 2), (4, 5), (8, 2)])
+def test_narrow_tile_value_network_is_bit_identical_to_the_one_tile_kernel(humans, B, monkeypatch):
+    """A few decisions (train.py's single-episode sampling: one env, 81 groups) run sarl_narrow_kernel: tiles of 16 / H whole
+    groups, one per workgroup, X built in LDS.  CROWDNAV_AMD_SARL_NARROW=0 keeps sarl_feature_kernel + sarl_mlp_pipe_kernel on
+    the same engine configuration: V, the chosen actions and the exported X / next states are the same BITS (the narrow kernel
+    sums over a group's humans, slices attention.4 and orders every layer's k loop as the one-tile kernel does), and both are
+    within 2e-5 of the torch module.  81 B groups are never a multiple of the 3 / 4 / 5 / 8 / 16 groups of a narrow tile."""
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(11)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for narrow in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+        eng.reset(5000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[narrow] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), out['action'].cpu().numpy(),
+                       eng.sarl_export('X').cpu(), eng.sarl_export('next_obs').cpu().numpy())
+        eng.close()
+    with torch.no_grad():
+        want = net(got['1'][3].reshape(B * 81, humans, 13)).reshape(B, 81).numpy()
+    assert np.abs(got['1'][0] - want).max() <= 2e-5
+    for a, b in zip(got['1'], got['0']):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True, 'maps inside the kernel'])
 def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
     """5 humans at the shipped widths run sarl_reg_kernel (activations in registers); CROWDNAV_AMD_SARL_REG=0 keeps the LDS
