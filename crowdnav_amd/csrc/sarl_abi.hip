@@ -273,8 +273,9 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
     s->n_groups = (size_t)C.B * C.n_actions;
     s->n_tiles = (s->n_groups + cn::kSarlGroups - 1) / cn::kSarlGroups;
     // Few decisions: 16-row tiles of whole groups, one per workgroup, X built in the kernel (sarl_narrow_kernel) — while the
-    // whole launch is at most two workgroups per CU; beyond that the one-tile kernel's 16-group tiles do ~1.5 x less matrix
-    // work per group.  CROWDNAV_AMD_SARL_NARROW: 0 never, 1 (default) by size, 2 whenever the configuration allows it.
+    // whole launch is at most one workgroup per CU (measured, a sampled step of 5 humans x 81 actions: 8 envs 53 us against
+    // 73 us on the one-tile kernels, 16 envs 90 against 74: 16-group tiles do ~1.5 x less matrix work per group).
+    // CROWDNAV_AMD_SARL_NARROW: 0 never, 1 (default) by size, 2 whenever the configuration allows it.
     {
         const int narrow_mode = env_int("CROWDNAV_AMD_SARL_NARROW", 1);
         const size_t per_tile = (size_t)(cn::kSarlGroups / (H < 1 ? 1 : H));
@@ -282,7 +283,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
         s->narrow = !cadrl && !lstm && !s->chunked && !s->reg_mlp && in_dim == 13 && !C.sort_lookahead && H >= 1 &&
                     H <= cn::kSarlMaxHumans && e->cfg.scenario_rule != CN_MIXED && s->narrow_lds <= 160 * 1024 &&
-                    (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)2 * s->n_cus));
+                    (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)s->n_cus));
     }
     const size_t nA = (size_t)C.B * (H + 1);
     if ((rc = dev_alloc(e, &s->actions, (size_t)2 * C.n_actions)) || (rc = dev_alloc(e, &s->orca_vel, 2 * nA)) ||

@@ -1457,14 +1457,13 @@ __device__ __forceinline__ void dense_narrow(const PackedLinear& P, const float*
 
 // The decision behind the network (cn_sarl_sample_step), by the last workgroup of sarl_narrow_kernel: one wave per env.  Not
 // inlined: its float64 reward / rotation code (registers, the libm's private arrays) stays out of the network's allocation.
-__device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel,
-                                           const double2* goal, const double2* rv, const double* theta, int wave, int lane,
-                                           const double* actions) {
+__device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* goal,
+                                           const double2* rv, int wave, int lane, const double* actions) {
     for (int b = wave; b < C.B; b += kNarrowWaves) {
         double bv = -__builtin_inf();
         int bi = -1;
         for (int a = lane; a < C.n_actions; a += kWaveSize) {
-            const double v = D.value[(size_t)b * C.n_actions + a];
+            const double v = __hip_atomic_load(&D.value[(size_t)b * C.n_actions + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v > bv) {
                 bv = v;
                 bi = a;
@@ -1478,9 +1477,12 @@ __device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D
             D.alive[b] = keep ? 1 : 0;
             sarl_explore_env(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, actions, !keep, D.best, D.action, nullptr, D.error, b);
         }
-        if (D.state_out && lane < C.H)
-            sarl_transform_row(C, D.in_dim, D.sort_humans, pos, vel, goal, rv, theta, D.state_out, D.env_stride, b, lane);
     }
+}
+// The joint state of env b for the replay memory (sarl_transform_row), on the idle wave of tile b
+__device__ __noinline__ void narrow_transform(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel,
+                                              const double2* goal, const double2* rv, const double* theta, int b, int h) {
+    sarl_transform_row(C, D.in_dim, D.sort_humans, pos, vel, goal, rv, theta, D.state_out, D.env_stride, b, h);
 }
 // onestep_lookahead's reward of one (env, action) group, for the tile that holds it (not inlined: float64, the libm's arrays)
 __device__ __noinline__ double narrow_reward(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
@@ -1566,6 +1568,9 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         }
     }
     dense_narrow(layer_of(*n, kL_mlp2_0), bufB, bufA, true, nullptr, wave, lane, cur);
+    // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network)
+    if (D.counter && D.state_out && wave == kNarrowWaves - 1 && tile < (size_t)C.B && lane < H)
+        narrow_transform(C, D, pos, vel, goal, rv, theta, (int)tile, lane);
     cur = narrow_fetch(layer_of(*n, kL_att0_global), wave, lane);
     lds_barrier();
     CN_SARL_TICK(4);
@@ -1651,10 +1656,13 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         if (head_lane) {
             const size_t G = tile * GT + lane;
             V[G] = v;
-            if (D.counter) D.value[G] = my_reward + C.gamma_bar * (double)v;  // multi_human_rl.py:52, as sarl_select_env
+            // multi_human_rl.py:52, as sarl_select_env.  An agent-scope atomic store: written through to where every XCD's
+            // agent-scope load finds it — no write-back of this XCD's whole L2 (a release fence) for 3 doubles
+            if (D.counter)
+                __hip_atomic_store(&D.value[G], my_reward + C.gamma_bar * (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (D.counter) {
-            __threadfence();  // this tile's values, device-wide, before it counts as arrived
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the stores above have been acknowledged before the tile counts as arrived
             if (lane == 0) arrived = atomicAdd(D.counter, 1) + 1;
         }
     }
@@ -1662,8 +1670,8 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     CN_SARL_CLOCK_END();
     if (!D.counter) return;  // cn_sarl_select: the network only
     // ---- cn_sarl_sample_step: the workgroup that finishes LAST decides for every env, one wave per env — arg-max of reward +
-    // gamma V, the epsilon-greedy draw on the env's own stream (sarl_explore_env), the joint state for the replay memory
-    // (sarl_transform_row) — instead of three more launches behind this one.
+    // gamma V, the epsilon-greedy draw on the env's own stream (sarl_explore_env) — instead of three more launches behind this
+    // one (the joint state for the replay memory was written by tile b meanwhile).
     int* last = reinterpret_cast<int*>(sbuf);
     if (wave == kNarrowWaves - 1 && lane == 0) {
         *last = arrived == (int)gridDim.x ? 1 : 0;
@@ -1671,8 +1679,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     }
     __syncthreads();
     if (!*last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    narrow_decide(C, D, pos, vel, goal, rv, theta, wave, lane, actions);
+    narrow_decide(C, D, pos, goal, rv, wave, lane, actions);
 }
 __host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net) {
     return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads);

@@ -190,9 +190,10 @@ def test_transform_matches_host_transform(with_om):
 def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
     """cn_sarl_sample_step (ABI v8) = alive &= ~done; cn_sarl_select; cn_sarl_explore(mask = alive); cn_sarl_transform;
     cn_step.  Three engines on the same seeds and weights for 104 steps (every episode ends, envs leave `alive`, the epsilon-greedy
-    draws continue each env's numpy stream): (a) the one call on the narrow-tile route (three launches; 40 envs are too many
-    for it and take the general route inside the call), (b) the one call with CROWDNAV_AMD_SARL_NARROW=0, (c) the five calls
-    by hand on the one-tile kernels.  Every history is the same bits."""
+    draws continue each env's numpy stream): (a) the one call on the narrow-tile route (three launches; forced with
+    CROWDNAV_AMD_SARL_NARROW=2: by size it is taken up to one workgroup per CU, 9 envs of 5 humans; 40 envs are 1080 tiles and
+    five envs per wave of the deciding workgroup), (b) the one call with CROWDNAV_AMD_SARL_NARROW=0 (the general route inside
+    the call), (c) the five calls by hand on the one-tile kernels.  Every history is the same bits."""
     import ctypes as C
     import crowdnav_amd
     from crowdnav_amd._lib import check
@@ -234,7 +235,7 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
         eng.close()
         return out
 
-    a, b, c = run('1', True), run('0', True), run('0', False)
+    a, b, c = run('2', True), run('0', True), run('0', False)
     assert (a[5][-1] == 0).all() and (a[5][0] == 1).all()   # every episode ended (time_limit / time_step = 100 steps at the latest)
     for x, y, w in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, w)
