@@ -427,6 +427,53 @@ def measure_policy_decision(B, H, policy, local_rank, iters=20):
                          'note': 'algorithmic flops (unpadded layer widths) over the HIP-event time of cn_sarl_select'}}
 
 
+def measure_sample_step(local_rank, envs=1, steps=100, repeats=5):
+    """BASELINE configs[4]'s in-scope piece: one train-phase sampling step (train.py:156-170 -> explorer.py:56-65 with
+    multi_human_rl.py:11-63 behind robot.act) of ONE env — cn_sarl_sample_step streamed `steps` times without a host check,
+    HIP events around the stream, the median of `repeats` episodes.  SARL at the shipped widths, 5 humans, 81 actions, random-init
+    weights, epsilon 0.1."""
+    import numpy as np
+    import torch
+    import crowdnav_amd
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=envs, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=0,
+                                       device=local_rank)
+    torch.manual_seed(0)
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    space, _, _ = build_action_space(1.0)
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+    eng.sarl_set_weights(net.state_dict())
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
+    traj, rew, inf, dmn = (z((envs, steps, 5, 13), torch.float32), z((steps, envs), torch.float64), z((steps, envs), torch.uint8),
+                           z((steps, envs), torch.float64))
+    act, alive, done, action = z((steps, envs), torch.int32), z((envs,), torch.uint8), z((envs,), torch.uint8), z((envs, 2), torch.float64)
+    step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
+    times = []
+    for rep in range(repeats + 1):  # (the first episode warms up)
+        eng.reset(2000 + rep * envs + np.arange(envs))
+        alive.fill_(1)
+        done.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        with no_gc():
+            a.record()
+            for t in range(steps):
+                step(t, 0.1)
+            b.record()
+            torch.cuda.synchronize()
+        times.append(a.elapsed_time(b) / 1e3 / steps)
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    per_step = sorted(times[1:])[len(times[1:]) // 2]
+    return {'workload': '%d env x 5 humans, 81 actions, SARL: cn_sarl_sample_step (decision + epsilon-greedy + replay state + '
+                        'transition), %d steps streamed' % (envs, steps),
+            'value': envs / per_step, 'unit': 'env-steps/s', 'us_per_step': per_step * 1e6,
+            'launches_per_step': 3, 'kernels': 'cn::orca_kernel, cn::sarl_narrow_kernel, cn::step_kernel',
+            'note': 'round 4: ten launches, 70-80 us per step; the reference schedule of configs[4] samples 10 000 episodes this way '
+                    '(profiles/r05_config5_reference_schedule.json: 45.5 s of RL sampling, weight re-pack / reset / read-back included)'}
+
+
 def secondary(B, local_rank):
     """BASELINE configs[2] (SARL / OM-SARL value-network rollouts) and configs[3] (20 humans) measured in the SAME run as
     the headline, after its timed region, so that the driver's record carries them."""
@@ -439,6 +486,7 @@ def secondary(B, local_rank):
     for policy in ('cadrl', 'lstm_rl'):
         out[policy] = measure_policy_decision(B, 5, policy, local_rank)
     out['h20'] = measure_h20(B, local_rank)
+    out['sample_step'] = measure_sample_step(local_rank)
     return out
 
 

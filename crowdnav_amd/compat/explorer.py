@@ -7,6 +7,7 @@ reference would have produced on its i-th env.reset(phase).  Otherwise the refer
 CrowdSim.step (one launch per transition)."""
 import copy
 import logging
+import os
 
 import torch
 
@@ -36,7 +37,54 @@ class Explorer(object):
         self.last_batch = None  # per-episode arrays of the last batched call (for callers that want more)
 
     def update_target_model(self, target_model):
+        """explorer.py:26-27 (copy.deepcopy).  When a target network of the same architecture exists already, its parameters
+        are overwritten in place: the same values, and the captured graph of its forward (_td_values) stays valid."""
+        old = self.target_model
+        if old is not None and type(old) is type(target_model):
+            try:
+                src, dst = target_model.state_dict(), old.state_dict()
+                if src.keys() == dst.keys() and all(src[k].shape == dst[k].shape and src[k].dtype == dst[k].dtype and
+                                                    src[k].device == dst[k].device for k in src):
+                    old.load_state_dict(src)
+                    return
+            except RuntimeError:
+                pass
         self.target_model = copy.deepcopy(target_model)
+        self._td_graph = None
+
+    def _td_values(self, nxt):
+        """target_model(next states) for the TD targets of update_memory (explorer.py:113-116), flat.  On a GPU the forward — some
+        35 tiny kernels for a few dozen rows: launch-bound — is replayed from a hipGraph captured on a fixed number of rows (the
+        rows beyond the call's hold earlier, finite inputs and are not read back).  CROWDNAV_AMD_TD_GRAPH=0: always eager."""
+        model = self.target_model
+        x = nxt.to(next(model.parameters()).device)
+        n = int(x.shape[0])
+        if (not x.is_cuda or n == 0 or getattr(self, '_td_graph_failed', False)
+                or os.environ.get('CROWDNAV_AMD_TD_GRAPH', '1') == '0'):
+            return model(x).reshape(-1)
+        g = getattr(self, '_td_graph', None)
+        key = (id(model), tuple(x.shape[1:]), x.dtype)
+        if g is None or g['key'] != key or g['x'].shape[0] < n:
+            rows = max(128, 2 * n if g is not None and g['key'] == key else n)
+            try:
+                sx = torch.zeros((rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(2):
+                        model(sx)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(graph):
+                    sy = model(sx)
+                g = self._td_graph = dict(key=key, x=sx, y=sy, graph=graph)
+            except Exception as exc:  # noqa: BLE001 - e.g. a layer whose library call cannot be captured: run eagerly from now on
+                logging.warning('TD-target forward: graph capture failed (%s); running eagerly', exc)
+                self._td_graph, self._td_graph_failed = None, True
+                return model(x).reshape(-1)
+        g['x'][:n].copy_(x)
+        g['graph'].replay()
+        return g['y'][:n].reshape(-1).clone()
 
     # ------------------------------------------------------------------ explorer.py:21-90
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
@@ -335,10 +383,15 @@ class Explorer(object):
             hkey = (id(eng), B, max_steps, human_num, D)
             if getattr(self, '_rl_hist', (None,))[0] != hkey:
                 z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
-                self._rl_hist = (hkey, z((B, max_steps, human_num, D), torch.float32), z((max_steps, B), torch.float64),
-                                 z((max_steps, B), torch.uint8), z((max_steps, B), torch.float64), z((max_steps, B), torch.int32),
-                                 z((B,), torch.uint8), z((B,), torch.uint8), z((B, 2), torch.float64))
-            _, traj, rew, inf, dmn, act, alive, done, action = self._rl_hist
+                # reward / min-distance / action / info histories are four regions of ONE byte buffer: one blocking copy
+                # brings all of them to the host (four of them were a tenth of a millisecond per sampled episode)
+                n = max_steps * B
+                packed = z((21 * n,), torch.uint8)
+                rew_, dmn_ = packed[:8 * n].view(torch.float64).view(max_steps, B), packed[8 * n:16 * n].view(torch.float64).view(max_steps, B)
+                act_, inf_ = packed[16 * n:20 * n].view(torch.int32).view(max_steps, B), packed[20 * n:].view(max_steps, B)
+                self._rl_hist = (hkey, z((B, max_steps, human_num, D), torch.float32), rew_, inf_, dmn_, act_,
+                                 z((B,), torch.uint8), z((B,), torch.uint8), z((B, 2), torch.float64), packed)
+            _, traj, rew, inf, dmn, act, alive, done, action, packed = self._rl_hist
             alive.fill_(1)
             done.zero_()
             T = 0
@@ -357,8 +410,9 @@ class Explorer(object):
             lap('steps')
             if prof is not None:
                 prof['n_steps_issued'] = prof.get('n_steps_issued', 0) + T
-            R, I, Dm = rew[:T].cpu().numpy(), inf[:T].cpu().numpy(), dmn[:T].cpu().numpy()
-            Ac = act[:T].cpu().numpy()
+            host, n = packed.cpu().numpy(), max_steps * B
+            R, Dm = host[:8 * n].view(np.float64).reshape(max_steps, B)[:T], host[8 * n:16 * n].view(np.float64).reshape(max_steps, B)[:T]
+            Ac, I = host[16 * n:20 * n].view(np.int32).reshape(max_steps, B)[:T], host[20 * n:].reshape(max_steps, B)[:T]
             terminal = I >= _lib.REACH_GOAL
             if not terminal.any(axis=0).all():
                 raise ValueError('Invalid end signal from environment')
@@ -369,23 +423,36 @@ class Explorer(object):
             last = I[Tb - 1, np.arange(B)]
             keep = np.flatnonzero((last == _lib.REACH_GOAL) | (last == _lib.COLLISION))
             if len(keep):
-                # rows in push order: episode by episode, step by step
-                b_idx = np.repeat(keep, Tb[keep])
-                i_idx = np.concatenate([np.arange(Tb[b]) for b in keep])
-                bt = torch.as_tensor(b_idx, device=eng.device)
-                it = torch.as_tensor(i_idx, device=eng.device)
-                states = traj[bt, it]                                         # [N, H, D]
+                # rows in push order: episode by episode, step by step.  An episode's rows are slices of the histories (no
+                # index tensors to upload, no gathers): states [0, n), next states [1, n] — row n only feeds the value that the
+                # last step replaces by its reward
                 single = policy.net_cfg.get('model') == 'cadrl'      # CADRL.transform: one human, [13]
-                is_last = torch.as_tensor(i_idx == Tb[b_idx] - 1, device=eng.device)
-                nxt = traj[bt, torch.clamp(it + 1, max=max_steps - 1)]
+                ns = [int(Tb[b]) for b in keep]
+                if max(ns) < max_steps:
+                    cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)  # noqa: E731
+                    states = cat([traj[b, :n_] for b, n_ in zip(keep, ns)])               # [N, H, D]
+                    nxt = cat([traj[b, 1:n_ + 1] for b, n_ in zip(keep, ns)])
+                    r = cat([rew[:n_, b] for b, n_ in zip(keep, ns)])
+                    ends = np.cumsum(ns) - 1                                              # the last step of every episode
+                else:  # (an episode as long as the histories: its row n does not exist)
+                    b_idx = np.repeat(keep, Tb[keep])
+                    i_idx = np.concatenate([np.arange(Tb[b]) for b in keep])
+                    bt = torch.as_tensor(b_idx, device=eng.device)
+                    it = torch.as_tensor(i_idx, device=eng.device)
+                    states, nxt = traj[bt, it], traj[bt, torch.clamp(it + 1, max=max_steps - 1)]
+                    r = rew[it, bt]
+                    ends = np.flatnonzero(i_idx == Tb[b_idx] - 1)
                 if single:
                     states, nxt = states[:, 0], nxt[:, 0]
                 with torch.no_grad():
-                    tm_device = next(self.target_model.parameters()).device
-                    v_next = self.target_model(nxt.to(tm_device)).reshape(-1).to(eng.device).double()
-                r = rew[it, bt]
-                values = torch.where(is_last, r, r + gamma_bar * v_next).float()
-                self._push_all(states, values)
+                    v_next = self._td_values(nxt).to(eng.device).double()
+                values = r + gamma_bar * v_next
+                if len(ends) == 1:
+                    values[-1] = r[-1]
+                else:
+                    e_idx = torch.as_tensor(ends, device=eng.device)
+                    values[e_idx] = r[e_idx]
+                self._push_all(states, values.float())
             lap('read-back + TD targets + push')
             for b in range(B):
                 n = int(Tb[b])

@@ -65,6 +65,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
     e->io_valid = false;
     e->steps_since_fill = -1;
     e->sarl = nullptr;
+    e->orca_fresh = false;
     e->async_fill = false;
     e->rollout_done = nullptr;
     e->next_fill_stream = 0;
@@ -225,6 +226,7 @@ int cn_destroy(cn_engine* e) {
 int cn_set_stream(cn_engine* e, void* hip_stream) {
     if (!e) return fail(CN_ERR_INVALID, "engine is NULL");
     e->stream = static_cast<hipStream_t>(hip_stream);
+    e->orca_fresh = false;
     return CN_OK;
 }
 

@@ -64,6 +64,8 @@ struct cn_engine {
     bool io_valid;
     int steps_since_fill;    // transitions launched since the scenario ring was last topped up; < 0 = never filled
     struct cn_sarl* sarl;    // SARL decision state (sarl_abi.hip), NULL until cn_sarl_configure
+    bool orca_fresh;         // cn_sarl_sample_step: the humans' ORCA velocities of the CURRENT state are in sarl->orca_vel (left by the
+                             // previous call's transition kernel); cleared by every other entry point (bind)
     double* discount;
     int discount_len;
     uint32_t* probe_key;
@@ -128,6 +130,7 @@ int dev_alloc(cn_engine* e, T** out, size_t n) {
 
 [[maybe_unused]] int bind(cn_engine* e) {
     if (!e) return fail(CN_ERR_INVALID, "engine is NULL");
+    e->orca_fresh = false;  // whatever this call is, it may change the state those velocities belong to
     CN_HIP(hipSetDevice(e->cfg.device));
     return CN_OK;
 }

@@ -4,6 +4,7 @@
 #include "engine_host.h"
 #include "sarl_kernels.h"
 #include "sarl_reg_kernel.h"
+#include "sarl_step_fused.h"
 
 struct cn_sarl {
     cn_sarl_config cfg;
@@ -38,6 +39,7 @@ struct cn_sarl {
     // sarl_narrow_kernel: a few decisions (train.py's single-episode sampling) on tiles of 16 / H groups, one per workgroup
     bool narrow;
     size_t narrow_tiles, narrow_lds;
+    bool fused_step;      // cn_sarl_sample_step on the narrow route: decision + transition + next ORCA as one kernel (CROWDNAV_AMD_SARL_FUSED_STEP)
     int* narrow_counter;  // cn_sarl_sample_step: workgroups of sarl_narrow_kernel that have written their V
     double* narrow_value; // ... and reward + gamma V per (env, action), each written by the tile that computed V
 };
@@ -281,6 +283,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         const size_t per_tile = (size_t)(cn::kSarlGroups / (H < 1 ? 1 : H));
         s->narrow_tiles = per_tile ? (s->n_groups + per_tile - 1) / per_tile : 0;
         s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
+        s->fused_step = env_int("CROWDNAV_AMD_SARL_FUSED_STEP", 1) != 0 && e->P.threads == 64 && !e->P.kd;
         s->narrow = !cadrl && !lstm && !s->chunked && !s->reg_mlp && in_dim == 13 && !C.sort_lookahead && H >= 1 &&
                     H <= cn::kSarlMaxHumans && e->cfg.scenario_rule != CN_MIXED && s->narrow_lds <= 160 * 1024 &&
                     (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)s->n_cus));
@@ -615,6 +618,7 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
 
 int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
                         int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin) {
+    const bool was_fresh = e && e->orca_fresh;  // bind() clears it: every entry point but this one invalidates the velocities
     int rc = bind(e);
     if (rc) return rc;
     cn_sarl* s = e->sarl;
@@ -628,17 +632,43 @@ int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* b
     if (env_stride == 0) env_stride = row;
     if (state_out && env_stride < row)
         return fail(CN_ERR_INVALID, "cn_sarl_sample_step: env_stride %lld < %lld", (long long)env_stride, (long long)row);
+    const bool fresh = was_fresh;
     if (s->narrow) {
-        // three launches: the humans' ORCA velocities, the value network with the decision behind it, the transition
-        if (!C.const_vel) cn_launch_orca(e, s->orca_vel);
+        // Two launches per step in a streamed loop: the value network (its tiles add the lookahead reward and write the replay
+        // state), then decision + transition + the humans' ORCA velocities of the NEXT decision (sarl_decide_step_kernel); the
+        // first call after anything else touched the engine computes those velocities with a launch of its own.  Workgroup
+        // geometries that kernel does not cover (several waves per workgroup, kd bookkeeping) and
+        // CROWDNAV_AMD_SARL_FUSED_STEP=0: ORCA, the network with the decision by its last workgroup, the transition.
+        const bool fused = s->fused_step;
+        if (!C.const_vel && !(fused && fresh)) cn_launch_orca(e, s->orca_vel);
         cn::SarlDecide D{};
-        D.counter = s->narrow_counter, D.epsilon = epsilon, D.alive = alive, D.done = done, D.best = best, D.action = action;
+        D.counter = fused ? nullptr : s->narrow_counter;
+        D.epsilon = epsilon, D.alive = alive, D.done = done, D.best = best, D.action = action;
         D.state_out = state_out, D.env_stride = env_stride, D.sort_humans = sort_humans ? 1 : 0, D.in_dim = s->net.in_dim;
         D.reward = s->reward, D.value = s->narrow_value, D.gtime = e->S.gtime, D.mt_key = e->S.mt_key, D.mt_pos = e->S.mt_pos, D.error = e->C.error;
         hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
                            e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
                            s->next_obs, s->V, D);
         CN_HIP(hipGetLastError());
+        if (fused) {
+            cn::StepIo io{action, reward, done, info, dmin, nullptr, nullptr, nullptr, 1};
+            float* next_vel = C.const_vel ? nullptr : s->orca_vel;
+            const dim3 grid(grid_envs(e)), block(e->P.threads);
+#define CN_DECIDE_STEP(MAXL, UNI)                                                                                      \
+    hipLaunchKernelGGL((cn::sarl_decide_step_kernel<MAXL, UNI>), grid, block, e->smem, e->stream, e->P, e->S, io, C, D, \
+                       s->actions, next_vel)
+            if (e->maxl == 5) {
+                if (e->P.robot_unicycle) CN_DECIDE_STEP(5, true);
+                else CN_DECIDE_STEP(5, false);
+            } else {
+                if (e->P.robot_unicycle) CN_DECIDE_STEP(10, true);
+                else CN_DECIDE_STEP(10, false);
+            }
+#undef CN_DECIDE_STEP
+            CN_HIP(hipGetLastError());
+            e->orca_fresh = next_vel != nullptr;
+            return CN_OK;
+        }
     } else {
         hipLaunchKernelGGL(cn::sarl_alive_kernel, dim3((C.B + 255) / 256), dim3(256), 0, e->stream, C.B, alive, done);
         if ((rc = cn_sarl_select(e, nullptr, best, action)) || (rc = cn_sarl_explore(e, epsilon, alive, best, action, nullptr)))

@@ -1300,6 +1300,18 @@ __host__ inline size_t sarl_mlp_lds_bytes(const SarlNet& net) {
 // ------------------------------------------------------------------------------------ action selection
 // value = reward + pow(gamma, time_step * v_pref) * V (multi_human_rl.py:52); the first strict maximum wins (:54);
 // a robot already at its goal stops (:22-23, policy.py:43-49).  best = -1 encodes that stop action.
+// The arg-max of env b -> best / action_out (one lane): a robot already at its goal stops (:22-23, policy.py:43-49)
+__device__ __forceinline__ void sarl_pick_tail(const SarlCfg& C, const double2* pos, const double2* goal, const double2* rv,
+                                               const double* actions, int* best, double* action_out, int b, int bi) {
+    const size_t g0 = (size_t)b * (C.H + 1);
+    int arg = bi;
+    const double dy = pos[g0].y - goal[g0].y, dx = pos[g0].x - goal[g0].x;
+    const bool arrived = norm2(dy, dx) < rv[g0].x;  // np.linalg.norm((py - gy, px - gx))
+    if (arrived) arg = -1;
+    best[b] = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
+    action_out[2 * b] = arg >= 0 ? actions[2 * arg] : 0.0;
+    action_out[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
+}
 // The wave's best (value, action) -> best / action_out of env b: a butterfly keeps the largest value, lowest index on ties
 // (= the first strict maximum of the reference's loop; NaN and -inf never win: `value > max_value` is false)
 __device__ __forceinline__ void sarl_pick_env(const SarlCfg& C, const double2* pos, const double2* goal, const double2* rv,
@@ -1314,14 +1326,7 @@ __device__ __forceinline__ void sarl_pick_env(const SarlCfg& C, const double2* p
         bi = take ? oi : bi;
     }
     if (lane != 0) return;
-    const size_t g0 = (size_t)b * (C.H + 1);
-    int arg = bi;
-    const double dy = pos[g0].y - goal[g0].y, dx = pos[g0].x - goal[g0].x;
-    const bool arrived = norm2(dy, dx) < rv[g0].x;  // np.linalg.norm((py - gy, px - gx))
-    if (arrived) arg = -1;
-    best[b] = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
-    action_out[2 * b] = arg >= 0 ? actions[2 * arg] : 0.0;
-    action_out[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
+    sarl_pick_tail(C, pos, goal, rv, actions, best, action_out, b, bi);
 }
 __device__ __forceinline__ void sarl_select_env(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
                                                 const double2* rv, const double* gtime, const double* theta,
@@ -1358,7 +1363,9 @@ __global__ void sarl_alive_kernel(int B, uint8_t* alive, const uint8_t* done) {
     if (b < B && done[b]) alive[b] = 0;
 }
 
-// What cn_sarl_sample_step adds behind the network (counter == nullptr: nothing).
+// What cn_sarl_sample_step adds to the network kernel: value != nullptr -> every tile adds the lookahead reward of its groups and
+// stores reward + gamma V, tile b writes env b's replay state; counter != nullptr -> the last workgroup decides as well (otherwise
+// sarl_decide_step_kernel does, in front of the transition).
 struct SarlDecide {
     int* counter;        // workgroups that have written their V (zero between launches)
     double epsilon;
@@ -1551,7 +1558,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     // cn_sarl_sample_step: the reward of the tile's groups on the lanes that will hold their V — the value head's wave, which
     // has no column tile of the 100-wide layers: this float64 chain runs beside mlp1.2's MFMAs.  The decision behind the
     // network then only compares reward + gamma V.
-    if (D.counter && head_lane) {
+    if (D.value && head_lane) {
         const size_t G = tile * GT + lane;
         my_reward = narrow_reward(C, pos, vel, goal, rv, D.gtime, theta, actions, (int)(G / C.n_actions), (int)(G % C.n_actions));
         D.reward[G] = my_reward;
@@ -1569,7 +1576,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     }
     dense_narrow(layer_of(*n, kL_mlp2_0), bufB, bufA, true, nullptr, wave, lane, cur);
     // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network)
-    if (D.counter && D.state_out && wave == kNarrowWaves - 1 && tile < (size_t)C.B && lane < H)
+    if (D.value && D.state_out && wave == kNarrowWaves - 1 && tile < (size_t)C.B && lane < H)
         narrow_transform(C, D, pos, vel, goal, rv, theta, (int)tile, lane);
     cur = narrow_fetch(layer_of(*n, kL_att0_global), wave, lane);
     lds_barrier();
@@ -1658,7 +1665,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
             V[G] = v;
             // multi_human_rl.py:52, as sarl_select_env.  An agent-scope atomic store: written through to where every XCD's
             // agent-scope load finds it — no write-back of this XCD's whole L2 (a release fence) for 3 doubles
-            if (D.counter)
+            if (D.value)
                 __hip_atomic_store(&D.value[G], my_reward + C.gamma_bar * (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (D.counter) {

@@ -1,0 +1,90 @@
+// cn_sarl_sample_step for a few envs, second half: ONE kernel for the decision, the transition and the humans' ORCA velocities of
+// the next decision —
+//   arg-max of reward + gamma V over the env's actions (the values sarl_narrow_kernel's tiles stored), the robot already at its
+//   goal, the previous step's episode ends folded into `alive`, the epsilon-greedy draw          multi_human_rl.py:11-63
+//   step_kernel's body (step_kernels.h) with that action                                           crowd_sim.py:317-420
+//   orca_kernel's body on the state the transition has just written: what the NEXT call's network kernel reads as the humans'
+//   next velocities (cn_engine::orca_fresh), so that a streamed sampling loop is two launches per step
+// instead of three kernels (orca, last-workgroup decision inside the network kernel, step).  One-wave workgroups without kd
+// bookkeeping only (up to 10 agents per simulator): an env's lanes are lanes of one wave, so its arg-max is folded with shuffles.
+#pragma once
+#include "sarl_kernels.h"
+
+namespace cn {
+
+template <int MAXL, bool UNI>
+__global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, StateView S, StepIo io, SarlCfg C, SarlDecide D,
+                                                                     const double* actions, float* next_orca_vel) {
+    const Smem s = carve<MAXL>(P);
+    const Lane L = lane_of(P);
+    // ---- the decision: the env's lanes stride over its actions, the robot's lane folds them in lane order (the largest value,
+    // the lowest index on ties = the first strict maximum of the reference's loop; NaN and -inf never win)
+    {
+        double bv = -__builtin_inf();
+        int bi = -1;
+        if (L.valid) {
+            for (int a = L.a; a < C.n_actions; a += P.A) {
+                const double v = D.value[(size_t)L.env * C.n_actions + a];
+                if (v > bv) {
+                    bv = v;
+                    bi = a;
+                }
+            }
+        }
+        double best_v = bv;
+        int best_i = bi;
+        for (int j = 1; j < P.A; ++j) {
+            const double ov = __shfl(bv, L.ebase + j);
+            const int oi = __shfl(bi, L.ebase + j);
+            const bool take = oi >= 0 && (best_i < 0 || ov > best_v || (ov == best_v && oi < best_i));
+            best_v = take ? ov : best_v;
+            best_i = take ? oi : best_i;
+        }
+        if (L.valid && L.a == 0) {
+            const int b = L.env;
+            sarl_pick_tail(C, S.pos, S.goal, S.rv, actions, D.best, D.action, b, best_i);
+            const bool keep = D.alive[b] && !(D.done && D.done[b]);  // (the previous call's flags: this call's are written below)
+            D.alive[b] = keep ? 1 : 0;
+            sarl_explore_env(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, actions, !keep, D.best, D.action, nullptr, D.error, b);
+        }
+    }
+    // ---- the transition: step_kernel's body (the robot's lane reads the action it has just written)
+    AgentRegs r = {};
+    if (L.valid) load_agent(S, L.gi, r);
+    float robot_max_speed = 0.0f;
+    build_pairs(P, s);
+    double gtime = (L.valid && L.a == 0) ? S.gtime[L.env] : 0.0;
+    double theta = (L.valid && L.a == 0) ? S.theta[L.env] : 0.0;
+    StepResult res;
+    double nvx, nvy;
+    step_core<MAXL, UNI, false>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta);
+    if (L.valid) {
+        if (L.a == 0) {
+            io.reward[L.env] = res.reward;
+            io.done[L.env] = res.done;
+            io.info[L.env] = res.info;
+            if (io.dmin) io.dmin[L.env] = res.dmin;
+            if (io.update) {
+                S.gtime[L.env] = gtime;
+                S.theta[L.env] = theta;
+            }
+        }
+        if (io.update) {
+            S.pos[L.gi] = make_double2(r.px, r.py);
+            S.vel[L.gi] = make_double2(r.vx, r.vy);
+        }
+    }
+    // ---- orca_kernel's body on the new state (r holds what was just stored)
+    if (next_orca_vel == nullptr) return;
+    block_sync(P);
+    load_robot_view(P, S, s, L, r, robot_max_speed);
+    float vx, vy;
+    orca_phases<MAXL, false>(P, s, L, r, robot_max_speed, L.valid, vx, vy);
+    if (L.valid) {
+        next_orca_vel[2 * L.gi] = vx;
+        next_orca_vel[2 * L.gi + 1] = vy;
+        if (L.a == 0) S.rsim_valid[L.env] = 1;
+    }
+}
+
+}  // namespace cn

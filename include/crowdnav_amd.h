@@ -334,13 +334,17 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
  *   cn_sarl_transform(e, state_out, env_stride, sort_humans)      (state_out == NULL: skipped)
  *   cn_step(e, action, 1, reward, done, info, dmin, NULL, NULL, NULL)
  * as one call.  For a FEW envs without occupancy maps (CN_MODEL_SARL, up to 8 humans, not the `mixed` rule, at most one
- * workgroup per CU: 9 envs of 5 humans x 81 actions — BASELINE configs[4]'s one episode at a time, train.py:156-170) that is
- * three launches instead of eight: ORCA for the humans' next velocities; the value network on tiles of 16 / num_humans whole
+ * workgroup per CU: 9 envs of 5 humans x 81 actions — BASELINE configs[4]'s one episode at a time, train.py:156-170) a streamed
+ * loop of these calls is TWO launches per step instead of eight: the value network on tiles of 16 / num_humans whole
  * (env, action) groups, one per workgroup — a decision spread over 27 CUs instead of 6, its input rows built in LDS, each
- * tile adding the lookahead reward of its own groups and writing env b's replay-memory state on an idle wave — whose last
- * workgroup takes the arg-max and draws epsilon-greedy; the transition.  Same bits as the five calls above in either case
- * (tests/test_rl_pipeline.py).  cn_sarl_select takes the same network kernel at these sizes (two launches less);
- * CROWDNAV_AMD_SARL_NARROW=0 keeps the one-tile kernels, 2 takes the narrow tiles at any size the configuration allows. */
+ * tile adding the lookahead reward of its own groups and writing env b's replay-memory state on an idle wave; then ONE kernel
+ * for the arg-max, the epsilon-greedy draw, the transition and the humans' ORCA velocities of the NEXT decision.  Those
+ * velocities are trusted by the next call only if no other entry point of this engine ran in between (any of them may change
+ * the state they belong to); otherwise, and on the first call, ORCA is a launch of its own in front.  Same bits as the five
+ * calls above in every case (tests/test_rl_pipeline.py).  cn_sarl_select takes the same network kernel at these sizes (two
+ * launches less).  CROWDNAV_AMD_SARL_NARROW=0 keeps the one-tile kernels, 2 takes the narrow tiles at any size the
+ * configuration allows; CROWDNAV_AMD_SARL_FUSED_STEP=0 (and workgroups of several waves / simulators of more than 10
+ * agents): ORCA, the network with the decision by its last workgroup, the transition — three launches. */
 int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
                         int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin);
 /* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):

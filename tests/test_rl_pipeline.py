@@ -190,7 +190,9 @@ def test_transform_matches_host_transform(with_om):
 def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
     """cn_sarl_sample_step (ABI v8) = alive &= ~done; cn_sarl_select; cn_sarl_explore(mask = alive); cn_sarl_transform;
     cn_step.  Three engines on the same seeds and weights for 104 steps (every episode ends, envs leave `alive`, the epsilon-greedy
-    draws continue each env's numpy stream): (a) the one call on the narrow-tile route (three launches; forced with
+    draws continue each env's numpy stream): (a) the one call on the narrow-tile route (two launches per step — the network, then decision + transition + the
+    next decision's ORCA velocities in one kernel, with another entry point in between every 13 steps — and, with
+    CROWDNAV_AMD_SARL_FUSED_STEP=0, three: ORCA, the network with the decision by its last workgroup, the transition; forced with
     CROWDNAV_AMD_SARL_NARROW=2: by size it is taken up to one workgroup per CU, 9 envs of 5 humans; 40 envs are 1080 tiles and
     five envs per wave of the deciding workgroup), (b) the one call with CROWDNAV_AMD_SARL_NARROW=0 (the general route inside
     the call), (c) the five calls by hand on the one-tile kernels.  Every history is the same bits."""
@@ -203,8 +205,9 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
     space, _, _ = build_action_space(1.0)
     T, D = 104, 13
 
-    def run(narrow, one_call):
+    def run(narrow, one_call, fused='1'):
         monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_FUSED_STEP', fused)
         eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=0)
         eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
         eng.sarl_set_weights(net.state_dict())
@@ -219,6 +222,8 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
             for t in range(T):
                 step(t, 0.3)
                 alive_hist.append(alive.clone())
+                if t % 13 == 12:
+                    eng.get_state()   # any other entry point: the next call must not trust the velocities the last one left
         else:
             lib, h, V = eng._lib, eng._h, C.c_void_p
             for t in range(T):
@@ -235,10 +240,54 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
         eng.close()
         return out
 
-    a, b, c = run('2', True), run('0', True), run('0', False)
+    a, a2, b, c = run('2', True), run('2', True, fused='0'), run('0', True), run('0', False)
     assert (a[5][-1] == 0).all() and (a[5][0] == 1).all()   # every episode ended (time_limit / time_step = 100 steps at the latest)
-    for x, y, w in zip(a, b, c):
-        assert np.array_equal(x, y) and np.array_equal(x, w)
+    for x, x2, y, w in zip(a, a2, b, c):
+        assert np.array_equal(x, x2) and np.array_equal(x, y) and np.array_equal(x, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,model_on_gpu', [('rl_sarl_plain.npz', False), ('rl_sarl_plain.npz', True), ('rl_cadrl.npz', True),
+                                               ('rl_lstm_rl.npz', True)])
+def test_single_episode_sampling_calls_reproduce_the_reference_memory(name, model_on_gpu):
+    """train.py:156-170 samples ONE episode per call: the same fixtures with max_envs = 1 — every episode its own one-env batch
+    (the narrow-tile route of cn_sarl_sample_step for SARL, one episode's slices of the histories as replay rows).  With the
+    model on the GPU (`examples/train_sarl.py --gpu`) the TD targets come from the graph-replayed forward of the target
+    network, whose parameters a second update_target_model overwrites in place."""
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory
+    g = load_golden(name)
+    c, env, robot, policy = _setup(g)
+    k = int(g['k'])
+    mem = DeviceReplayMemory(100000, 'cuda:0')
+    dev = torch.device('cuda:0' if model_on_gpu else 'cpu')
+    if model_on_gpu:
+        policy.get_model().to(dev)
+        policy.set_device(dev)
+    ex = c.Explorer(env, robot, dev, mem, float(g['gamma']), target_policy=policy)
+    ex.max_envs = 1
+    scrambled = __import__('copy').deepcopy(policy.get_model())
+    with torch.no_grad():
+        for p_ in scrambled.parameters():
+            p_.mul_(0.5)
+    ex.update_target_model(scrambled)
+    first = ex.target_model
+    ex.update_target_model(policy.get_model())   # same architecture: in place
+    assert ex.target_model is first
+    assert all(torch.equal(a, b) for a, b in zip(ex.target_model.state_dict().values(), policy.get_model().state_dict().values()))
+    env.case_counter['train'] = int(g['first_case'])
+    ex.run_k_episodes(k, 'train', update_memory=True, episode=0)
+    lb = ex.last_batch
+    assert lb['outcome'] == g['ep_outcome'].tolist() and lb['steps'] == g['ep_steps'].tolist()
+    for e in range(k):
+        assert lb['actions'][e] == g['ep_actions'][e][:int(g['ep_steps'][e])].tolist(), e
+    assert len(mem) == len(g['memory_values'])
+    states = torch.stack([mem[i][0].cpu() for i in range(len(mem))]).numpy()
+    values = torch.cat([mem[i][1].cpu() for i in range(len(mem))]).numpy()
+    if states.ndim == 2:
+        states = states[:, None, :]
+    assert np.abs(states - g['memory_states']).max() <= 5e-6 and np.abs(values - g['memory_values']).max() <= 1e-6
+    if model_on_gpu and name != 'rl_lstm_rl.npz':
+        assert ex._td_graph is not None   # (an nn.LSTM forward may refuse capture: then the eager path ran, with a warning)
 
 
 @pytest.mark.gpu
