@@ -469,9 +469,10 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5):
     return {'workload': '%d env x 5 humans, 81 actions, SARL: cn_sarl_sample_step (decision + epsilon-greedy + replay state + '
                         'transition), %d steps streamed' % (envs, steps),
             'value': envs / per_step, 'unit': 'env-steps/s', 'us_per_step': per_step * 1e6,
-            'launches_per_step': 3, 'kernels': 'cn::orca_kernel, cn::sarl_narrow_kernel, cn::step_kernel',
+            'launches_per_step': 2, 'kernels': 'cn::sarl_narrow_kernel (value network on 27 workgroups, reward, replay state), '
+                                               'cn::sarl_decide_step_kernel (arg-max, draw, transition, next ORCA)',
             'note': 'round 4: ten launches, 70-80 us per step; the reference schedule of configs[4] samples 10 000 episodes this way '
-                    '(profiles/r05_config5_reference_schedule.json: 45.5 s of RL sampling, weight re-pack / reset / read-back included)'}
+                    '(profiles/r05_config5_reference_schedule.json: weight re-pack / reset / read-back / TD targets included)'}
 
 
 def secondary(B, local_rank):
