@@ -396,7 +396,7 @@ class Explorer(object):
             done.zero_()
             T = 0
             lap('weights + reset')
-            # Per step: ONE library call (cn_sarl_sample_step: three launches at one env) and no torch kernel — every result
+            # Per step: ONE library call (cn_sarl_sample_step: two launches at one env) and no torch kernel — every result
             # lands in its row of the histories, and an env leaves `alive` at the start of the step after its episode ended
             # (so "somebody still samples" is alive & ~done here)
             step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)

@@ -420,7 +420,7 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     alive &= ~done (the previous step's episode ends; zero `done` before an episode's first step), then cn_sarl_select ->
     cn_sarl_explore (mask = alive) -> cn_sarl_transform -> cn_step — with row t of the caller's histories (traj [B, T, H, D]
     float32; rew / dmin [T, B] float64; info [T, B] uint8; act [T, B] int32: the chosen action index) as outputs, addresses
-    precomputed.  For a few envs the library runs it in three launches (include/crowdnav_amd.h)."""
+    precomputed.  For a few envs a streamed loop of these calls is two launches per step (include/crowdnav_amd.h)."""
     B, T, H, D = traj.shape
     if B != self.B or H != self.H:
         raise ValueError('traj is [%d, T, %d, D]; the engine holds %d envs x %d humans' % (B, H, self.B, self.H))
