@@ -54,6 +54,32 @@ def test_trainer_on_device_memory_cpu():
     assert later < first and np.isfinite(tr.optimize_batch(3))
 
 
+def test_target_model_updates_in_place_and_td_values_cpu():
+    """Explorer.update_target_model (explorer.py:26-27: copy.deepcopy): the first call copies, later calls with the same
+    architecture overwrite the copy's parameters in place (same values; a captured graph of its forward stays valid), another
+    architecture is copied afresh; _td_values on a CPU model is the plain forward."""
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    torch.manual_seed(2)
+    a = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    b = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    ex = c.Explorer(None, None, torch.device('cpu'), None, 0.9)
+    ex.update_target_model(a)
+    first = ex.target_model
+    assert first is not a and all(torch.equal(p, q) for p, q in zip(first.parameters(), a.parameters()))
+    ex.update_target_model(b)
+    assert ex.target_model is first and all(torch.equal(p, q) for p, q in zip(first.parameters(), b.parameters()))
+    with torch.no_grad():
+        next(b.parameters()).add_(1.0)                     # the source moves on: the target keeps what it was given
+    assert not torch.equal(next(first.parameters()), next(b.parameters()))
+    x = torch.randn(7, 5, 13)
+    with torch.no_grad():
+        assert torch.equal(ex._td_values(x), first(x).reshape(-1))
+    other = ValueNetwork(13, 6, [64, 32], [32, 16], [64, 32, 32, 1], [32, 32, 1], True, 1.0, 4)
+    ex.update_target_model(other)
+    assert ex.target_model is not first and ex.target_model is not other
+
+
 def test_rl_fixture_is_self_consistent_cpu():
     """The reference's memory holds exactly the steps of its ReachGoal / Collision episodes; terminal targets are the
     terminal rewards (explorer.py:111-113)."""
