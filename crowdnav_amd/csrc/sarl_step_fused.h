@@ -17,6 +17,8 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
                                                                      const double* actions, float* next_orca_vel) {
     const Smem s = carve<MAXL>(P);
     const Lane L = lane_of(P);
+    AgentRegs r = {};
+    if (L.valid) load_agent(S, L.gi, r);  // (requested in front of the decision's own loads: one round trip for both)
     // ---- the decision: the env's lanes stride over its actions, the robot's lane folds them in lane order (the largest value,
     // the lowest index on ties = the first strict maximum of the reference's loop; NaN and -inf never win)
     {
@@ -42,15 +44,18 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
         }
         if (L.valid && L.a == 0) {
             const int b = L.env;
-            sarl_pick_tail(C, S.pos, S.goal, S.rv, actions, D.best, D.action, b, best_i);
+            // sarl_pick_tail on the robot's own registers (the same doubles): a robot already at its goal stops (:22-23)
+            const bool arrived = norm2(r.py - r.gy, r.px - r.gx) < r.rad;
+            const int arg = arrived ? -1 : best_i;
+            D.best[b] = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
+            D.action[2 * b] = arg >= 0 ? actions[2 * arg] : 0.0;
+            D.action[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
             const bool keep = D.alive[b] && !(D.done && D.done[b]);  // (the previous call's flags: this call's are written below)
             D.alive[b] = keep ? 1 : 0;
             sarl_explore_env(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, actions, !keep, D.best, D.action, nullptr, D.error, b);
         }
     }
     // ---- the transition: step_kernel's body (the robot's lane reads the action it has just written)
-    AgentRegs r = {};
-    if (L.valid) load_agent(S, L.gi, r);
     float robot_max_speed = 0.0f;
     build_pairs(P, s);
     double gtime = (L.valid && L.a == 0) ? S.gtime[L.env] : 0.0;
