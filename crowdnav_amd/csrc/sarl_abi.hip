@@ -148,6 +148,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
     C.gamma_bar = std::pow(c->gamma, e->cfg.time_step * e->cfg.robot_v_pref);
     C.unicycle = e->P.robot_unicycle;
     C.const_vel = c->constant_velocity_model ? 1 : 0;
+    C.cadrl = cadrl ? 1 : 0;
     C.sort_lookahead = (C.const_vel && lstm) ? 1 : 0;
 
     s->arena = nullptr, s->arena_used = 0;
@@ -284,7 +285,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->narrow_tiles = per_tile ? (s->n_groups + per_tile - 1) / per_tile : 0;
         s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
         s->fused_step = env_int("CROWDNAV_AMD_SARL_FUSED_STEP", 1) != 0 && e->P.threads == 64 && !e->P.kd;
-        s->narrow = !cadrl && !lstm && !s->chunked && !s->reg_mlp && in_dim == 13 && !C.sort_lookahead && H >= 1 &&
+        s->narrow = !lstm && !s->chunked && !s->reg_mlp && in_dim == 13 && !C.sort_lookahead && H >= 1 &&
                     H <= cn::kSarlMaxHumans && e->cfg.scenario_rule != CN_MIXED && s->narrow_lds <= 160 * 1024 &&
                     (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)s->n_cus));
     }

@@ -140,6 +140,7 @@ struct SarlCfg {
     int B, H, n_actions;
     int with_om, cell_num, om_channels;
     int unicycle;  // actions are ActionRot(v, r): cadrl.py:119-125, crowd_sim.py:339-341
+    int cadrl;           // cadrl.ValueNetwork (the row MLP + minimum over humans) instead of sarl.ValueNetwork: sarl_narrow_kernel's branch
     int const_vel;       // query_env = false (multi_human_rl.py:39-42): humans keep their velocity, reward = compute_reward
     int sort_lookahead;  // ... and the joint state LstmRL.predict sorted by decreasing distance feeds the network (lstm_rl.py:96-103)
     double cell_size;
@@ -1519,7 +1520,8 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     const size_t tile = blockIdx.x;
     const SarlNetRef* n = &net;
     CN_SARL_CLOCK_BEGIN();
-    BTile cur = narrow_fetch(layer_of(*n, kL_mlp1_0), wave, lane);
+    // (cadrl.ValueNetwork: its four layers live in the mlp3 slots)
+    BTile cur = narrow_fetch(layer_of(*n, C.cadrl ? kL_mlp3_0 : kL_mlp1_0), wave, lane);
     // every word of LDS starts finite (k padding meets zero weights); meanwhile the tile's rows of X in registers
     {
         f32x4* z = reinterpret_cast<f32x4*>(lds);
@@ -1543,9 +1545,81 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
 #pragma unroll
         for (int k = 0; k < 13; ++k) xs[(k >> 2) * 64 + (k & 3) * 16 + tid] = f[k];
     }
-    BTile nxt = narrow_fetch(layer_of(*n, kL_mlp1_2), wave, lane);
+    BTile nxt = narrow_fetch(layer_of(*n, C.cadrl ? kL_mlp3_2 : kL_mlp1_2), wave, lane);
     lds_barrier();
     CN_SARL_TICK(1);
+    // What every tile does with the V of its groups (on the value head's wave), and what follows it under cn_sarl_sample_step
+    const auto finish = [&](float v) {
+        int arrived = 0;
+        if (wave == kNarrowWaves - 1) {
+            if (head_lane) {
+                const size_t G = tile * GT + lane;
+                V[G] = v;
+                // multi_human_rl.py:52, as sarl_select_env.  An agent-scope atomic store: written through to where every XCD's
+                // agent-scope load finds it — no write-back of this XCD's whole L2 (a release fence) for 3 doubles
+                if (D.value)
+                    __hip_atomic_store(&D.value[G], my_reward + C.gamma_bar * (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (D.counter) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the stores above have been acknowledged before the tile counts as arrived
+                if (lane == 0) arrived = atomicAdd(D.counter, 1) + 1;
+            }
+        }
+        if (!D.counter) return;  // cn_sarl_select, or the decision is sarl_decide_step_kernel's: the network only
+        // ---- the workgroup that finishes LAST decides for every env, one wave per env — arg-max of reward + gamma V, the
+        // epsilon-greedy draw on the env's own stream (sarl_explore_env) — instead of three more launches behind this one (the
+        // joint state for the replay memory was written by tile b meanwhile).
+        int* last = reinterpret_cast<int*>(sbuf);
+        if (wave == kNarrowWaves - 1 && lane == 0) {
+            *last = arrived == (int)gridDim.x ? 1 : 0;
+            if (*last) atomicExch(D.counter, 0);  // ready for the next launch
+        }
+        __syncthreads();
+        if (!*last) return;
+        narrow_decide(C, D, pos, goal, rv, wave, lane, actions);
+    };
+    const auto reward_of_my_group = [&]() {
+        // cn_sarl_sample_step: the reward of the tile's groups on the lanes that will hold their V — the value head's wave, which has
+        // no column tile of the 100-wide layers: this float64 chain runs beside a 100-wide layer's MFMAs.  The decision behind the
+        // network then only compares reward + gamma V.
+        if (D.value && head_lane) {
+            const size_t G = tile * GT + lane;
+            my_reward = narrow_reward(C, pos, vel, goal, rv, D.gtime, theta, actions, (int)(G / C.n_actions), (int)(G % C.n_actions));
+            D.reward[G] = my_reward;
+        }
+    };
+    const auto replay_state_of_my_env = [&]() {
+        // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network)
+        if (D.value && D.state_out && wave == kNarrowWaves - 1 && tile < (size_t)C.B && lane < H)
+            narrow_transform(C, D, pos, vel, goal, rv, theta, (int)tile, lane);
+    };
+    if (C.cadrl) {
+        // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row — cadrl_mlp_kernel's four layers on the
+        // tile's 16 rows — then the minimum over the humans of a group (cadrl.py:162-163: the first minimum's value)
+        dense_narrow(layer_of(*n, kL_mlp3_0), xs, bufA, true, nullptr, wave, lane, cur);
+        cur = narrow_fetch(layer_of(*n, kL_mlp3_4), wave, lane);
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_2), bufA, bufB, true, nullptr, wave, lane, nxt);
+        reward_of_my_group();
+        nxt = narrow_fetch(layer_of(*n, kL_mlp3_6), wave, lane);
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_4), bufB, bufA, true, nullptr, wave, lane, cur);
+        replay_state_of_my_env();
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_6), bufA, kbuf, false, nullptr, wave, lane, nxt);  // column 0 of the tile: row r at word r
+        lds_barrier();
+        float m = 0.0f;
+        if (wave == kNarrowWaves - 1 && lane < GT) {
+            m = kbuf[lane * H];
+            for (int h = 1; h < H; ++h) {
+                const float v = kbuf[lane * H + h];
+                m = v < m ? v : m;
+            }
+        }
+        CN_SARL_CLOCK_END();
+        finish(m);
+        return;
+    }
     // self_state = state[:, 0, :6] (sarl.py:36): the first human's row of the group
     float self_val = 0.0f;
     const int sg = tid & 15, sf = tid >> 4;
@@ -1555,14 +1629,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     lds_barrier();
     CN_SARL_TICK(2);
     dense_narrow(layer_of(*n, kL_mlp1_2), bufA, bufB, true, nullptr, wave, lane, nxt);  // h2
-    // cn_sarl_sample_step: the reward of the tile's groups on the lanes that will hold their V — the value head's wave, which
-    // has no column tile of the 100-wide layers: this float64 chain runs beside mlp1.2's MFMAs.  The decision behind the
-    // network then only compares reward + gamma V.
-    if (D.value && head_lane) {
-        const size_t G = tile * GT + lane;
-        my_reward = narrow_reward(C, pos, vel, goal, rv, D.gtime, theta, actions, (int)(G / C.n_actions), (int)(G % C.n_actions));
-        D.reward[G] = my_reward;
-    }
+    reward_of_my_group();
     nxt = narrow_fetch(layer_of(*n, kL_mlp2_2), wave, lane);
     lds_barrier();
     CN_SARL_TICK(3);
@@ -1575,9 +1642,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         }
     }
     dense_narrow(layer_of(*n, kL_mlp2_0), bufB, bufA, true, nullptr, wave, lane, cur);
-    // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network)
-    if (D.value && D.state_out && wave == kNarrowWaves - 1 && tile < (size_t)C.B && lane < H)
-        narrow_transform(C, D, pos, vel, goal, rv, theta, (int)tile, lane);
+    replay_state_of_my_env();
     cur = narrow_fetch(layer_of(*n, kL_att0_global), wave, lane);
     lds_barrier();
     CN_SARL_TICK(4);
@@ -1647,7 +1712,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     dense_narrow(layer_of(*n, kL_mlp3_4), jbuf, mbuf, true, nullptr, wave, lane, nxt);
     lds_barrier();
     CN_SARL_TICK(13);
-    int arrived = 0;
+    float v = 0.0f;
     if (wave == kNarrowWaves - 1) {  // mlp3.6 as value_head_on_one_wave: 4 k slices of the 16 rows, summed in slice order
         const PackedLinear P = layer_of(*n, kL_mlp3_6);
         const int row = lane & 15, slice = lane >> 4;
@@ -1657,36 +1722,13 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
             const float* x = mbuf + s * 64 + row;
             sum += (x[0] * w[0] + x[16] * w[16]) + (x[32] * w[32] + x[48] * w[48]);
         }
-        float v = as_global(P.bias)[0];
+        v = as_global(P.bias)[0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v += __shfl(sum, row + 16 * j);
-        if (head_lane) {
-            const size_t G = tile * GT + lane;
-            V[G] = v;
-            // multi_human_rl.py:52, as sarl_select_env.  An agent-scope atomic store: written through to where every XCD's
-            // agent-scope load finds it — no write-back of this XCD's whole L2 (a release fence) for 3 doubles
-            if (D.value)
-                __hip_atomic_store(&D.value[G], my_reward + C.gamma_bar * (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (D.counter) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the stores above have been acknowledged before the tile counts as arrived
-            if (lane == 0) arrived = atomicAdd(D.counter, 1) + 1;
-        }
     }
     CN_SARL_TICK(14);
     CN_SARL_CLOCK_END();
-    if (!D.counter) return;  // cn_sarl_select: the network only
-    // ---- cn_sarl_sample_step: the workgroup that finishes LAST decides for every env, one wave per env — arg-max of reward +
-    // gamma V, the epsilon-greedy draw on the env's own stream (sarl_explore_env) — instead of three more launches behind this
-    // one (the joint state for the replay memory was written by tile b meanwhile).
-    int* last = reinterpret_cast<int*>(sbuf);
-    if (wave == kNarrowWaves - 1 && lane == 0) {
-        *last = arrived == (int)gridDim.x ? 1 : 0;
-        if (*last) atomicExch(D.counter, 0);  // ready for the next launch
-    }
-    __syncthreads();
-    if (!*last) return;
-    narrow_decide(C, D, pos, goal, rv, wave, lane, actions);
+    finish(v);
 }
 __host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net) {
     return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads);

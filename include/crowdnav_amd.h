@@ -333,7 +333,7 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
  *   cn_sarl_explore(e, epsilon, alive, best, action, NULL)
  *   cn_sarl_transform(e, state_out, env_stride, sort_humans)      (state_out == NULL: skipped)
  *   cn_step(e, action, 1, reward, done, info, dmin, NULL, NULL, NULL)
- * as one call.  For a FEW envs without occupancy maps (CN_MODEL_SARL, up to 8 humans, not the `mixed` rule, at most one
+ * as one call.  For a FEW envs without occupancy maps (CN_MODEL_SARL or CN_MODEL_CADRL, up to 8 humans, not the `mixed` rule, at most one
  * workgroup per CU: 9 envs of 5 humans x 81 actions — BASELINE configs[4]'s one episode at a time, train.py:156-170) a streamed
  * loop of these calls is TWO launches per step instead of eight: the value network on tiles of 16 / num_humans whole
  * (env, action) groups, one per workgroup — a decision spread over 27 CUs instead of 6, its input rows built in LDS, each

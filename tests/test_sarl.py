@@ -140,6 +140,36 @@ def test_narrow_tile_value_network_is_bit_identical_to_the_one_tile_kernel(human
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans,B', [(5, 1), (5, 4), (1, 3), (3, 2), (8, 2)])
+def test_narrow_tile_cadrl_network_is_bit_identical_to_the_one_tile_kernel(humans, B, monkeypatch):
+    """cadrl.ValueNetwork (the row MLP, then the minimum over a group's humans) on the narrow tiles: the same bits as
+    sarl_feature_kernel + cadrl_mlp_kernel (CROWDNAV_AMD_SARL_NARROW=0), within 2e-5 of the torch module."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import cadrl
+    from crowdnav_amd.compat.sarl import build_action_space
+    torch.manual_seed(13)
+    net = cadrl.ValueNetwork(13, [150, 100, 100, 1])
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for narrow in ('2', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+        eng.reset(6000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='cadrl', mlp3_dims=(150, 100, 100, 1))
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[narrow] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), out['action'].cpu().numpy(),
+                       out['values'].cpu().numpy(), eng.sarl_export('X').cpu())
+        eng.close()
+    with torch.no_grad():
+        rows = net(got['2'][4].reshape(B * 81 * humans, 13)).reshape(B, 81, humans)
+    assert np.abs(got['2'][0] - rows.min(dim=2).values.numpy()).max() <= 2e-5
+    for a, b in zip(got['2'], got['0']):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True, 'maps inside the kernel'])
 def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
     """5 humans at the shipped widths run sarl_reg_kernel (activations in registers); CROWDNAV_AMD_SARL_REG=0 keeps the LDS
