@@ -49,7 +49,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 PMC_PROFILE = os.path.join(ROOT, 'profiles', 'r05_traffic.json')
-REFERENCE_PYTHON_PROFILE = os.path.join(ROOT, 'profiles', 'r05_reference_python.json')
+REFERENCE_PYTHON_PROFILE = os.path.join(ROOT, 'profiles', 'r06_reference_python.json')
+CONFIG5_PROFILES = [os.path.join(ROOT, 'profiles', n) for n in ('r06_config5_reference_schedule.json',
+                                                                 'r05_config5_reference_schedule.json')]
 
 
 def algorithmic_bytes_per_env_step(H):
@@ -484,10 +486,16 @@ def secondary(B, local_rank):
         key = 'om_sarl' if om else 'sarl'
         out[key] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'roofline')}
         out[key]['workload'] = r['config']['workload']
+        out[key]['decisions_per_s'] = B / (r['roofline']['select_ms'] / 1e3)
+        out[key]['cpu_baseline'] = reference_decision_baseline('sarl+om' if om else 'sarl')
     for policy in ('cadrl', 'lstm_rl'):
         out[policy] = measure_policy_decision(B, 5, policy, local_rank)
+        out[policy]['cpu_baseline'] = reference_decision_baseline(policy)
     out['h20'] = measure_h20(B, local_rank)
+    out['h20']['cpu_baseline'] = cpu_baseline_h20()
     out['sample_step'] = measure_sample_step(local_rank)
+    out['sample_step']['cpu_baseline'] = reference_sampling_baseline()
+    out['config5_schedule'] = config5_schedule_estimate()
     return out
 
 
@@ -528,6 +536,36 @@ def cpu_baseline(envs, humans, target_seconds=8.0):
                   'all cores' % (envs, humans, steps, dt_all),
         'single_core_value': n_one / dt_one,
     }
+
+
+def cpu_baseline_h20(envs=512, steps=60):
+    """CPU side of secondary.h20.r12: the C++ oracle on all host cores on a bounded sample of the same workload (20 humans, 12 m
+    circle, auto-reset), and the unmodified reference Python loop at that crowd on one core (reference_python_run)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    import crowd_oracle
+    cores = crowd_oracle.CrowdOracle.max_threads()
+    crowd_oracle.CrowdOracle.set_threads(cores)
+    best = None
+    for _ in range(2):
+        o = crowd_oracle.CrowdOracle(num_envs=envs, num_humans=20, robot_policy=1, robot_visible=1, circle_radius=12.0)
+        o.reset(2000 + np.arange(envs))
+        z = lambda dt: np.zeros(envs, dtype=dt)  # noqa: E731
+        t0 = time.perf_counter()
+        total, _ = o.rollout(steps, 2000, 2 ** 32 - 2000, 4, z(np.int32), z(np.int32), z(np.float64))
+        dt = time.perf_counter() - t0
+        if dt < 1.0:
+            steps *= max(2, int(2.0 / max(dt, 1e-3)))
+        if best is None or total / dt > best[0] / best[1]:
+            best = (total, dt, steps)
+    run = reference_python_run()
+    c20 = (run['raw'] or {}).get('crowd20')
+    return {'value': best[0] / best[1], 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d envs x 20 humans x %d steps on the 12 m circle, auto-reset, OpenMP over envs (oracle/crowd_oracle.cpp), '
+                      '%.1f s' % (envs, best[2], best[1]),
+            'reference_python': None if not c20 else {
+                'value': c20['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference', 'host': _reference_host(run),
+                'sample': '%d env-steps in %.1f s; %s' % (c20['env_steps'], c20['seconds'], c20['what'])}}
 
 
 def ring_depth():
@@ -714,38 +752,118 @@ def init_distributed(backend, local_rank):
                os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')))
 
 
-def reference_python_baseline(cases=250, timeout=240):
-    """north_star: "reported next to the reference Python-RVO2 CPU path timed on the same host (core count stated)".
-    The UNMODIFIED reference's own loop (env.reset / robot.act / env.step, crowd_nav/test.py:86-92 with --policy orca) timed ON
-    THIS HOST, one core, by oracle/time_reference_python.py in a subprocess (the reference is test infrastructure: the copy
-    `make -C oracle ref` leaves under the git-ignored oracle/_ref/ travels with the snapshot; its rvo2 module is the float32
-    restatement oracle/rvo2_pymodule.cpp — upstream Python-RVO2 is not installable offline).  A bounded sample: 2 x `cases`
-    test cases (~17 k env-steps, a few seconds).  Without a reference copy on this machine: the figure committed from the build
-    container, labelled as such."""
+_REFERENCE_RUN = {}  # the one subprocess run of oracle/time_reference_python.py of this process: {'raw': dict | None, 'here': bool}
+
+
+def reference_python_run(cases=250, decisions=30, sampling_seconds=8.0, timeout=300):
+    """ONE subprocess run of oracle/time_reference_python.py per bench process — the UNMODIFIED reference (test infrastructure:
+    the copy `make -C oracle ref` leaves under the git-ignored oracle/_ref/ travels with the snapshot; its rvo2 module is the
+    float32 restatement oracle/rvo2_pymodule.cpp — upstream Python-RVO2 is not installable offline) timed ON THIS HOST, one
+    pinned core, torch on one thread: its ORCA loop (2 x `cases` test cases), `decisions` robot.act -> predict calls per value
+    network, and `sampling_seconds` of single-episode train-phase sampling calls.  ~20 s of wall time in all.  Without a
+    reference copy on this machine: the figures committed from the build container, labelled as such."""
+    if _REFERENCE_RUN:
+        return _REFERENCE_RUN
     script = os.path.join(ROOT, 'oracle', 'time_reference_python.py')
+    raw, here = None, False
     try:
-        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='', OMP_NUM_THREADS='1')
-        p = subprocess.run([sys.executable, script, '--json', '--cases', str(cases)], capture_output=True, text=True,
-                           timeout=timeout, env=env)
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='', OMP_NUM_THREADS='1',
+                   MKL_NUM_THREADS='1')
+        p = subprocess.run([sys.executable, script, '--json', '--cases', str(cases), '--decisions', str(decisions),
+                            '--sampling-seconds', str(sampling_seconds)], capture_output=True, text=True, timeout=timeout, env=env)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
         if p.returncode == 0 and line:
-            r = json.loads(line[-1])
-            return {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'], 'kind': 'reference',
-                    'host': r['host_cpu'] + ' (THIS host, timed in this run)',
-                    'sample': '%d + %d env-steps in %.1f s (2 x %d test cases, robot invisible / visible), %s'
-                              % (r['runs'][0]['env_steps'], r['runs'][1]['env_steps'],
-                                 r['runs'][0]['seconds'] + r['runs'][1]['seconds'], cases, r['what']),
-                    'value_visible_robot': r['value_visible_robot'],
-                    'note': 'unmodified reference Python (oracle/_ref or /root/reference) on the float32 rvo2 restatement'}
-    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired):
+            raw, here = json.loads(line[-1]), True
+    except (OSError, ValueError, subprocess.TimeoutExpired):
         pass
-    if os.path.exists(REFERENCE_PYTHON_PROFILE):
-        r = json.load(open(REFERENCE_PYTHON_PROFILE))
-        return {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'], 'kind': 'reference',
-                'host': r['host_cpu'] + ' (build container, NOT this host)',
-                'note': r['what'] + '; on the float32 rvo2 restatement; committed figure (%s): no reference copy on this machine'
-                        % os.path.relpath(REFERENCE_PYTHON_PROFILE, ROOT)}
+    if raw is None and os.path.exists(REFERENCE_PYTHON_PROFILE):
+        try:
+            raw = json.load(open(REFERENCE_PYTHON_PROFILE))
+        except (OSError, ValueError):
+            raw = None
+    _REFERENCE_RUN.update(raw=raw, here=here)
+    return _REFERENCE_RUN
+
+
+def _reference_host(run):
+    return run['raw']['host_cpu'] + (' (THIS host, timed in this run)' if run['here'] else
+                                     ' (build container, NOT this host: committed figure %s, no reference copy on this machine)'
+                                     % os.path.relpath(REFERENCE_PYTHON_PROFILE, ROOT))
+
+
+def reference_python_baseline():
+    """north_star: "reported next to the reference Python-RVO2 CPU path timed on the same host (core count stated)": the ORCA
+    leg of reference_python_run() — the reference's own loop (env.reset / robot.act / env.step, crowd_nav/test.py:86-92 with
+    --policy orca), one core."""
+    run = reference_python_run()
+    r = run['raw']
+    if r is None or 'value' not in r:
+        return None
+    out = {'value': r['value'], 'unit': r['unit'], 'cores': r['cores'], 'kind': 'reference', 'host': _reference_host(run),
+           'value_visible_robot': r.get('value_visible_robot'),
+           'note': r['what'] + '; unmodified reference Python (oracle/_ref or /root/reference) on the float32 rvo2 restatement'}
+    if run['here']:
+        out['sample'] = '%d + %d env-steps in %.1f s (2 x %d test cases, robot invisible / visible)' % (
+            r['runs'][0]['env_steps'], r['runs'][1]['env_steps'], r['runs'][0]['seconds'] + r['runs'][1]['seconds'],
+            r['runs'][0]['test_cases'])
+    return out
+
+
+def reference_decision_baseline(policy):
+    """cpu_baseline of one secondary decision row: the reference's own robot.act -> predict (multi_human_rl.py:11-63 /
+    cadrl.py:130-176 / lstm_rl.py:69-104: 81 onestep_lookahead + 81 batch-1 forwards) on one core of this host.
+    policy: 'sarl' | 'sarl+om' | 'cadrl' | 'lstm_rl'."""
+    run = reference_python_run()
+    r = run['raw']
+    for rec in ((r or {}).get('decision') or {}).get('runs', []):
+        if rec['policy'] == policy:
+            return {'value': rec['decisions_per_s'], 'unit': 'decisions/s', 'cores': 1, 'kind': 'reference',
+                    'host': _reference_host(run), 'ms_per_decision': rec['ms_per_decision'],
+                    'sample': '%d decisions of the unmodified robot.act -> predict in %.1f s (5 humans, 81 actions, random-init '
+                              'weights, torch CPU on 1 thread; only robot.act timed)' % (rec['decisions'], rec['seconds'])}
     return None
+
+
+def reference_sampling_baseline():
+    """cpu_baseline of secondary.sample_step: the reference's train-phase sampling loop (train.py:156-170: single-episode
+    explorer.run_k_episodes(1, 'train', update_memory=True) calls, epsilon-greedy SARL robot) on one core of this host."""
+    run = reference_python_run()
+    rec = (run['raw'] or {}).get('sampling')
+    if not rec:
+        return None
+    return {'value': rec['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference', 'host': _reference_host(run),
+            'ms_per_env_step': rec['ms_per_env_step'],
+            'sample': '%d episodes = %d env-steps in %.1f s of the unmodified Explorer.run_k_episodes(1, \'train\', update_memory=True), '
+                      'epsilon %.1f, torch CPU on 1 thread' % (rec['episodes'], rec['env_steps'], rec['seconds'], rec['epsilon'])}
+
+
+def config5_schedule_estimate():
+    """BASELINE.md §4 row 5 ("wall-clock per phase vs CPU reference") for configs[4]: the in-scope phases of the reference's
+    own train.config schedule as measured on the MI355X (the committed profiles/r0N_config5_reference_schedule.json: 10 000
+    single-episode sampling calls, 3 000 imitation episodes) beside what the unmodified reference needs for the SAME env-step
+    counts at the rates timed on this host in this run: imitation collection at the ORCA loop's rate (its robot is ORCA,
+    train.py:115-129), RL sampling at the sampling leg's rate.  The SGD phases are torch on both sides (out of scope)."""
+    path = next((p for p in CONFIG5_PROFILES if os.path.exists(p)), None)
+    if path is None:
+        return None
+    t = json.load(open(path)).get('timing') or {}
+    orca, samp = reference_python_baseline(), reference_sampling_baseline()
+    out = {'schedule_from': os.path.relpath(path, ROOT),
+           'device_s': {'il_collect': t.get('il_collect_s'), 'rl_sample': t.get('rl_sample_s')},
+           'env_steps': {'il_collect': t.get('il_env_steps'), 'rl_sample': t.get('rl_env_steps')},
+           'out_of_scope_s': {'il_sgd': t.get('il_sgd_s'), 'rl_sgd': t.get('rl_sgd_s')}}
+    est = {}
+    if orca and t.get('il_env_steps'):
+        est['il_collect'] = t['il_env_steps'] / orca['value']
+    if samp and t.get('rl_env_steps'):
+        est['rl_sample'] = t['rl_env_steps'] / samp['value']
+    out['reference_estimate_s'] = est
+    out['speedup'] = {k: est[k] / out['device_s'][k] for k in est if out['device_s'].get(k)}
+    out['note'] = ('reference_estimate_s = the schedule\'s env-step count of the phase / the unmodified reference\'s env-steps/s on ONE '
+                   'core of this host (cpu_baseline.reference_python for the ORCA-driven imitation collection, '
+                   'secondary.sample_step.cpu_baseline for the SARL sampling); an estimate scaled from a bounded sample, not a run '
+                   'of the whole schedule (the reference needs ~%.0f h for it)' % (sum(est.values()) / 3600.0 if est else 0))
+    return out
 
 
 def self_launch(n):

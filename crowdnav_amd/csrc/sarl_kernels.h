@@ -1589,9 +1589,10 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         }
     };
     const auto replay_state_of_my_env = [&]() {
-        // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network)
-        if (D.value && D.state_out && wave == kNarrowWaves - 1 && tile < (size_t)C.B && lane < H)
-            narrow_transform(C, D, pos, vel, goal, rv, theta, (int)tile, lane);
+        // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network).
+        // A small action table has fewer tiles than envs (one human, 13 actions, 6 envs: 5 tiles): the tiles stride over the envs.
+        if (D.value && D.state_out && wave == kNarrowWaves - 1 && lane < H)
+            for (size_t b = tile; b < (size_t)C.B; b += gridDim.x) narrow_transform(C, D, pos, vel, goal, rv, theta, (int)b, lane);
     };
     if (C.cadrl) {
         // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row — cadrl_mlp_kernel's four layers on the

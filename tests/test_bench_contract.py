@@ -75,25 +75,71 @@ def test_committed_profile_provenance_is_decidable_in_this_checkout():
     assert 'csrc_sha_profiled' in src or 'profile_commit' in src or src['stale'] is None
 
 
-def test_reference_python_baseline_is_timed_on_this_host_or_labelled_off_host(monkeypatch):
-    """cpu_baseline.reference_python: the unmodified reference loop timed ON THE BENCH HOST when a reference copy is present
-    (/root/reference here, oracle/_ref on the GPU box: VERDICT r4 #2b); otherwise the committed figure, which must say that it
-    comes from the build container."""
+def test_reference_python_baselines_are_timed_on_this_host_or_labelled_off_host(monkeypatch):
+    """EVERY number of the line has the unmodified reference's CPU path beside it — cpu_baseline.reference_python
+    (ORCA loop), secondary.{sarl,om_sarl,cadrl,lstm_rl}.cpu_baseline (robot.act -> predict, decisions/s),
+    secondary.sample_step.cpu_baseline (train-phase sampling, env-steps/s), secondary.h20.cpu_baseline.reference_python and
+    secondary.config5_schedule.reference_estimate_s — timed ON THE BENCH HOST when a reference copy is present
+    (/root/reference here, oracle/_ref on the GPU box) by ONE subprocess run; otherwise the committed figures, which must say
+    that they come from the build container."""
     import bench
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import ref_harness
     assert os.path.exists(bench.REFERENCE_PYTHON_PROFILE)
     r = json.load(open(bench.REFERENCE_PYTHON_PROFILE))
     assert r['cores'] == 1 and r['value'] > 0 and 'host_cpu' in r
+    assert {d['policy'] for d in r['decision']['runs']} == {'sarl', 'sarl+om', 'cadrl', 'lstm_rl'}
+    assert r['sampling']['env_steps'] > 0 and r['crowd20']['humans'] == 20
+
+    def check(where):
+        orca = bench.reference_python_baseline()
+        assert orca['kind'] == 'reference' and orca['cores'] == 1 and orca['value'] > 0 and where in orca['host']
+        for pol in ('sarl', 'sarl+om', 'cadrl', 'lstm_rl'):
+            d = bench.reference_decision_baseline(pol)
+            assert d['unit'] == 'decisions/s' and d['cores'] == 1 and d['kind'] == 'reference' and where in d['host']
+            assert 1.0 < d['value'] < 1000.0 and 'robot.act' in d['sample']  # ~10 decisions/s/core (SURVEY §6)
+        sm = bench.reference_sampling_baseline()
+        assert sm['unit'] == 'env-steps/s' and sm['cores'] == 1 and where in sm['host'] and 1.0 < sm['value'] < 1000.0
+        est = bench.config5_schedule_estimate()
+        assert est['schedule_from'].startswith('profiles/') and est['env_steps']['rl_sample'] > 100000
+        assert est['reference_estimate_s']['rl_sample'] > 100 * est['device_s']['rl_sample']
+        assert est['reference_estimate_s']['il_collect'] > est['device_s']['il_collect']
+        return orca
+
     if ref_harness.available():
-        live = bench.reference_python_baseline(cases=12)
-        assert live['kind'] == 'reference' and live['cores'] == 1 and live['value'] > 0
-        assert 'THIS host' in live['host'] and 'env-steps' in live['sample']
-    # no reference copy (the subprocess fails): the committed figure, labelled
+        bench._REFERENCE_RUN.clear()
+        bench.reference_python_run(cases=12, decisions=2, sampling_seconds=0.5)
+        live = check('THIS host')
+        assert 'env-steps' in live['sample']
+    # no reference copy (the subprocess fails): the committed figures, labelled
+    bench._REFERENCE_RUN.clear()
     monkeypatch.setattr(bench.subprocess, 'run', lambda *a, **k: (_ for _ in ()).throw(OSError('no reference')))
-    off = bench.reference_python_baseline(cases=12)
-    assert off['value'] == r['value'] and '(build container, NOT this host)' in off['host']
-    assert 'no reference copy on this machine' in off['note']
+    off = check('(build container, NOT this host')
+    assert off['value'] == r['value'] and 'no reference copy on this machine' in off['host']
+    bench._REFERENCE_RUN.clear()
+
+
+def test_secondary_rows_carry_their_cpu_baseline(monkeypatch):
+    """the wiring of bench.secondary(): every measured row gets the reference figure of ITS quantity (stand-in measurements)"""
+    import bench
+    monkeypatch.setattr(bench, 'measure_sarl', lambda B, H, om, *a, **k: {
+        'value': 1.0, 'unit': 'env-steps/s', 'steps': 1, 'ms_per_step': 1.0, 'roofline': {'select_ms': 2.0},
+        'config': {'workload': 'w'}})
+    monkeypatch.setattr(bench, 'measure_policy_decision', lambda B, H, policy, lr: {'decisions_per_s': 1.0})
+    monkeypatch.setattr(bench, 'measure_h20', lambda B, lr: {'r12': {}})
+    monkeypatch.setattr(bench, 'measure_sample_step', lambda lr: {'value': 1.0})
+    monkeypatch.setattr(bench, 'cpu_baseline_h20', lambda: {'kind': 'port'})
+    seen = []
+    monkeypatch.setattr(bench, 'reference_decision_baseline', lambda pol: seen.append(pol) or {'policy': pol})
+    monkeypatch.setattr(bench, 'reference_sampling_baseline', lambda: {'unit': 'env-steps/s'})
+    monkeypatch.setattr(bench, 'config5_schedule_estimate', lambda: {'reference_estimate_s': {}})
+    out = bench.secondary(4096, 0)
+    assert seen == ['sarl', 'sarl+om', 'cadrl', 'lstm_rl']
+    assert out['sarl']['cpu_baseline'] == {'policy': 'sarl'} and out['om_sarl']['cpu_baseline'] == {'policy': 'sarl+om'}
+    assert out['sarl']['decisions_per_s'] == 4096 / 2e-3
+    assert out['cadrl']['cpu_baseline'] == {'policy': 'cadrl'} and out['lstm_rl']['cpu_baseline'] == {'policy': 'lstm_rl'}
+    assert out['sample_step']['cpu_baseline'] == {'unit': 'env-steps/s'} and out['h20']['cpu_baseline'] == {'kind': 'port'}
+    assert 'reference_estimate_s' in out['config5_schedule']
 
 
 def test_distributed_init_failure_names_the_ipc_switch(monkeypatch):

@@ -212,8 +212,8 @@ def test_transform_matches_host_transform(with_om):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,humans', [(1, 5), (3, 5), (16, 5), (2, 3), (40, 5)])
-def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
+@pytest.mark.parametrize('B,humans,n_act', [(1, 5, 81), (3, 5, 81), (16, 5, 81), (2, 3, 81), (40, 5, 81), (6, 1, 13), (9, 2, 5)])
+def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, monkeypatch):
     """cn_sarl_sample_step (ABI v8) = alive &= ~done; cn_sarl_select; cn_sarl_explore(mask = alive); cn_sarl_transform;
     cn_step.  Three engines on the same seeds and weights for 104 steps (every episode ends, envs leave `alive`, the epsilon-greedy
     draws continue each env's numpy stream): (a) the one call on the narrow-tile route (two launches per step — the network, then decision + transition + the
@@ -221,7 +221,9 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
     CROWDNAV_AMD_SARL_FUSED_STEP=0, three: ORCA, the network with the decision by its last workgroup, the transition; forced with
     CROWDNAV_AMD_SARL_NARROW=2: by size it is taken up to one workgroup per CU, 9 envs of 5 humans; 40 envs are 1080 tiles and
     five envs per wave of the deciding workgroup), (b) the one call with CROWDNAV_AMD_SARL_NARROW=0 (the general route inside
-    the call), (c) the five calls by hand on the one-tile kernels.  Every history is the same bits."""
+    the call), (c) the five calls by hand on the one-tile kernels.  Every history is the same bits.  The last two cases have a
+    small action table — FEWER narrow tiles than envs (6 envs x 13 actions of one human are 5 tiles, 9 x 5 of two humans
+    6): every env's replay-memory state must still be written."""
     import ctypes as C
     import crowdnav_amd
     from crowdnav_amd._lib import check
@@ -235,7 +237,7 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, monkeypatch):
         monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
         monkeypatch.setenv('CROWDNAV_AMD_SARL_FUSED_STEP', fused)
         eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=0)
-        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space[:n_act]]))
         eng.sarl_set_weights(net.state_dict())
         eng.reset(7000 + np.arange(B))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
