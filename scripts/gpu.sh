@@ -1,5 +1,5 @@
 # The ONE GPU-box runner: `gpurun -- 'bash scripts/gpu.sh <stage> [<stage> ...]'`.  Stages write under gpurun_out/<tag>/
-# (tag = $CN_TAG, default r05); summaries that matter are copied into profiles/ by hand.  Experiment builds live under
+# (tag = $CN_TAG, default r06); summaries that matter are copied into profiles/ by hand.  Experiment builds live under
 # build/exp/ (make -C crowdnav_amd/csrc exp NAME=.. DEFS=..) and are selected with CROWDNAV_AMD_LIB.
 #   tests [pytest args]   pytest -m gpu (whole suite, or the files given in $CN_TESTS)
 #   smoke                 __graft_entry__.smoke()
@@ -14,7 +14,7 @@
 #                         sarl_reg_kernel<4> and <16> (MFMA busy) -> ${TAG}_traffic.json
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp
 shopt -s nullglob
-REPO=$GRAFT_REPO_ROOT; TAG=${CN_TAG:-r05}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; cd $REPO
+REPO=$GRAFT_REPO_ROOT; TAG=${CN_TAG:-r06}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; cd $REPO
 line() { timeout 20 python scripts/bench_line.py "$1"; }
 bench() { # name, [VAR=val ...] -- args
   name=$1; shift; envs=(); while [ "$1" != "--" ] && [ $# -gt 0 ]; do envs+=("$1"); shift; done; shift

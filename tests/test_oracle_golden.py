@@ -142,3 +142,30 @@ def test_survey_known_answer_velocities(oracle_mod):
         assert tuple(out['action'][0]) == action and out['reward'][0] == 0.0
         assert ' '.join(v.tobytes().hex() for v in out['orca_vel'][0][1:]) == hexes
     assert tuple(o.get_state()[0][0][1][:2]) != (0.0, 0.0)
+
+
+def test_committed_fixtures_regenerate_bit_for_bit_from_the_unmodified_reference(tmp_path):
+    """the fixtures are not a one-off.  With the reference on this machine (/root/reference or oracle/_ref),
+    oracle/gen_golden.py — the UNMODIFIED reference Python on the float32 rvo2 restatement — rewrites traj_visible_h5.npz
+    and outcomes_500.npz into a scratch directory in a subprocess; every array must equal the committed file's bit for bit
+    and the key sets must match (no stale schema)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'oracle'))
+    import ref_harness
+    if not ref_harness.available():
+        pytest.skip('the reference is not on this machine')
+    code = ("import sys; sys.path.insert(0, %r); import gen_golden as g; g.OUT = %r; "
+            "g.trajectories('traj_visible_h5.npz', list(range(10)), robot_visible=True); g.outcomes_500()"
+            % (os.path.join(root, 'oracle'), str(tmp_path)))
+    subprocess.run([sys.executable, '-c', code], check=True, capture_output=True, timeout=300,
+                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    for name in ('traj_visible_h5.npz', 'outcomes_500.npz'):
+        new, old = dict(np.load(str(tmp_path / name))), dict(load_golden(name))
+        assert sorted(new) == sorted(old)
+        for k in new:
+            assert new[k].dtype == old[k].dtype and new[k].shape == old[k].shape and new[k].tobytes() == old[k].tobytes(), (name, k)
+    info = np.load(str(tmp_path / 'outcomes_500.npz'))['invisible_info']
+    assert np.bincount(info, minlength=5).tolist() == [0, 0, 213, 284, 3]   # the paper's ORCA row (0.43 / 0.57)
