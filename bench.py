@@ -715,6 +715,7 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
         s0 = snapshot()[0]
         fence()
         fence()
+        f0 = eng.launch_counts()['ring_fills']
         with no_gc():
             ts = time.perf_counter()
             run(args.steps)
@@ -724,7 +725,7 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
         n = int((snapshot()[0] - s0).sum().item())
         dt_max, = comm.all_reduce([dt], op='max')
         n_all, = comm.all_reduce([n])
-        samples.append(n_all / dt_max)
+        samples.append((n_all / dt_max, eng.launch_counts()['ring_fills'] - f0))
     s = [float(v) for v in summary.cpu().tolist()]
     event_spans = [(e0.elapsed_time(e1) / 1e3, n) for e0, e1, n in events]
     fill_s = None
@@ -1075,10 +1076,15 @@ def main():
         'boundary_ms': boundary * 1e3,
         'value_incl_boundary': total / (elapsed + boundary),
         'value_samples': None if not m['samples'] else {
-            'n': len(m['samples']), 'min': min(m['samples']), 'median': sorted(m['samples'])[len(m['samples']) // 2],
-            'max': max(m['samples']), 'all': m['samples'],
+            'n': len(m['samples']), 'min': min(v for v, _ in m['samples']),
+            'median': sorted(v for v, _ in m['samples'])[len(m['samples']) // 2], 'max': max(v for v, _ in m['samples']),
+            'all': [v for v, _ in m['samples']], 'ring_fills': [f for _, f in m['samples']],
+            'median_without_fill': (lambda w: sorted(w)[len(w) // 2] if w else None)([v for v, f in m['samples'] if f == 0]),
+            'median_with_fill': (lambda w: sorted(w)[len(w) // 2] if w else None)([v for v, f in m['samples'] if f > 0]),
             'note': 'further repetitions of the same %d warm-up + %d timed steps on the same engine, fenced like the first; '
-                    '`value` is the first sample' % (args.warmup, args.steps)},
+                    '`value` is the first sample.  ring_fills: scenario-ring fills inside each repetition\'s timed region (rank 0) — a '
+                    'repetition that carries one (every %d steps) is the slow mode of the spread; value_amortised_fill charges '
+                    'the steady-state share' % (args.warmup, args.steps, m['ring_depth'])},
         'value_r3_definition': None if m3 is None else m3['total'] / m3['elapsed'],
         'fill_ms': None if fill_s is None else fill_s * 1e3,
         'value_amortised_fill': amortised,
