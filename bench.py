@@ -569,9 +569,10 @@ def cpu_baseline_h20(envs=512, steps=60):
                 'sample': '%d env-steps in %.1f s; %s' % (c20['env_steps'], c20['seconds'], c20['what'])}}
 
 
-def ring_depth():
-    """depth of an engine's scenario ring (cn_create reads the same variable; default 48 episodes ahead of every env)"""
-    return max(1, int(os.environ.get('CROWDNAV_AMD_RING_DEPTH') or 48))
+def ring_depth(async_fill=False):
+    """depth of an engine's scenario ring (cn_create reads the same variable; default 48 episodes ahead of every env, 144 under
+    the asynchronous fill)"""
+    return max(1, int(os.environ.get('CROWDNAV_AMD_RING_DEPTH') or (144 if async_fill else 48)))
 
 
 def measure_fill_seconds(eng, depth):
@@ -742,7 +743,7 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
     torch.cuda.empty_cache()
     return {'elapsed': mx[0], 'boundary': mx[1], 'fill_s': mx[2] if mx[2] >= 0 else None, 'total': total, 'episodes': episodes,
             'fills_in_timed_region': fills // world if world > 1 else fills, 'events': event_spans, 'summary': s,
-            'per_rank': per_rank, 'rccl': rccl, 'ring_depth': ring_depth(), 'samples': samples}
+            'per_rank': per_rank, 'rccl': rccl, 'ring_depth': ring_depth(args.async_fill), 'samples': samples}
 
 
 def init_distributed(backend, local_rank):

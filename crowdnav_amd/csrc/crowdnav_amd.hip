@@ -119,6 +119,12 @@ int cn_create(const cn_config* c, cn_engine** out) {
     P.robot_unicycle = c->robot_kinematics == CN_UNICYCLE;
     e->async_fill = (c->flags & CN_FLAG_ASYNC_SCENARIO_FILL) != 0 && e->gen_wave;
     P.async_fill = e->async_fill ? 1 : 0;
+    // Asynchronous fill: a slot is refilled by the fill launch AFTER the call that consumed it, behind up to one call's worth of
+    // other scenarios, and a hard scenario of the reference geometry (20 humans on the 4 m circle: up to 3 M attempts) is tens
+    // of milliseconds of one wave — so the ring is the latency buffer.  Measured (r06, 4096 x 20, 999-step calls, every
+    // scenario generated afresh): depth 48 / 96 / 144 = 16 % / 3 % / 0 % of the env-steps paused.  0.6 GB of the 288.
+    if (e->async_fill && !getenv("CROWDNAV_AMD_RING_DEPTH")) P.ring_depth = 144;
+    e->fill_queue_wgs = env_int("CROWDNAV_AMD_FILL_QUEUE_WGS", 1024);  // 0: one workgroup per (env, slot) (rounds 2-5)
     P.dt = c->time_step;
     P.time_limit = c->time_limit;
     P.success_reward = c->success_reward;
@@ -167,6 +173,7 @@ int cn_create(const cn_config* c, cn_engine** out) {
         (rc = dev_alloc(e, &S.ring_ready, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ring_claim, e->async_fill ? (size_t)P.B * P.ring_depth : (size_t)1)) ||
         (rc = dev_alloc(e, &S.ep_word, (size_t)P.B)) || (rc = dev_alloc(e, &S.dyn_queue, (size_t)P.B + 1)) ||
+        (rc = dev_alloc(e, &e->fill_list, e->async_fill ? (size_t)cn_engine::kFillStreams * (2 + 2 * (size_t)P.B * P.ring_depth) : (size_t)2)) ||
         (rc = dev_alloc(e, &S.cache_pos, e->gen_wave ? (size_t)cn::kScenarioCacheMax * P.A : (size_t)1)) ||
         (rc = dev_alloc(e, &S.cache_goal, e->gen_wave ? (size_t)cn::kScenarioCacheMax * P.A : (size_t)1)) ||
         (rc = dev_alloc(e, &S.cache_rv, e->gen_wave ? (size_t)cn::kScenarioCacheMax * P.A : (size_t)1)) ||
@@ -494,15 +501,26 @@ static int fill_ring_if_needed(cn_engine* e, const cn::RolloutView& R, int n_ste
     if (e->async_fill) {
         // a fill launch per transition launch, on the next side stream, ordered after the PREVIOUS transition kernel (whose
         // episode counters it reads) and beside the one about to be launched; nobody waits for it
-        hipStream_t fs = e->fill_streams[e->next_fill_stream];
+        const int this_stream = e->next_fill_stream;
+        hipStream_t fs = e->fill_streams[this_stream];
         e->next_fill_stream = (e->next_fill_stream + 1) % cn_engine::kFillStreams;
         CN_HIP(hipEventRecord(e->rollout_done, e->stream));
         CN_HIP(hipStreamWaitEvent(fs, e->rollout_done, 0));
         // (tried and dropped: 4 workgroups per env walking its slots in order — 4.0 M instead of 20.8 M env-steps/s at the
-        // reference geometry, a workgroup stuck on a hard scenario delays its env's later slots; a claim-then-work-list pair
-        // of kernels hung on the GPU box and was not pursued)
-        hipLaunchKernelGGL(cn::ring_fill_wave_async_kernel, dim3(e->P.B * e->P.ring_depth), dim3(cn::kWave), 0, fs, e->P, e->C,
-                           e->S, R);
+        // reference geometry, a workgroup stuck on a hard scenario delays its env's later slots.  Round 2's claim-then-work-list
+        // pair of kernels "hung on the GPU box"; round 6 found why — a generator loop of the shape `for (;;) { lane 0 pops with
+        // atomicAdd; j = readfirstlane; if (j >= jobs) break; generate }` never terminates as compiled (the popping loop below is
+        // written around a ballot instead) — and the pair is now the default: CROWDNAV_AMD_FILL_QUEUE_WGS generator workgroups)
+        if (e->fill_queue_wgs > 0) {  // scan + persistent generator workgroups on a job list (step_kernels.h); the default
+            int* list = e->fill_list + (size_t)this_stream * (2 + 2 * (size_t)e->P.B * e->P.ring_depth);
+            CN_HIP(hipMemsetAsync(list, 0, 2 * sizeof(int), fs));
+            const int items = e->P.B * e->P.ring_depth;
+            hipLaunchKernelGGL(cn::ring_fill_scan_kernel, dim3((items + 255) / 256), dim3(256), 0, fs, e->P, e->S, R, list);
+            hipLaunchKernelGGL(cn::ring_fill_jobs_kernel, dim3(e->fill_queue_wgs), dim3(cn::kWave), 0, fs, e->P, e->C, e->S, R, list);
+        } else {
+            hipLaunchKernelGGL(cn::ring_fill_wave_async_kernel, dim3(e->P.B * e->P.ring_depth), dim3(cn::kWave), 0, fs, e->P, e->C,
+                               e->S, R);
+        }
         e->launch_counts[CN_COUNT_ASYNC_FILLS] += 1;
         e->steps_since_fill = 0;
         return CN_OK;

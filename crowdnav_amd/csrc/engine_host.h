@@ -59,6 +59,8 @@ struct cn_engine {
     static constexpr int kFillStreams = 8;
     bool async_fill;
     hipStream_t fill_streams[kFillStreams];
+    int* fill_list = nullptr;    // [kFillStreams][2 + 2 B D] job lists of ring_fill_scan_kernel / ring_fill_jobs_kernel, one per side stream
+    int fill_queue_wgs = 0;      // persistent generator workgroups of an asynchronous fill launch (0: one workgroup per slot)
     hipEvent_t rollout_done;
     int next_fill_stream;
     bool io_valid;

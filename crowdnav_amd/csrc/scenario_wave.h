@@ -28,19 +28,33 @@ __device__ __forceinline__ void wave_sync() { wave_lds_sync(); }
 // or three window evaluations instead of twenty.
 
 struct WaveRng {
-    uint32_t* key;   // [624] generator state (LDS)
-    uint32_t* prev;  // [2][624] the states one and two blocks earlier, or NULL (kept only when the stream is handed on)
-    uint32_t* out;   // [kWindow] tempered outputs, ring indexed by stream position % kWindow (LDS)
+    // RAW generator words of the latest two blocks: block n lives at ring + (n & 1) * 624, i.e. stream word p at ring[p % 1248];
+    // the seeded state is "block -1".  A block is generated OUT OF PLACE from the one before it (no read-after-write hazard
+    // inside a phase) and nothing is tempered until it is read: the conservative stages of the rejection test read three of an
+    // attempt's six words, the exact arithmetic reads all six of a handful of attempts.
+    uint32_t* ring;   // [2][624] (LDS)
+    uint32_t* prev2;  // [624] the block two generations back, or NULL (kept only when the stream is handed on: persist)
     uint32_t produced;  // stream words generated so far (wave-uniform)
     uint32_t cursor;    // next unread stream word (wave-uniform)
     static constexpr uint32_t kWindow = 1248;
 
+    // words base + J .. base + 63 of init_genrand into lanes J .. 63 of v (v_writelane_b32: the lane select is an inline constant;
+    // this clang has no writelane builtin, and two SGPR operands would break the constant-bus rule)
+    template <int J>
+    __device__ static __forceinline__ void seed_chunk(uint32_t& s, uint32_t& v, uint32_t base) {
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(J));
+        s = 1812433253u * (s ^ (s >> 30)) + base + (uint32_t)J + 1u;
+        if constexpr (J + 1 < 64) seed_chunk<J + 1>(s, v, base);
+    }
     __device__ void seed(uint32_t s, int lane) {
-        if (lane == 0) {
-            for (int i = 0; i < 624; ++i) {
-                key[i] = s;
-                s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
-            }
+        // init_genrand: a serial chain (word i + 1 from word i).  Sixty-four words at a time are collected in one register
+        // through v_writelane and stored with one LDS instruction.
+        uint32_t* key = ring + 624;
+        s = __builtin_amdgcn_readfirstlane(s);
+        for (int base = 0; base < 624; base += 64) {  // (the last chunk runs 16 words past the state: never stored)
+            uint32_t v = 0;
+            seed_chunk<0>(s, v, (uint32_t)base);
+            if (base + lane < 624) key[base + lane] = v;
         }
         produced = 0;
         cursor = 0;
@@ -59,39 +73,42 @@ struct WaveRng {
         return v;
     }
 
-    // Regenerate the 624-word block in place, in the three dependency-free ranges of the recurrence
-    // new[i] = new_or_old[i + 397 mod 624] ^ twist(old[i], old[i + 1]), and append its tempered words to the window.
+    // Block n from block n - 1: new[i] = (i < 227 ? old[i + 397] : new[i - 227]) ^ twist(old[i], old[i + 1]); new[623] takes
+    // new[0].  Word i = lane + 64 k is lane's k-th word: the ten twists of a lane read only the old block (all requests up
+    // front), then three dependent ranges of the recurrence.
     __device__ void next_block(int lane) {
-        if (prev) {
-            for (int i = lane; i < 624; i += 64) {
-                prev[624 + i] = prev[i];
-                prev[i] = key[i];
-            }
+        const uint32_t n = produced / 624u;
+        uint32_t* X = ring + (n & 1u) * 624u;
+        const uint32_t* O = ring + ((n + 1u) & 1u) * 624u;
+        if (prev2) {
+            for (int i = lane; i < 624; i += 64) prev2[i] = X[i];
             wave_sync();
         }
-        for (int ph = 0; ph < 3; ++ph) {
-            const int lo = ph == 0 ? 0 : (ph == 1 ? 227 : 454);
-            const int hi = ph == 0 ? 227 : (ph == 1 ? 454 : 623);
-            uint32_t v[4];
+        uint32_t tw[10];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lo + lane + 64 * k;
-                if (i < hi) {
-                    const int im = (i + 397 >= 624) ? i + 397 - 624 : i + 397;
-                    v[k] = key[im] ^ twist(key[i], key[i + 1]);
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lo + lane + 64 * k;
-                if (i < hi) key[i] = v[k];
-            }
-            wave_sync();
+        for (int k = 0; k < 10; ++k) {
+            const int i = lane + 64 * k;
+            tw[k] = i < 623 ? twist(O[i], O[i + 1]) : 0u;
         }
-        if (lane == 0) key[623] = key[396] ^ twist(key[623], key[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            if (i < 227) X[i] = O[i + 397] ^ tw[k];
+        }
         wave_sync();
-        for (int i = lane; i < 624; i += 64) out[(produced + i) % kWindow] = temper(key[i]);
+#pragma unroll
+        for (int k = 3; k < 8; ++k) {
+            const int i = lane + 64 * k;
+            if (i >= 227 && i < 454) X[i] = X[i - 227] ^ tw[k];
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 7; k < 10; ++k) {
+            const int i = lane + 64 * k;
+            if (i >= 454 && i < 623) X[i] = X[i - 227] ^ tw[k];
+        }
+        wave_sync();
+        if (lane == 0) X[623] = X[396] ^ twist(O[623], X[0]);
         produced += 624;
         wave_sync();
     }
@@ -114,7 +131,7 @@ struct WaveRng {
         }
         cursor = target;
     }
-    __device__ uint32_t word(uint32_t stream_index) const { return out[stream_index % kWindow]; }
+    __device__ uint32_t word(uint32_t stream_index) const { return temper(ring[stream_index % kWindow]); }
     // np.random.random() from the two words at stream_index
     __device__ double random_at(uint32_t stream_index) const {
         const uint32_t a = word(stream_index) >> 5, b = word(stream_index + 1) >> 6;
@@ -130,8 +147,10 @@ struct WaveRng {
         const bool drained = cursor == produced;  // also the freshly seeded generator (0 == 0)
         const int pos = drained ? 0 : (int)(cursor - kb * 624u);
         const bool in_latest = kb + 1u == latest;
+        const uint32_t* key = ring + ((latest - 1u) & 1u) * 624u;  // the latest block (the seeded state when none was generated)
+        const uint32_t* prev = ring + (latest & 1u) * 624u;        // the one before it
         const uint32_t* newer = in_latest ? key : prev;
-        const uint32_t* older = drained ? key : (in_latest ? prev : prev + 624);
+        const uint32_t* older = drained ? key : (in_latest ? prev : prev2);
         for (int i = lane; i < 624; i += 64) dst[(size_t)i * stride] = i < pos ? newer[i] : older[i];
         if (lane == 0) *pos_out = pos;
     }
@@ -140,11 +159,14 @@ struct WaveRng {
 // Shared scratch of one generator wave.  KEEP: the stream is handed on when the scenario is done (cn_reset: the env's own
 // numpy stream continues behind it), which takes the generator states of the two blocks before the current one; the ring
 // fill and rollout-begin kernels never do that, and 5 KB less per workgroup is 14 generator waves per CU instead of 9.
+// Blocked-cell table of the circle-crossing rejection test: a kGridN x kGridN bitmap over the square the attempts can fall in.
+constexpr int kGridN = 160;
+constexpr int kGridRowWords = kGridN / 32;
 template <bool KEEP>
 struct WaveScratchT {
-    uint32_t key[624];
-    uint32_t prev[KEEP ? 2 * 624 : 2];
-    uint32_t out[WaveRng::kWindow];
+    uint32_t ring[WaveRng::kWindow];   // raw generator words of the latest two blocks
+    uint32_t prev2[KEEP ? 624 : 2];
+    uint32_t grid[kGridN * kGridRowWords];
     double2 ppos[64];
     double2 pgoal[64];
     double prad[64];
@@ -155,16 +177,73 @@ struct WaveScratchT {
 using WaveScratch = WaveScratchT<true>;
 using WaveScratchFill = WaveScratchT<false>;
 
-// Conservative float32 prefilter of the circle-crossing rejection test (crowd_sim.py:159-175).  On the reference's own
-// geometry (20 humans on the 4 m circle) the last humans of a scenario are accepted once in 10^3..10^4 attempts: almost every
-// attempt lies DEEP inside some placed agent's exclusion disc, and deciding that does not need the float64 cos / sin and the
-// up to 38 exact float64 distance tests of the reference arithmetic.  An attempt is rejected here only if its float32
-// position is closer than min_dist - margin to a placed position or goal; the float32 position is within
-// 2e-6 (R + 2) m of the float64 one (angle: 27 of 53 random bits, rounded to 24: 5e-7 rad; cosf / sinf: 2 ulp; the sums
-// and differences: a few ulp of R + 1), and margin = 2e-5 (R + 2) m is ten times that — so every attempt rejected here is
-// rejected by the exact test, and a pass of 64 attempts without a survivor moves the cursor on exactly as the exact path
-// would.  Survivors (and the give-up rule) go through the exact path unchanged: same stream, same decisions, same bits.
-__device__ __forceinline__ float prefilter_margin(double R) { return 2.0e-5f * ((float)R + 2.0f); }
+// Conservative float32 stages of the circle-crossing rejection test (crowd_sim.py:159-175).  On the reference's own geometry
+// (20 humans on the 4 m circle) the last humans of a scenario are accepted once in 10^3..10^4 attempts: almost every attempt
+// lies DEEP inside some placed agent's exclusion disc, and deciding that needs neither the float64 cos / sin nor the up to 38
+// exact float64 distance tests of the reference arithmetic.
+//
+// The float32 position of an attempt: angle fraction = the top 27 bits of the attempt's first word (of the 53 the reference
+// uses), cos / sin by the hardware's V_COS_F32 / V_SIN_F32 (input in revolutions), noise from the top 27 bits of its third and
+// fifth word.  Its distance from the float64 position is bounded by kTrigAbsError * R (measured exhaustively over all 2^27
+// fractions: scripts/probes/trig_error.hip, tests/test_generator_trig.py) + 2 pi R 2^-27 (angle truncation) + a few ulp of R + 1.
+//
+// Stage 1, the BLOCKED-CELL TABLE: a bitmap over the square [-ext, ext]^2 (ext = R + v_pref / 2 + three cells); a cell's bit is
+// set when the WHOLE cell lies within min_dist - table_margin of a placed position or goal — marked row by row when an agent
+// is placed (one lane per grid row: the blocked x-interval of the row, conservatively rounded, OR-ed into the row's words).
+// An attempt whose float32 position falls in a set cell is rejected: 0.2 % of the attempts survive at R = 4 (cell 5.7 cm).
+// Stage 2: a survivor's float32 position against every placed point (one lane per placed agent), rejected if closer than
+// min_dist - margin.  Stage 3: the reference arithmetic, again one lane per placed agent.  margin and table_margin are ten
+// times the error bounds, so whatever stages 1 and 2 reject the exact test rejects, survivors are decided by the exact test,
+// and they are examined in stream order: same stream, same decisions, same bits as the sequential loop.
+constexpr float kTrigAbsError = 1.0e-5f;  // |V_COS_F32(f) - cos(2 pi f)|, same for sin, f in [0, 1): bound asserted by the probe
+__device__ __forceinline__ float prefilter_margin(double R) { return 10.0f * (kTrigAbsError * (float)R + 1.0e-6f * ((float)R + 2.0f)); }
+
+struct BlockedGrid {
+    uint32_t* bits;
+    float ext, inv_cell, cell;
+    __device__ void init(uint32_t* g, double R, double v_pref, int lane) {
+        bits = g;
+        ext = (float)(R + 0.5 * v_pref) / (1.0f - 6.0f / (float)kGridN);
+        cell = 2.0f * ext / (float)kGridN;
+        inv_cell = (float)kGridN / (2.0f * ext);
+        for (int i = lane; i < kGridN * kGridRowWords; i += 64) bits[i] = 0u;
+    }
+    // word index and bit of the cell a float32 position falls in
+    __device__ void locate(float x, float y, int& word, uint32_t& bit) const {
+        int ix = (int)((x + ext) * inv_cell), iy = (int)((y + ext) * inv_cell);
+        ix = ix < 0 ? 0 : (ix > kGridN - 1 ? kGridN - 1 : ix);
+        iy = iy < 0 ? 0 : (iy > kGridN - 1 ? kGridN - 1 : iy);
+        word = iy * kGridRowWords + (ix >> 5);
+        bit = 1u << (ix & 31);
+    }
+    // mark the cells that lie entirely inside the disc of radius rt around (cx, cy); `sub` of `nsub` lane groups share the rows
+    __device__ void mark(float cx, float cy, float rt, int sub, int nsub) {
+        const int iy0 = (int)floorf((cy - rt + ext) * inv_cell), iy1 = (int)floorf((cy + rt + ext) * inv_cell);
+        const float rt2 = rt * rt;
+        for (int iy = iy0 + sub; iy <= iy1; iy += nsub) {
+            if (iy < 0 || iy >= kGridN) continue;
+            const float y0 = (float)iy * cell - ext;
+            const float dy = fmaxf(fabsf(y0 - cy), fabsf(y0 + cell - cy));
+            const float w2 = rt2 - dy * dy;
+            if (!(w2 > 0.0f)) continue;
+            const float w = sqrtf(w2) * (1.0f - 1.0e-6f);
+            int lo = (int)ceilf((cx - w + ext) * inv_cell), hi = (int)floorf((cx + w + ext) * inv_cell);  // cells [lo, hi)
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > kGridN ? kGridN : hi;
+#pragma unroll
+            for (int wd = 0; wd < kGridRowWords; ++wd) {
+                const int a = lo > 32 * wd ? lo : 32 * wd, b = hi < 32 * wd + 32 ? hi : 32 * wd + 32;
+                if (a < b) {
+                    const uint32_t m = (b - a == 32 ? 0xffffffffu : ((1u << (b - a)) - 1u)) << (a - 32 * wd);
+                    atomicOr(&bits[iy * kGridRowWords + wd], m);
+                }
+            }
+        }
+    }
+};
+// table_margin: position error (as for prefilter_margin) + the table's own float32 rounding (cell bounds, interval ends: a few
+// ulp of ext) — ten-fold
+__device__ __forceinline__ float table_margin(double R) { return prefilter_margin(R) + 1.0e-4f; }
 
 // Builds agents [0, A) at pos/vel/goal/rv[base + agent] (vel may be NULL); returns np.random.random() calls consumed.
 // Must be called by all 64 lanes of a one-wave workgroup.
@@ -176,7 +255,7 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
                                                   int* mt_pos_out = nullptr) {
     const double kPi = 3.141592653589793;
     const int lane = threadIdx.x & 63;
-    WaveRng rng{s.key, mt_key_out ? s.prev : nullptr, s.out, 0, 0};
+    WaveRng rng{s.ring, mt_key_out ? s.prev2 : nullptr, 0, 0};
     rng.seed(seed, lane);
     const int A = c.num_agents;
     const double R = c.circle_radius;
@@ -194,9 +273,12 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
     wave_sync();
     // window state of the window-reuse path (circle crossing, fixed attributes): lane l holds the attempt at stream position
     // rng.cursor + 6 l once `win` is set; lanes below wstart belong to humans already placed
-    bool win = false, w_collide = true;
-    int wstart = 0;
-    double w_x = 0.0, w_y = 0.0;
+    bool win = false, w_blocked = true;
+    int wstart = 0, w_word = 0;
+    uint32_t w_bit = 0u;
+    float w_fx = 0.0f, w_fy = 0.0f;
+    BlockedGrid grid{};
+    const float tmargin = table_margin(R);
     for (int i = 1; i < A; ++i) {
         double radius = c.human_radius, v_pref = c.human_v_pref;
         if (c.randomize) {
@@ -213,47 +295,26 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
             const unsigned long long N = ((c.max_attempts + 63ull) / 64ull) * 64ull;
             const uint32_t hstart = rng.cursor + (win ? 6u * wstart : 0u);  // stream position of this human's first attempt
             unsigned long long tried = 0;
+            if (i == 1) {  // the table, with the robot's start and goal marked (lanes 0-31 / 32-63: the two discs' rows)
+                grid.init(s.grid, R, v_pref, lane);
+                wave_sync();
+                const float rt = (float)(radius + c.robot_radius + c.discomfort_dist) - tmargin;
+                if (rt > 0.0f) grid.mark(0.0f, lane < 32 ? -Rf : Rf, rt, lane & 31, 32);
+            }
             if (lane == i - 1) {  // the prefilter's threshold against the agent placed last (same for every later human)
                 const float t = (float)(radius + s.prad[lane] + c.discomfort_dist) - margin;
                 s.fthr2[lane] = t > 0.0f ? t * t : 0.0f;
             }
             wave_sync();
             for (;;) {
-                if (!win) {  // evaluate the 64 attempts at the cursor against everybody placed so far
+                if (!win) {  // the 64 attempts at the cursor: float32 position, blocked-cell table
                     rng.ensure(6 * 64, lane);
-                    const uint32_t at = rng.cursor + 6u * lane;
-                    bool inside = false;
-                    {
-                        const float frac = (float)(rng.word(at) >> 5) * 0x1p-27f;
-                        float sn, cs;
-                        sincosf(frac * 6.2831855f, &sn, &cs);
-                        const float fx = Rf * cs + ((float)(rng.word(at + 2) >> 5) * 0x1p-27f - 0.5f) * vpf;
-                        const float fy = Rf * sn + ((float)(rng.word(at + 4) >> 5) * 0x1p-27f - 0.5f) * vpf;
-                        for (int k = 0; k < i; ++k) {
-                            const float4 q = s.fpg[k];
-                            const float t2 = s.fthr2[k];
-                            const float ax = fx - q.x, ay = fy - q.y, bx = fx - q.z, by = fy - q.w;
-                            inside = inside | (ax * ax + ay * ay < t2) | (bx * bx + by * by < t2);
-                        }
-                    }
-                    w_collide = true;
-                    if (__ballot(!inside) != 0ull) {  // somebody may be free: the reference arithmetic
-                        const double angle = rng.random_at(at) * kPi * 2;
-                        const double nx = (rng.random_at(at + 2) - 0.5) * v_pref;
-                        const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
-                        w_x = R * cos(angle) + nx;
-                        w_y = R * sin(angle) + ny;
-                        w_collide = inside;
-                        if (!inside)
-                            for (int k = 0; k < i; ++k) {
-                                const double2 p = s.ppos[k], g = s.pgoal[k];
-                                const double min_dist = radius + s.prad[k] + c.discomfort_dist;
-                                if (closer_than(w_x - p.x, w_y - p.y, min_dist) || closer_than(w_x - g.x, w_y - g.y, min_dist)) {
-                                    w_collide = true;
-                                    break;
-                                }
-                            }
-                    }
+                    const uint32_t at = (rng.cursor + 6u * lane) % WaveRng::kWindow;  // (6 | 1248: an attempt's words do not wrap)
+                    const float frac = (float)(WaveRng::temper(rng.ring[at]) >> 5) * 0x1p-27f;
+                    w_fx = Rf * __builtin_amdgcn_cosf(frac) + ((float)(WaveRng::temper(rng.ring[at + 2]) >> 5) * 0x1p-27f - 0.5f) * vpf;
+                    w_fy = Rf * __builtin_amdgcn_sinf(frac) + ((float)(WaveRng::temper(rng.ring[at + 4]) >> 5) * 0x1p-27f - 0.5f) * vpf;
+                    grid.locate(w_fx, w_fy, w_word, w_bit);
+                    w_blocked = (s.grid[w_word] & w_bit) != 0u;
                     win = true, wstart = 0;
                 }
                 const unsigned long long left = N - tried;  // attempts this human may still examine
@@ -267,23 +328,52 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
                     const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
                     s.giveup = make_double2(R * cos(angle) + nx, R * sin(angle) + ny);
                 }
-                const unsigned long long ok = __ballot(mine && !w_collide);
-                if (ok) {
-                    const int first = __ffsll((long long)ok) - 1;
-                    if (lane == first) {
-                        s.ppos[i] = make_double2(w_x, w_y);
-                        s.pgoal[i] = make_double2(-w_x, -w_y);
-                        s.fpg[i] = make_float4((float)w_x, (float)w_y, (float)-w_x, (float)-w_y);
+                // the table's survivors one by one, in stream order, every placed agent on its own lane
+                unsigned long long cand = __ballot(mine && !w_blocked);
+                int first = -1;
+                double x = 0.0, y = 0.0;
+                while (cand) {
+                    const int L = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1ull;
+                    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_fx), L));
+                    const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_fy), L));
+                    bool inside = false;
+                    if (lane < i) {
+                        const float4 q = s.fpg[lane];
+                        const float t2 = s.fthr2[lane];
+                        const float ax = sx - q.x, ay = sy - q.y, bx = sx - q.z, by = sy - q.w;
+                        inside = (ax * ax + ay * ay < t2) | (bx * bx + by * by < t2);
+                    }
+                    if (__ballot(inside) != 0ull) continue;  // deep inside somebody's disc
+                    const uint32_t at = rng.cursor + 6u * (uint32_t)L;  // the reference arithmetic (wave-uniform values)
+                    const double angle = rng.random_at(at) * kPi * 2;
+                    const double nx = (rng.random_at(at + 2) - 0.5) * v_pref;
+                    const double ny = (rng.random_at(at + 4) - 0.5) * v_pref;
+                    x = R * cos(angle) + nx;
+                    y = R * sin(angle) + ny;
+                    bool collide = false;
+                    if (lane < i) {
+                        const double2 p = s.ppos[lane], g = s.pgoal[lane];
+                        const double min_dist = radius + s.prad[lane] + c.discomfort_dist;
+                        collide = closer_than(x - p.x, y - p.y, min_dist) || closer_than(x - g.x, y - g.y, min_dist);
+                    }
+                    if (__ballot(collide) != 0ull) continue;
+                    first = L;
+                    break;
+                }
+                if (first >= 0) {
+                    if (lane == 0) {
+                        s.ppos[i] = make_double2(x, y);
+                        s.pgoal[i] = make_double2(-x, -y);
+                        s.fpg[i] = make_float4((float)x, (float)y, (float)-x, (float)-y);
                         s.prad[i] = radius;
                     }
+                    // the new human's two discs into the table; the lanes behind the accepted attempt are the next human's
+                    // first attempts: all they still have to clear is this human — they look their cell up again
+                    const float rt = (float)(radius + radius + c.discomfort_dist) - tmargin;
+                    if (rt > 0.0f && i + 1 < A) grid.mark(lane < 32 ? (float)x : (float)-x, lane < 32 ? (float)y : (float)-y, rt, lane & 31, 32);
                     wave_sync();
-                    // the lanes behind the accepted attempt are the next human's first attempts: what they still have to clear
-                    // is this human (same expression as the loop above, with prad[i] = radius)
-                    if (lane > first && !w_collide) {
-                        const double2 p = s.ppos[i], g = s.pgoal[i];
-                        const double min_dist = radius + s.prad[i] + c.discomfort_dist;
-                        w_collide = closer_than(w_x - p.x, w_y - p.y, min_dist) || closer_than(w_x - g.x, w_y - g.y, min_dist);
-                    }
+                    w_blocked = w_blocked || (s.grid[w_word] & w_bit) != 0u;
                     wstart = first + 1;
                     if (wstart == 64) rng.cursor += 6u * 64, win = false, wstart = 0;
                     break;
@@ -292,14 +382,16 @@ __device__ inline uint64_t generate_scenario_wave(const ScenarioCfg& c, Scratch&
                 tried += span < left ? span : left;
                 if (tried >= N) {  // give up like nobody would: take the first candidate of the last pass of 64, flag it
                     wave_sync();
+                    const double gx = s.giveup.x, gy = s.giveup.y;
                     if (lane == 0) {
-                        const double x = s.giveup.x, y = s.giveup.y;
-                        s.ppos[i] = make_double2(x, y);
-                        s.pgoal[i] = make_double2(-x, -y);
-                        s.fpg[i] = make_float4((float)x, (float)y, (float)-x, (float)-y);
+                        s.ppos[i] = make_double2(gx, gy);
+                        s.pgoal[i] = make_double2(-gx, -gy);
+                        s.fpg[i] = make_float4((float)gx, (float)gy, (float)-gx, (float)-gy);
                         s.prad[i] = radius;
                         *c.error = 1;
                     }
+                    const float rt = (float)(radius + radius + c.discomfort_dist) - tmargin;
+                    if (rt > 0.0f && i + 1 < A) grid.mark(lane < 32 ? (float)gx : (float)-gx, lane < 32 ? (float)gy : (float)-gy, rt, lane & 31, 32);
                     rng.rewind_to(seed, hstart + 6u * (uint32_t)(N - 64ull + 1ull), lane);
                     win = false, wstart = 0;
                     break;

@@ -1426,6 +1426,81 @@ __global__ __launch_bounds__(kWave) void ring_fill_wave_async_kernel(Params P, S
     if (threadIdx.x == 0) __hip_atomic_store(&S.ring_ready[idx], ordinal + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same fill as a WORK LIST (round 6; the default) instead of one workgroup per (env, slot) — 4096 x 144 = 590 k workgroups of
+// which a fifth have something to do cost a 999-step call 4.5 ms of dispatch beside its transition kernel.  Two launches on the
+// fill stream: ring_fill_scan_kernel examines the (env, urgency) items — urgency u = how many episodes ahead of the env's next
+// one the scenario lies — one per lane, claims the slots exactly as above and appends the claimed (env, ordinal) pairs to a job
+// list, URGENCY-MAJOR (every env's nearest missing scenario before anybody's far one: a hard scenario — tens of milliseconds
+// of one wave — far ahead in the ring has the whole ring's worth of steps to finish); ring_fill_jobs_kernel is a fixed grid of
+// persistent one-wave generator workgroups that pop kFillJobBatch jobs at a time.  No workgroup ever waits for another one.
+// Measured (r06, 4096 x 20 on the 4 m circle, 999-step calls): every scenario generated afresh 91.9 -> 94.3 M env-steps/s,
+// scenario cache on 125.2 -> 139.4 M; 256 / 512 / 1024 / 2048 generator workgroups: 74.7 / 86.3 / 94.3 / 89.1 M.
+//   list: int [2 + 2 * B * D]: [0] jobs appended, [1] jobs popped, then the (env, ordinal) pairs; [0] and [1] are zeroed on the
+//   fill stream in front of the scan (one list per side stream: fill launches overlap)
+__global__ __launch_bounds__(256) void ring_fill_scan_kernel(Params P, StateView S, RolloutView R, int* list) {
+    const int D = P.ring_depth;
+    const int total = P.B * D;
+    const cn_rollout_io* io = R.io;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = item / P.B, b = item - u * P.B;
+    int ordinal = 0;
+    bool claimed = false;
+    if (item < total) {
+        const int word = __hip_atomic_load(&S.ep_word[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (state, episodes finished)
+        const int state = word & 3;
+        if (state != kRetired) {
+            ordinal = (word >> 2) + (state == kWaitingScenario ? 0 : 1) + u;
+            const int64_t c = episode_id(*io, b, ordinal);
+            if (!(io->episode_limit >= 0 && c >= io->episode_limit)) {
+                const int idx = b * D + ordinal % D, want = ordinal + 1;
+                const int have = S.ring_claim[idx];
+                claimed = have < want && atomicCAS(&S.ring_claim[idx], have, want) == have;
+            }
+        }
+    }
+    // one atomic per wave: the wave's claimed items go to consecutive list entries in lane (= env) order
+    const unsigned long long m = __ballot(claimed);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&list[0], __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (claimed) {
+        const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+        list[2 + 2 * k] = b;
+        list[3 + 2 * k] = ordinal;
+    }
+}
+
+constexpr int kFillJobBatch = 4;  // jobs a generator workgroup pops at a time
+__global__ __launch_bounds__(kWave) void ring_fill_jobs_kernel(Params P, ScenarioCfg C, StateView S, RolloutView R, int* list) {
+    __shared__ WaveScratchFill scratch;
+    const int lane = threadIdx.x;
+    const int D = P.ring_depth;
+    const cn_rollout_io* io = R.io;
+    const int jobs = list[0];  // (complete: the scan kernel ran in front of this one on the same stream)
+    int first = 0;
+    do {
+        if (lane == 0) first = atomicAdd(&list[1], kFillJobBatch);
+        first = __shfl(first, 0);
+        // lane l < kFillJobBatch holds job first + l; the batch's scenarios are generated one after the other by the whole wave
+        int jb = 0, jord = 0;
+        const bool have = lane < kFillJobBatch && first + lane < jobs;
+        if (have) jb = list[2 + 2 * (first + lane)], jord = list[3 + 2 * (first + lane)];
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int b = __shfl(jb, src), ord = __shfl(jord, src);
+            const int idx = b * D + ord % D;
+            cached_scenario_wave(P, C, S, scratch, *io, episode_id(*io, b, ord), (size_t)idx * P.A);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (a cached copy is written by A lanes, not by lane 0 alone)
+            __syncthreads();
+            if (lane == 0) __hip_atomic_store(&S.ring_ready[idx], ord + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } while (first + kFillJobBatch < jobs);
+}
+
 // Is scenario `ordinal` of env b resident?  Synchronous fill: the launch-time fill level; asynchronous: the slot's own flag
 // (acquire at device scope: the scenario data written by the concurrently running fill kernel is visible after it).
 __device__ __forceinline__ bool scenario_ready(const Params& P, const StateView& S, int env, int ordinal, int ring_filled) {

@@ -116,5 +116,12 @@ h20ab)
     ( export CROWDNAV_AMD_LIB=$lib; timeout 120 python scripts/reset_probe.py 22 2>&1 | grep "reset ms" | sed "s/^/$n: /" | tee -a $OUT/reset_probe.txt )
   done
   for envs in ${CN_H20_ENVS:-}; do bench h20_intree_r12_envs$envs -- --no-cpu-baseline --humans 20 --circle-radius 12 --envs $envs --steps 1500 --warmup 500 --chunk 500; done ;;
+gen)
+  # the scenario generators: trig bound, parity of everything that resets, and the 20-human shard with every scenario generated afresh
+  mkdir -p build/exp; hipcc --offload-arch=gfx950 -O2 scripts/probes/trig_error.hip -o build/exp/trig_error 2>/dev/null && build/exp/trig_error | tee $OUT/trig_error.txt
+  timeout 900 python -m pytest tests/test_generator_trig.py tests/test_gpu_parity.py tests/test_shard20.py tests/test_ring_wrap.py tests/test_mixed.py tests/test_bench_size_parity.py tests/test_big_crowds.py -m gpu -q -x 2>&1 | grep -vE "version|Hostname|Librccl|amdgpu.ids" | tail -8
+  bench bench_h20_r4_async_nocache CROWDNAV_AMD_SCENARIO_CACHE=0 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill
+  bench bench_h20_r4_async_train CROWDNAV_AMD_SCENARIO_CACHE=0 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 5994 --warmup 402 --chunk 999 --preroll 99 --async-fill
+  ( timeout 120 python scripts/reset_probe.py 22 2>&1 | grep "reset ms" | tee $OUT/reset_probe.txt ) ;;
 *) echo "unknown stage $stage" ;;
 esac; done
