@@ -123,5 +123,27 @@ gen)
   bench bench_h20_r4_async_nocache CROWDNAV_AMD_SCENARIO_CACHE=0 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 7992 --warmup 402 --chunk 999 --preroll 99 --seed-base 1000 --seed-mod 1021 --async-fill
   bench bench_h20_r4_async_train CROWDNAV_AMD_SCENARIO_CACHE=0 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 5994 --warmup 402 --chunk 999 --preroll 99 --async-fill
   ( timeout 120 python scripts/reset_probe.py 22 2>&1 | grep "reset ms" | tee $OUT/reset_probe.txt ) ;;
+pmcnet)
+  # MFMA-pipe counters of the four value networks (one --pmc pass each) + their kernel-trace durations: SQ_VALU_MFMA_BUSY_CYCLES
+  # over the SIMD-cycles of the kernel = how busy the matrix pipe is in EXECUTED terms (padding included)
+  MF="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+  declare -A NET
+  NET[sarl]="$REPO/scripts/sarl_bench.py --iters 3"; NET[om_sarl]="$REPO/scripts/sarl_bench.py --iters 3 --om 1"
+  NET[cadrl]="$REPO/scripts/policy_bench.py --policy cadrl --iters 3"; NET[lstm_rl]="$REPO/scripts/policy_bench.py --policy lstm_rl --iters 3"
+  for v in sarl om_sarl cadrl lstm_rl; do
+    prof pmc_${v}_mfma --pmc $MF --output-format csv -d $OUT/pmc_${v}_mfma -o p -- python ${NET[$v]}
+    prof trace_${v} --kernel-trace --stats --output-format csv -d $OUT/trace_${v} -o trace -- python ${NET[$v]}
+  done
+  python scripts/mfma_busy.py $OUT | tee $OUT/pmc_networks_summary.txt ;;
+flips)
+  rm -f $OUT/argmax_flips.jsonl
+  CROWDNAV_AMD_ARGMAX_REPORT=$OUT/argmax_flips.jsonl timeout 600 python -m pytest tests/test_sarl.py tests/test_big_crowds.py tests/test_noquery.py tests/test_mixed.py -m gpu -q 2>&1 | tail -n 2
+  python - <<PY
+import json
+rows = [json.loads(l) for l in open('$OUT/argmax_flips.jsonl')]
+print('decisions', sum(r['decisions'] for r in rows), 'arg-max flips vs the reference', sum(r['argmax_flips'] for r in rows))
+for r in rows: print(' %-110s %4d decisions %3d flips  largest reference gap of a flip %.2e' % (r['fixture'][:110], r['decisions'], r['argmax_flips'], r['largest_reference_gap_of_a_flip']))
+PY
+  ;;
 *) echo "unknown stage $stage" ;;
 esac; done

@@ -21,6 +21,27 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 
 
+def report_argmax(fixture, best, ref_best, ref_values, route=''):
+    """VERDICT r5 weak #1b: how many decisions of a reference fixture the device picks differently (the tests assert equality
+    only where the reference's own top-2 gap exceeds the value tolerance).  Returns (decisions, flips, largest reference gap
+    between the reference's pick and the device's); with CROWDNAV_AMD_ARGMAX_REPORT=<file> one JSON line per call is appended."""
+    import json
+    best, ref_best, ref_values = np.asarray(best), np.asarray(ref_best), np.asarray(ref_values)
+    n = len(ref_best)
+    ok = (best >= 0) & (ref_best >= 0)
+    differ = ok & (best != ref_best)
+    rows = np.arange(n)
+    gap = np.zeros(n)
+    gap[differ] = ref_values[rows[differ], ref_best[differ]] - ref_values[rows[differ], best[differ]]
+    rec = {'fixture': fixture, 'route': route, 'decisions': int(n), 'argmax_flips': int(differ.sum()),
+           'largest_reference_gap_of_a_flip': float(gap.max()) if differ.any() else 0.0}
+    path = os.environ.get('CROWDNAV_AMD_ARGMAX_REPORT')
+    if path:
+        with open(path, 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    return rec['decisions'], rec['argmax_flips'], rec['largest_reference_gap_of_a_flip']
+
+
 def episodes_of(g):
     """Split a packed trajectory fixture (oracle/gen_golden.py: pack) into per-episode dicts."""
     out, s0, a0 = [], 0, 0

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, report_argmax
 
 
 def _load(net, g):
@@ -32,6 +32,7 @@ def _check(eng, out, g):
     assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
     assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), cpu(out['best']), g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= 1 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
 
@@ -136,6 +137,7 @@ def _check_unicycle(eng, out, g):
     assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
     assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), cpu(out['best']), g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= len(g['states']) // 4 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
     assert np.array_equal(cpu(out['action'])[clear], g['action'][clear])

@@ -4,7 +4,7 @@ keep 5 human slots; humans the rule left out are parked far away, behind the pre
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, report_argmax
 
 FIXTURES = ['mixed.npz', 'mixed_invisible.npz']
 SLOTS = 5
@@ -232,6 +232,7 @@ def test_value_networks_mask_the_absent_humans_of_a_mixed_episode(policy, kernel
     values = out['values'].cpu().numpy()
     assert np.abs(values - g[pre + 'values']).max() <= 1e-6
     top2 = np.sort(g[pre + 'values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), out['best'].cpu().numpy(), g[pre + 'best'], g[pre + 'values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= n // 4
     assert np.array_equal(out['best'].cpu().numpy()[clear], g[pre + 'best'][clear])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, report_argmax
 
 FIXTURES = ['sarl_plain.npz', 'sarl_om.npz']
 SELECT_FIXTURES = FIXTURES + ['sarl_h12.npz']  # 12 humans: more than a tile's LDS holds, streamed in chunks of 5
@@ -71,6 +71,7 @@ def test_sarl_select_vs_reference(name):
     assert np.abs(values - g["values"]).max() <= 1e-6
     best = cpu(out['best'])
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), best, g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-5
     assert clear.sum() >= n // 4
     assert np.array_equal(best[clear], g['best'][clear])
@@ -627,6 +628,7 @@ def test_cadrl_select_vs_reference():
     assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
     assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), cpu(out['best']), g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= n // 2 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
     assert np.array_equal(cpu(out['action'])[clear], g['action'][clear])
@@ -687,6 +689,7 @@ def test_lstm_rl_select_vs_reference():
     assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
     assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), cpu(out['best']), g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= n // 4 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
 
@@ -730,6 +733,7 @@ def test_lstm_rl_pairwise_select_vs_reference():
     assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
     assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), cpu(out['best']), g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= n // 4 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
 
@@ -755,6 +759,7 @@ def test_sarl_unicycle_select_vs_reference():
     assert np.abs(cpu(eng.sarl_export('V')) - g['net_out']).max() <= 1e-6
     assert np.abs(cpu(out['values']) - g['values']).max() <= 1e-6
     top2 = np.sort(g['values'], axis=1)[:, -2:]
+    import os as _os; report_argmax(_os.environ.get('PYTEST_CURRENT_TEST', ''), cpu(out['best']), g['best'], g['values'])
     clear = (top2[:, 1] - top2[:, 0]) > 4e-6
     assert clear.sum() >= n // 4 and np.array_equal(cpu(out['best'])[clear], g['best'][clear])
     assert np.array_equal(cpu(out['action'])[clear], g['action'][clear])
