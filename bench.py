@@ -430,7 +430,7 @@ def measure_policy_decision(B, H, policy, local_rank, iters=20):
                          'note': 'algorithmic flops (unpadded layer widths) over the HIP-event time of cn_sarl_select'}}
 
 
-def measure_sample_step(local_rank, envs=1, steps=100, repeats=5):
+def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False):
     """BASELINE configs[4]'s in-scope piece: one train-phase sampling step (train.py:156-170 -> explorer.py:56-65 with
     multi_human_rl.py:11-63 behind robot.act) of ONE env — cn_sarl_sample_step streamed `steps` times without a host check,
     HIP events around the stream, the median of `repeats` episodes.  SARL at the shipped widths, 5 humans, 81 actions, random-init
@@ -442,12 +442,13 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5):
     eng = crowdnav_amd.BatchedCrowdSim(num_envs=envs, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=0,
                                        device=local_rank)
     torch.manual_seed(0)
-    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    D = 61 if with_om else 13
+    net = ValueNetwork(D, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
     space, _, _ = build_action_space(1.0)
-    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
     eng.sarl_set_weights(net.state_dict())
     z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
-    traj, rew, inf, dmn = (z((envs, steps, 5, 13), torch.float32), z((steps, envs), torch.float64), z((steps, envs), torch.uint8),
+    traj, rew, inf, dmn = (z((envs, steps, 5, D), torch.float32), z((steps, envs), torch.float64), z((steps, envs), torch.uint8),
                            z((steps, envs), torch.float64))
     act, alive, done, action = z((steps, envs), torch.int32), z((envs,), torch.uint8), z((envs,), torch.uint8), z((envs, 2), torch.float64)
     step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
@@ -465,14 +466,18 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5):
             b.record()
             torch.cuda.synchronize()
         times.append(a.elapsed_time(b) / 1e3 / steps)
+    counts = eng.launch_counts()
     eng.close()
     del eng
     torch.cuda.empty_cache()
     per_step = sorted(times[1:])[len(times[1:]) // 2]
-    return {'workload': '%d env x 5 humans, 81 actions, SARL: cn_sarl_sample_step (decision + epsilon-greedy + replay state + '
-                        'transition), %d steps streamed' % (envs, steps),
+    calls = (repeats + 1) * steps
+    return {'workload': '%d env x 5 humans, 81 actions, %s: cn_sarl_sample_step (decision + epsilon-greedy + replay state + '
+                        'transition), %d steps streamed' % (envs, 'OM-SARL (occupancy maps)' if with_om else 'SARL', steps),
             'value': envs / per_step, 'unit': 'env-steps/s', 'us_per_step': per_step * 1e6,
-            'launches_per_step': 2, 'kernels': 'cn::sarl_narrow_kernel (value network on 27 workgroups, reward, replay state), '
+            'launches_per_step': 2 if (counts['sarl_narrow'], counts['sarl_decide_steps']) == (calls, calls) else None,
+            'launch_counts': {k: counts[k] for k in ('sarl_narrow', 'sarl_decide_steps')}, 'calls': calls,
+            'kernels': 'cn::sarl_narrow_kernel (value network on 27 workgroups, reward, replay state), '
                                                'cn::sarl_decide_step_kernel (arg-max, draw, transition, next ORCA)',
             'note': 'round 4: ten launches, 70-80 us per step; the reference schedule of configs[4] samples 10 000 episodes this way '
                     '(profiles/r05_config5_reference_schedule.json: weight re-pack / reset / read-back / TD targets included)'}
@@ -496,6 +501,7 @@ def secondary(B, local_rank):
     out['h20']['cpu_baseline'] = cpu_baseline_h20()
     out['sample_step'] = measure_sample_step(local_rank)
     out['sample_step']['cpu_baseline'] = reference_sampling_baseline()
+    out['sample_step']['om_sarl'] = measure_sample_step(local_rank, with_om=True)
     out['config5_schedule'] = config5_schedule_estimate()
     return out
 

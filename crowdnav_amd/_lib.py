@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CROWDNAV_AMD_LIB: another build of the same library (kernel A/B experiments, scripts/gpu_ab.sh); default in-tree
 LIB_PATH = os.environ.get('CROWDNAV_AMD_LIB') or os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
@@ -19,7 +19,7 @@ ROBOT_EXTERNAL, ROBOT_ORCA = 0, 1
 CIRCLE_CROSSING, SQUARE_CROSSING, MIXED = 0, 1, 2
 HOLONOMIC, UNICYCLE = 0, 1
 RECORD_FIELDS, SUMMARY_FIELDS = 6, 8
-LAUNCH_COUNTERS = ('rollout_kernels', 'scheduled_kernels', 'ring_fills', 'async_fills')  # CN_COUNT_*
+LAUNCH_COUNTERS = ('rollout_kernels', 'scheduled_kernels', 'ring_fills', 'async_fills', 'sarl_narrow', 'sarl_decide_steps')  # CN_COUNT_*
 FLAG_ASYNC_SCENARIO_FILL = 1
 
 

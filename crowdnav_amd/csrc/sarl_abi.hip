@@ -285,7 +285,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->narrow_tiles = per_tile ? (s->n_groups + per_tile - 1) / per_tile : 0;
         s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
         s->fused_step = env_int("CROWDNAV_AMD_SARL_FUSED_STEP", 1) != 0 && e->P.threads == 64 && !e->P.kd;
-        s->narrow = !lstm && !s->chunked && !s->reg_mlp && in_dim == 13 && !C.sort_lookahead && H >= 1 &&
+        s->narrow = !lstm && !s->chunked && !s->reg_mlp && (in_dim == 13 || (C.with_om && !cadrl)) && !C.sort_lookahead && H >= 1 &&
                     H <= cn::kSarlMaxHumans && e->cfg.scenario_rule != CN_MIXED && s->narrow_lds <= 160 * 1024 &&
                     (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)s->n_cus));
     }
@@ -477,9 +477,15 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
     // maps, LSTM-RL's re-ordering; otherwise the feature kernel derives them itself.  The reward of every (env, action) is
     // evaluated inside sarl_select_kernel.  (Each small kernel less is ~7 us of a 70 us single-env decision.)
     if (s->narrow) {  // X never leaves the network kernel's LDS
+        if (C.with_om)  // the humans' next states and the map each of them sees: once per (env, human)
+            hipLaunchKernelGGL(cn::sarl_lookahead_kernel, dim3((C.B * H + 255) / 256), dim3(256), 0, e->stream, C, e->S.pos,
+                               e->S.vel, e->S.rv, s->orca_vel, s->next_obs, s->om);
+        cn::SarlDecide D0{};
+        D0.in_dim = s->net.in_dim;
         hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
                            e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
-                           s->next_obs, s->V, cn::SarlDecide{});
+                           s->next_obs, s->V, D0, C.with_om ? (const float*)s->om : (const float*)nullptr);
+        e->launch_counts[CN_COUNT_SARL_NARROW] += 1;
         hipLaunchKernelGGL(cn::sarl_select_kernel, dim3((C.B + 3) / 4), dim3(256), 0, e->stream, C, e->S.pos, e->S.vel,
                            e->S.goal, e->S.rv, e->S.gtime, e->S.theta, s->actions, s->reward, s->V, values, best, action);
         CN_HIP(hipGetLastError());
@@ -642,14 +648,24 @@ int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* b
         // CROWDNAV_AMD_SARL_FUSED_STEP=0: ORCA, the network with the decision by its last workgroup, the transition.
         const bool fused = s->fused_step;
         if (!C.const_vel && !(fused && fresh)) cn_launch_orca(e, s->orca_vel);
+        // occupancy maps: the previous call's sarl_decide_step_kernel left next_obs / om behind its ORCA pass (fresh); otherwise
+        // sarl_lookahead_kernel, a launch of its own like ORCA
+        if (C.with_om && !(fused && fresh && !C.const_vel))
+            hipLaunchKernelGGL(cn::sarl_lookahead_kernel, dim3((C.B * C.H + 255) / 256), dim3(256), 0, e->stream, C, e->S.pos,
+                               e->S.vel, e->S.rv, s->orca_vel, s->next_obs, s->om);
         cn::SarlDecide D{};
         D.counter = fused ? nullptr : s->narrow_counter;
         D.epsilon = epsilon, D.alive = alive, D.done = done, D.best = best, D.action = action;
         D.state_out = state_out, D.env_stride = env_stride, D.sort_humans = sort_humans ? 1 : 0, D.in_dim = s->net.in_dim;
         D.reward = s->reward, D.value = s->narrow_value, D.gtime = e->S.gtime, D.mt_key = e->S.mt_key, D.mt_pos = e->S.mt_pos, D.error = e->C.error;
-        hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
+        if (C.with_om) D.next_obs_out = s->next_obs, D.om_out = s->om;
+        // the replay-memory states on a workgroup of their own beside the tiles (CROWDNAV_AMD_SARL_SIDE_WG=0: on tile b's idle wave)
+        static const bool side = env_int("CROWDNAV_AMD_SARL_SIDE_WG", 1) != 0;
+        D.side_wg = (side && state_out) ? 1 : 0;
+        hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles + (unsigned)D.side_wg), dim3(cn::kNarrowThreads), s->narrow_lds,
                            e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
-                           s->next_obs, s->V, D);
+                           s->next_obs, s->V, D, C.with_om ? (const float*)s->om : (const float*)nullptr);
+        e->launch_counts[CN_COUNT_SARL_NARROW] += 1;
         CN_HIP(hipGetLastError());
         if (fused) {
             cn::StepIo io{action, reward, done, info, dmin, nullptr, nullptr, nullptr, 1};
@@ -667,6 +683,7 @@ int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* b
             }
 #undef CN_DECIDE_STEP
             CN_HIP(hipGetLastError());
+            e->launch_counts[CN_COUNT_SARL_DECIDE_STEPS] += 1;
             e->orca_fresh = next_vel != nullptr;
             return CN_OK;
         }

@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "orca_device.h"     // wave_lds_sync
 #include "scenario_device.h"  // norm2
 
 namespace cn {
@@ -231,6 +232,96 @@ __device__ __forceinline__ void occupancy_map(const SarlCfg& C, int i, StateOf s
         occupancy_map_cap<kSarlMaxHumans>(C, i, state_of, m);
     else
         occupancy_map_cap<kSarlAnyHumans>(C, i, state_of, m);
+}
+
+// The same maps for the envs of ONE workgroup, spread over its lanes (sarl_decide_step_kernel: the maps of the next decision sit
+// on a one-env sampling step's critical path, and a human's lane alone needs 1 + 4 x 2 float64 atan2 and 4 x 2 sincos in a
+// row: +28 us).  The float64 operations of occupancy_map_cap, each exactly once and in the same expressions — only spread out:
+//   phase 1  one item per human (its heading), per ordered pair (the other's bearing and distance) and per ordered pair again
+//            (the other's velocity direction and speed): every atan2 / sqrt of the maps at once
+//   phase 2  two items per ordered pair: cos / sin of the relative bearing -> cell; of the relative velocity direction -> (vx', vy')
+//   phase 3  one item per (human, cell): count and velocity sums over the others IN INDEX ORDER (python's sum())
+// so a map costs one atan2 and one sincos in a row.  state_of(e, j, px, py, vx, vy): human j of the workgroup's env e.
+// scratch: (8 H + 52 H (H - 1)) bytes per env (H <= kSarlMaxHumans); sync(): the workgroup's barrier.
+__host__ __device__ inline size_t occupancy_coop_bytes(int H) { return (size_t)8 * H + (size_t)52 * H * (H - 1); }
+// map_of(e, i): where human i of env e's map (cells x channels floats) goes.
+template <class StateOf, class Sync, class MapOf>
+__device__ __forceinline__ void occupancy_maps_cooperative(const SarlCfg& C, int E, int tid, int threads, char* scratch, StateOf state_of,
+                                                           Sync sync, MapOf map_of) {
+    const int H = C.H, P = H * (H - 1);
+    const size_t per_env = occupancy_coop_bytes(H);
+    const auto ang_of = [&](int e) { return reinterpret_cast<double*>(scratch + e * per_env); };
+    const auto pa_of = [&](int e) { return reinterpret_cast<double2*>(scratch + e * per_env + 8 * H); };           // (bearing, velocity direction)
+    const auto pd_of = [&](int e) { return reinterpret_cast<double2*>(scratch + e * per_env + 8 * H + 16 * P); };  // (distance, speed)
+    const auto pr_of = [&](int e) { return reinterpret_cast<double2*>(scratch + e * per_env + 8 * H + 32 * P); };  // (vx', vy')
+    const auto pc_of = [&](int e) { return reinterpret_cast<int*>(scratch + e * per_env + 8 * H + 48 * P); };      // cell or -1
+    const int n1 = H + 2 * P;
+    for (int it = tid; it < E * n1; it += threads) {
+        const int e = it / n1, k = it - e * n1;
+        double px, py, vx, vy;
+        if (k < H) {
+            state_of(e, k, px, py, vx, vy);
+            ang_of(e)[k] = atan2(vy, vx);
+        } else {
+            const int q = k - H, p = q < P ? q : q - P;
+            const int i = p / (H - 1), jj = p - i * (H - 1), j = jj < i ? jj : jj + 1;
+            double qx, qy, wx, wy;
+            state_of(e, j, qx, qy, wx, wy);
+            if (q < P) {
+                state_of(e, i, px, py, vx, vy);
+                const double ox = qx - px, oy = qy - py;
+                pa_of(e)[p].x = atan2(oy, ox);
+                pd_of(e)[p].x = sqrt(ox * ox + oy * oy);
+            } else {
+                pa_of(e)[p].y = atan2(wy, wx);
+                pd_of(e)[p].y = sqrt(wx * wx + wy * wy);
+            }
+        }
+    }
+    sync();
+    for (int it = tid; it < E * 2 * P; it += threads) {
+        const int e = it / (2 * P), q = it - e * 2 * P, p = q < P ? q : q - P;
+        const int i = p / (H - 1);
+        const double my_angle = ang_of(e)[i];
+        if (q < P) {
+            const double rotation = pa_of(e)[p].x - my_angle, dist = pd_of(e)[p].x;
+            const double rx = cos(rotation) * dist, ry = sin(rotation) * dist;
+            const double xi = floor(rx / C.cell_size + C.cell_num / 2.0);
+            const double yi = floor(ry / C.cell_size + C.cell_num / 2.0);
+            pc_of(e)[p] = (xi < 0 || xi >= C.cell_num || yi < 0 || yi >= C.cell_num) ? -1 : (int)(C.cell_num * yi + xi);
+        } else {
+            const double vrot = pa_of(e)[p].y - my_angle, speed = pd_of(e)[p].y;
+            pr_of(e)[p] = make_double2(cos(vrot) * speed, sin(vrot) * speed);
+        }
+    }
+    sync();
+    const int cells = C.cell_num * C.cell_num, ch = C.om_channels;
+    for (int it = tid; it < E * H * cells; it += threads) {
+        const int e = it / (H * cells), r = it - e * H * cells, i = r / cells, cell = r - i * cells;
+        double cnt = 0.0, svx = 0.0, svy = 0.0;
+        for (int jj = 0; jj < H - 1; ++jj) {  // the others in index order
+            const int p = i * (H - 1) + jj;
+            if (pc_of(e)[p] != cell) continue;
+            const double2 rv = pr_of(e)[p];
+            cnt += 1.0;
+            svx += rv.x;
+            svy += rv.y;
+        }
+        float* m = map_of(e, i);
+        if (ch == 1) {
+            m[cell] = cnt > 0.0 ? 1.0f : 0.0f;
+        } else if (ch == 2) {
+            m[2 * cell] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
+            m[2 * cell + 1] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
+        } else {
+            m[3 * cell] = cnt > 0.0 ? (float)(cnt / cnt) : 0.0f;
+            m[3 * cell + 1] = cnt > 0.0 ? (float)(svx / cnt) : 0.0f;
+            m[3 * cell + 2] = cnt > 0.0 ? (float)(svy / cnt) : 0.0f;
+        }
+    }
+}
+__device__ __forceinline__ bool occupancy_coop_ok(const SarlCfg& C, size_t scratch_bytes, int envs) {
+    return C.H >= 2 && C.H <= kSarlMaxHumans && (size_t)envs * occupancy_coop_bytes(C.H) <= scratch_bytes;
 }
 
 // LstmRL.predict re-orders the humans of the joint state by DEcreasing distance to the robot (lstm_rl.py:96-103; python's
@@ -514,7 +605,8 @@ __global__ void sarl_feature_kernel(SarlCfg C, int in_dim, int ks_x, const doubl
 // Explorer.update_memory pushes into the replay memory.  lane = (env, position in the joint state).
 __device__ __forceinline__ void sarl_transform_row(const SarlCfg& C, int in_dim, int sort_humans, const double2* pos,
                                                    const double2* vel, const double2* goal, const double2* rv,
-                                                   const double* theta, float* out, int64_t env_stride, int b, int h) {
+                                                   const double* theta, float* out, int64_t env_stride, int b, int h,
+                                                   bool maps = true) {
     const size_t g0 = (size_t)b * (C.H + 1);
     // perm[p] = human at position p of the joint state.  LSTM-RL (sort_humans): LstmRL.predict re-orders the humans by
     // DEcreasing distance to the robot before MultiHumanRL.predict runs (lstm_rl.py:96-103; python's sorted(...,
@@ -553,7 +645,7 @@ __device__ __forceinline__ void sarl_transform_row(const SarlCfg& C, int in_dim,
     float* x = out + (size_t)b * env_stride + (size_t)h * in_dim;
 #pragma unroll
     for (int k = 0; k < 13; ++k) x[k] = f[k];
-    if (C.with_om) {
+    if (C.with_om && maps) {  // (maps = false: the caller's lanes share them, occupancy_maps_cooperative)
         auto state_of = [&](int j, double& px, double& py, double& vx, double& vy) {
             int oj = j;
             if (!big) {
@@ -1383,6 +1475,11 @@ struct SarlDecide {
     uint32_t* mt_key;
     int* mt_pos;
     int* error;
+    // occupancy maps (round 6): what sarl_lookahead_kernel computes per (env, human) for the NEXT decision, written by
+    // sarl_decide_step_kernel behind its ORCA pass (null without maps)
+    double* next_obs_out;  // [B][H][5]
+    float* om_out;         // [B][H][cells * channels]
+    int side_wg;           // sarl_narrow_kernel: the LAST workgroup of the grid is not a tile — it writes the replay-memory states
 };
 // The same network for a FEW decisions (the single-episode sampling of train.py:156-170: one env, 81 groups = 6 tiles): the
 // one-tile kernels above put a decision on 6 of 256 CUs for ~40 us.  Here a tile is ONE 16-row MFMA tile holding
@@ -1447,6 +1544,7 @@ __device__ __forceinline__ void dense_narrow(const PackedLinear& P, const float*
         const float* afrag = in + lane;
         f32x4 acc;
         if (P.kpad <= 3 * kSarlKChunk) acc = narrow_k_loop<3>(afrag, t);
+        else if (P.kpad <= 4 * kSarlKChunk) acc = narrow_k_loop<4>(afrag, t);  // (61 inputs: 16 k-steps)
         else if (P.kpad <= 5 * kSarlKChunk) acc = narrow_k_loop<5>(afrag, t);
         else acc = narrow_k_loop<kNarrowK / kSarlKChunk>(afrag, t);
         if (P.kpad > kNarrowK) {  // wider than the shipped layers: the rest of the k loop straight from L2
@@ -1489,8 +1587,21 @@ __device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D
 }
 // The joint state of env b for the replay memory (sarl_transform_row), on the idle wave of tile b
 __device__ __noinline__ void narrow_transform(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel,
-                                              const double2* goal, const double2* rv, const double* theta, int b, int h) {
-    sarl_transform_row(C, D.in_dim, D.sort_humans, pos, vel, goal, rv, theta, D.state_out, D.env_stride, b, h);
+                                              const double2* goal, const double2* rv, const double* theta, int b, int h, bool maps) {
+    sarl_transform_row(C, D.in_dim, D.sort_humans, pos, vel, goal, rv, theta, D.state_out, D.env_stride, b, h, maps);
+}
+// ... and its occupancy maps (the CURRENT human states, multi_human_rl.py:96-105) shared by the 64 lanes of that wave: a human's
+// lane alone needs 30 us of float64 trigonometry for its map — longer than the whole network beside it
+__device__ __noinline__ void narrow_transform_maps(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel, int b,
+                                                   int lane, char* scratch) {
+    const size_t g0 = (size_t)b * (C.H + 1);
+    occupancy_maps_cooperative(
+        C, 1, lane, kWaveSize, scratch,
+        [&](int, int j, double& px, double& py, double& vx, double& vy) {
+            px = pos[g0 + 1 + j].x, py = pos[g0 + 1 + j].y, vx = vel[g0 + 1 + j].x, vy = vel[g0 + 1 + j].y;
+        },
+        [] { wave_lds_sync(); },
+        [&](int, int i) { return D.state_out + (size_t)b * D.env_stride + (size_t)i * D.in_dim + 13; });
 }
 // onestep_lookahead's reward of one (env, action) group, for the tile that holds it (not inlined: float64, the libm's arrays)
 __device__ __noinline__ double narrow_reward(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
@@ -1502,7 +1613,7 @@ __device__ __noinline__ double narrow_reward(const SarlCfg& C, const double2* po
 __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef net, SarlCfg C, const double2* pos, const double2* vel,
                                                                      const double2* goal, const double2* rv, const double* theta,
                                                                      const double* actions, const float* orca_vel, double* next_obs,
-                                                                     float* V, SarlDecide D) {
+                                                                     float* V, SarlDecide D, const float* om) {
     extern __shared__ float lds[];
     float* xs = lds;                          // [ks_x][64]  X of the tile
     float* bufA = xs + net.ks_x * 64;         // [ks_a][64]  wide hidden layers
@@ -1518,7 +1629,20 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     const int H = C.H, GT = kSarlGroups / H, rows = GT * H;
     const int n_groups = C.B * C.n_actions;
     const size_t tile = blockIdx.x;
+    const unsigned n_tiles = gridDim.x - (unsigned)D.side_wg;
     const SarlNetRef* n = &net;
+    if (D.side_wg && blockIdx.x == n_tiles) {
+        // cn_sarl_sample_step: the CURRENT joint state of every env for the replay memory (sarl_transform_row; nothing of it
+        // depends on the network) by a workgroup of its own, beside the tiles on another CU — with occupancy maps a state is
+        // ~5 us of float64 trigonometry even when a wave's lanes share it.  One wave per env.
+        const bool coop = C.with_om && !D.sort_humans && occupancy_coop_ok(C, occupancy_coop_bytes(H), 1);
+        char* scratch = reinterpret_cast<char*>(lds) + (size_t)wave * ((occupancy_coop_bytes(H) + 15) & ~(size_t)15);
+        for (int b = wave; b < C.B; b += kNarrowWaves) {
+            if (lane < H) narrow_transform(C, D, pos, vel, goal, rv, theta, b, lane, !coop);
+            if (coop) narrow_transform_maps(C, D, pos, vel, b, lane, scratch);
+        }
+        return;
+    }
     CN_SARL_CLOCK_BEGIN();
     // (cadrl.ValueNetwork: its four layers live in the mlp3 slots)
     BTile cur = narrow_fetch(layer_of(*n, C.cadrl ? kL_mlp3_0 : kL_mlp1_0), wave, lane);
@@ -1538,12 +1662,38 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         if (row_valid)
             sarl_feature_row(C, (int)(G / C.n_actions), (int)(G % C.n_actions), h, pos, goal, rv, theta, actions, next_obs, vel,
                              orca_vel, f);
+        // (occupancy maps) where this row's map starts in `om`; vbuf is not part of the zeroed region
+        if (om != nullptr) reinterpret_cast<int*>(vbuf)[tid] = row_valid ? (int)(((G / C.n_actions) * H + h) * (size_t)(D.in_dim - 13)) : -1;
     }
     lds_barrier();
     CN_SARL_TICK(0);
     if (row_valid) {
 #pragma unroll
         for (int k = 0; k < 13; ++k) xs[(k >> 2) * 64 + (k & 3) * 16 + tid] = f[k];
+    }
+    if (om != nullptr) {
+        // occupancy maps (multi_human_rl.py:46-49): columns 13.. of a row are its human's map among the humans' NEXT states —
+        // the same for every action of the env (sarl_lookahead_kernel or the previous call's sarl_decide_step_kernel wrote
+        // them).  Four consecutive cells per thread (one 16-byte load), the row's offset into `om` from its own thread (vbuf)
+        const int extra = D.in_dim - 13, quads = extra >> 2;  // (cells x channels: 16 x 3 at the shipped size)
+        const int* row_om = reinterpret_cast<const int*>(vbuf);
+        for (int i = tid; i < rows * quads; i += kNarrowThreads) {
+            const int r = i / quads, q = i - r * quads;
+            const int base = row_om[r];
+            if (base >= 0) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(om + base + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = 13 + 4 * q + j;
+                    xs[(kk >> 2) * 64 + (kk & 3) * 16 + r] = m[j];
+                }
+            }
+        }
+        for (int i = tid; i < rows * (extra & 3); i += kNarrowThreads) {  // (a cell count that is not a multiple of four)
+            const int r = i / (extra & 3), k = 4 * quads + i - r * (extra & 3);
+            const int base = row_om[r], kk = 13 + k;
+            if (base >= 0) xs[(kk >> 2) * 64 + (kk & 3) * 16 + r] = om[base + k];
+        }
     }
     BTile nxt = narrow_fetch(layer_of(*n, C.cadrl ? kL_mlp3_2 : kL_mlp1_2), wave, lane);
     lds_barrier();
@@ -1571,7 +1721,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         // joint state for the replay memory was written by tile b meanwhile).
         int* last = reinterpret_cast<int*>(sbuf);
         if (wave == kNarrowWaves - 1 && lane == 0) {
-            *last = arrived == (int)gridDim.x ? 1 : 0;
+            *last = arrived == (int)n_tiles ? 1 : 0;
             if (*last) atomicExch(D.counter, 0);  // ready for the next launch
         }
         __syncthreads();
@@ -1589,10 +1739,16 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         }
     };
     const auto replay_state_of_my_env = [&]() {
-        // ... and the CURRENT joint state of env b for the replay memory, by tile b's idle wave (nothing of it depends on the network).
+        // ... and (without the side workgroup) the CURRENT joint state of env b for the replay memory, by tile b's idle wave.
         // A small action table has fewer tiles than envs (one human, 13 actions, 6 envs: 5 tiles): the tiles stride over the envs.
-        if (D.value && D.state_out && wave == kNarrowWaves - 1 && lane < H)
-            for (size_t b = tile; b < (size_t)C.B; b += gridDim.x) narrow_transform(C, D, pos, vel, goal, rv, theta, (int)b, lane);
+        if (D.value && D.state_out && !D.side_wg && wave == kNarrowWaves - 1) {
+            // (occupancy maps: the wave's lanes share them; mbuf — the value head's pong buffer — is idle until mlp3.0)
+            const bool coop = C.with_om && !D.sort_humans && occupancy_coop_ok(C, sizeof(float) * 64 * (size_t)net.ks_a, 1);
+            for (size_t b = tile; b < (size_t)C.B; b += n_tiles) {
+                if (lane < H) narrow_transform(C, D, pos, vel, goal, rv, theta, (int)b, lane, !coop);
+                if (coop) narrow_transform_maps(C, D, pos, vel, (int)b, lane, reinterpret_cast<char*>(mbuf));
+            }
+        }
     };
     if (C.cadrl) {
         // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row — cadrl_mlp_kernel's four layers on the

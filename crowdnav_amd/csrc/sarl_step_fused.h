@@ -5,6 +5,7 @@
 //   step_kernel's body (step_kernels.h) with that action                                           crowd_sim.py:317-420
 //   orca_kernel's body on the state the transition has just written: what the NEXT call's network kernel reads as the humans'
 //   next velocities (cn_engine::orca_fresh), so that a streamed sampling loop is two launches per step
+//   (occupancy maps) sarl_lookahead_kernel's body on those velocities: the next decision's map columns
 // instead of three kernels (orca, last-workgroup decision inside the network kernel, step).  One-wave workgroups without kd
 // bookkeeping only (up to 10 agents per simulator): an env's lanes are lanes of one wave, so its arg-max is folded with shuffles.
 #pragma once
@@ -89,6 +90,39 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
         next_orca_vel[2 * L.gi] = vx;
         next_orca_vel[2 * L.gi + 1] = vy;
         if (L.a == 0) S.rsim_valid[L.env] = 1;
+    }
+    // ---- sarl_lookahead_kernel's body for the next decision (occupancy maps only): the humans' next observable states from the
+    // velocities just computed — staged in LDS (posd / act are dead by now) — and the map each human sees among them, by the
+    // human's own lane with the same functions, so the same bits
+    if (D.om_out == nullptr) return;
+    block_sync(P);
+    if (L.valid && L.a > 0) {
+        const double nvx = (double)vx, nvy = (double)vy;
+        s.posd[L.lane] = make_double2(r.px + nvx * C.dt, r.py + nvy * C.dt);
+        s.act[L.lane] = make_double2(nvx, nvy);
+    }
+    block_sync(P);
+    if (L.valid && L.a > 0) {
+        const double2 p = s.posd[L.lane], w = s.act[L.lane];
+        double* o = D.next_obs_out + ((size_t)L.env * C.H + (L.a - 1)) * 5;
+        o[0] = p.x, o[1] = p.y, o[2] = w.x, o[3] = w.y, o[4] = r.rad;
+    }
+    const int env0 = (int)blockIdx.x * P.E;
+    const int envs_here = C.B - env0 < P.E ? C.B - env0 : P.E;
+    float* om0 = D.om_out + (size_t)env0 * C.H * C.cell_num * C.cell_num * C.om_channels;
+    const auto state_of = [&](int e, int j, double& px, double& py, double& wx, double& wy) {
+        const double2 p = s.posd[e * P.A + 1 + j], w = s.act[e * P.A + 1 + j];
+        px = p.x, py = p.y, wx = w.x, wy = w.y;
+    };
+    // the workgroup's lanes share the maps' float64 trigonometry (sarl_kernels.h): `lines` and `proj` are dead by now
+    if (occupancy_coop_ok(C, (size_t)P.nA * 2 * kLineStride * 16, envs_here)) {
+        occupancy_maps_cooperative(C, envs_here, (int)threadIdx.x, (int)blockDim.x, reinterpret_cast<char*>(s.lines), state_of,
+                                   [&]() { block_sync(P); },
+                                   [&](int e, int i) { return om0 + ((size_t)e * C.H + i) * C.cell_num * C.cell_num * C.om_channels; });
+    } else if (L.valid && L.a > 0) {
+        const int e = L.env - env0;
+        occupancy_map(C, L.a - 1, [&](int j, double& px, double& py, double& wx, double& wy) { state_of(e, j, px, py, wx, wy); },
+                      D.om_out + ((size_t)L.env * C.H + (L.a - 1)) * C.cell_num * C.cell_num * C.om_channels);
     }
 }
 

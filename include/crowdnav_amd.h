@@ -236,9 +236,12 @@ enum {
     CN_COUNT_SCHEDULED_KERNELS = 1, /* ... of which launches of the shard kernel's schedules: one per call under the dynamic
                                        schedule, four per call (sub-launches) under the static 3-of-4 one */
     CN_COUNT_RING_FILLS = 2,        /* synchronous scenario-ring fills (one per cn_rollout call that needed one) */
-    CN_COUNT_ASYNC_FILLS = 3        /* fill launches on the side streams (CN_FLAG_ASYNC_SCENARIO_FILL: one per call) */
+    CN_COUNT_ASYNC_FILLS = 3,       /* fill launches on the side streams (CN_FLAG_ASYNC_SCENARIO_FILL: one per call) */
+    CN_COUNT_SARL_NARROW = 4,       /* (ABI v9) value-network launches on the narrow tiles (cn_sarl_select / cn_sarl_sample_step
+                                       of a few envs): which route a decision took */
+    CN_COUNT_SARL_DECIDE_STEPS = 5  /* (ABI v9) cn_sarl_sample_step calls that ran decision + transition + next ORCA as ONE kernel */
 };
-#define CN_LAUNCH_COUNTERS 4
+#define CN_LAUNCH_COUNTERS 6
 int cn_launch_counts(cn_engine* e, uint64_t* counts_host);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -333,12 +336,13 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
  *   cn_sarl_explore(e, epsilon, alive, best, action, NULL)
  *   cn_sarl_transform(e, state_out, env_stride, sort_humans)      (state_out == NULL: skipped)
  *   cn_step(e, action, 1, reward, done, info, dmin, NULL, NULL, NULL)
- * as one call.  For a FEW envs without occupancy maps (CN_MODEL_SARL or CN_MODEL_CADRL, up to 8 humans, not the `mixed` rule, at most one
+ * as one call.  For a FEW envs (CN_MODEL_SARL with or without occupancy maps, or CN_MODEL_CADRL; up to 8 humans, not the `mixed` rule, at most one
  * workgroup per CU: 9 envs of 5 humans x 81 actions — BASELINE configs[4]'s one episode at a time, train.py:156-170) a streamed
  * loop of these calls is TWO launches per step instead of eight: the value network on tiles of 16 / num_humans whole
  * (env, action) groups, one per workgroup — a decision spread over 27 CUs instead of 6, its input rows built in LDS, each
  * tile adding the lookahead reward of its own groups and writing env b's replay-memory state on an idle wave; then ONE kernel
- * for the arg-max, the epsilon-greedy draw, the transition and the humans' ORCA velocities of the NEXT decision.  Those
+ * for the arg-max, the epsilon-greedy draw, the transition and the humans' ORCA velocities (with occupancy maps also their next
+ * states and the maps) of the NEXT decision.  Those
  * velocities are trusted by the next call only if no other entry point of this engine ran in between (any of them may change
  * the state they belong to); otherwise, and on the first call, ORCA is a launch of its own in front.  Same bits as the five
  * calls above in every case (tests/test_rl_pipeline.py).  cn_sarl_select takes the same network kernel at these sizes (two

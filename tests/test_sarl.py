@@ -109,17 +109,21 @@ def test_sarl_mlp_vs_torch_fp32_random_inputs(humans, with_om):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('humans,B', [(5, 1), (5, 3), (5, 16), (1, 2), (2, 3), (3, 2), (4, 5), (8, 2)])
-def test_narrow_tile_value_network_is_bit_identical_to_the_one_tile_kernel(humans, B, monkeypatch):
+@pytest.mark.parametrize('humans,B,with_om', [(5, 1, False), (5, 3, False), (5, 16, False), (1, 2, False), (2, 3, False), (3, 2, False),
+                                              (4, 5, False), (8, 2, False), (5, 1, True), (5, 3, True), (2, 3, True), (3, 4, True), (8, 2, True)])
+def test_narrow_tile_value_network_is_bit_identical_to_the_one_tile_kernel(humans, B, with_om, monkeypatch):
     """A few decisions (train.py's single-episode sampling: one env, 81 groups) run sarl_narrow_kernel: tiles of 16 / H whole
     groups, one per workgroup, X built in LDS.  CROWDNAV_AMD_SARL_NARROW=0 keeps sarl_feature_kernel + sarl_mlp_pipe_kernel on
     the same engine configuration: V, the chosen actions and the exported X / next states are the same BITS (the narrow kernel
     sums over a group's humans, slices attention.4 and orders every layer's k loop as the one-tile kernel does), and both are
-    within 2e-5 of the torch module.  81 B groups are never a multiple of the 3 / 4 / 5 / 8 / 16 groups of a narrow tile."""
+    within 2e-5 of the torch module.  81 B groups are never a multiple of the 3 / 4 / 5 / 8 / 16 groups of a narrow tile.
+    with_om (round 6): 61-wide rows — the 48 map columns of a row come from the per-(env, human) occupancy maps, mlp1.0 runs its
+    16 k-steps on the tile; the launch counter proves the narrow route ran."""
     import crowdnav_amd
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
     torch.manual_seed(11)
-    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    d = 61 if with_om else 13
+    net = ValueNetwork(d, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
     space, _, _ = build_action_space(1.0)
     got = {}
     for narrow in ('2', '0'):  # (2 = whenever the configuration allows it: by size the narrow tiles stop at one workgroup per CU)
@@ -127,14 +131,18 @@ def test_narrow_tile_value_network_is_bit_identical_to_the_one_tile_kernel(human
         eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
         eng.reset(5000 + np.arange(B))
         eng.step(np.zeros((B, 2)), update=True)
-        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]))
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
         eng.sarl_set_weights(net.state_dict())
         out = eng.sarl_select()
+        # (8 humans stream through the tile in chunks: no narrow tiles, both runs take the same kernels)
+        assert eng.launch_counts()['sarl_narrow'] == (1 if narrow == '2' and humans <= 5 else 0)
         got[narrow] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), out['action'].cpu().numpy(),
                        eng.sarl_export('X').cpu(), eng.sarl_export('next_obs').cpu().numpy())
+        if with_om:
+            got[narrow] += (eng.sarl_export('om').cpu().numpy(),)
         eng.close()
     with torch.no_grad():
-        want = net(got['2'][3].reshape(B * 81, humans, 13)).reshape(B, 81).numpy()
+        want = net(got['2'][3].reshape(B * 81, humans, d)).reshape(B, 81).numpy()
     assert np.abs(got['2'][0] - want).max() <= 2e-5
     for a, b in zip(got['2'], got['0']):
         assert np.array_equal(np.asarray(a), np.asarray(b))
