@@ -286,7 +286,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
         s->fused_step = env_int("CROWDNAV_AMD_SARL_FUSED_STEP", 1) != 0 && e->P.threads == 64 && !e->P.kd;
         s->narrow = !lstm && !s->chunked && !s->reg_mlp && (in_dim == 13 || (C.with_om && !cadrl)) && !C.sort_lookahead && H >= 1 &&
-                    H <= cn::kSarlMaxHumans && e->cfg.scenario_rule != CN_MIXED && s->narrow_lds <= 160 * 1024 &&
+                    H <= cn::kSarlMaxHumans && s->narrow_lds <= 160 * 1024 &&
                     (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)s->n_cus));
     }
     const size_t nA = (size_t)C.B * (H + 1);

@@ -1625,6 +1625,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     float* mbuf = kbuf + net.ks_a * 64;       // [ks_a][64]  value-head pong
     float* sbuf = mbuf + net.ks_a * 64;       // [64]        attention scores -> weights (row r at word r)
     float* vbuf = sbuf + 64;                  // [kSarlThreads] partial sums of attention.4
+    int* hc = reinterpret_cast<int*>(vbuf + kSarlThreads);  // [16] humans present in the tile's groups (H unless the `mixed` rule)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = C.H, GT = kSarlGroups / H, rows = GT * H;
     const int n_groups = C.B * C.n_actions;
@@ -1662,6 +1663,15 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         if (row_valid)
             sarl_feature_row(C, (int)(G / C.n_actions), (int)(G % C.n_actions), h, pos, goal, rv, theta, actions, next_obs, vel,
                              orca_vel, f);
+        if (h == 0) {  // len(state.human_states): under the `mixed` rule the env's absent humans are parked behind the present ones
+            int present = H;
+            if (row_valid) {
+                const size_t e0 = (G / C.n_actions) * (size_t)(H + 1);
+                present = 0;
+                for (int j = 0; j < H; ++j) present += is_parked(pos[e0 + 1 + j]) ? 0 : 1;
+            }
+            hc[g] = present;
+        }
         // (occupancy maps) where this row's map starts in `om`; vbuf is not part of the zeroed region
         if (om != nullptr) reinterpret_cast<int*>(vbuf)[tid] = row_valid ? (int)(((G / C.n_actions) * H + h) * (size_t)(D.in_dim - 13)) : -1;
     }
@@ -1768,9 +1778,10 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         float m = 0.0f;
         if (wave == kNarrowWaves - 1 && lane < GT) {
             m = kbuf[lane * H];
+            const int cnt = hc[lane];
             for (int h = 1; h < H; ++h) {
                 const float v = kbuf[lane * H + h];
-                m = v < m ? v : m;
+                m = (h < cnt && v < m) ? v : m;
             }
         }
         CN_SARL_CLOCK_END();
@@ -1793,9 +1804,10 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     if (n->with_global) {
         for (int i = tid; i < n->ks_b * 64; i += kNarrowThreads) {
             const int r = i & 15, first = (i & ~15) + (r / H) * H;
+            const int cnt = r < rows ? hc[r / H] : H;
             float sum = 0.0f;
-            for (int h = 0; h < H; ++h) sum += bufB[first + h];
-            gbuf[i] = r < rows ? sum / (float)H : 0.0f;  // (row 15 of 3 x 5: reads past the tile's rows, result unused)
+            for (int h = 0; h < H; ++h) sum += h < cnt ? bufB[first + h] : 0.0f;  // (as sarl_mlp_pipe_kernel masks a `mixed` episode)
+            gbuf[i] = r < rows ? sum / (float)cnt : 0.0f;  // (row 15 of 3 x 5: reads past the tile's rows, result unused)
         }
     }
     dense_narrow(layer_of(*n, kL_mlp2_0), bufB, bufA, true, nullptr, wave, lane, cur);
@@ -1836,8 +1848,9 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
             const int r = lane & 15;
             float v = as_global(P.bias)[0];
             for (int s = 0; s < slices; ++s) v += vbuf[s * 16 + r];
-            const float e = expf(v) * (v != 0.0f ? 1.0f : 0.0f);
             const int g0 = (r / H) * H;
+            const bool present = r < rows ? (r - g0) < hc[r / H] : true;
+            const float e = present ? expf(v) * (v != 0.0f ? 1.0f : 0.0f) : 0.0f;
             float total = 0.0f;
             for (int h = 0; h < H; ++h) total += __shfl(e, (g0 + h) & 15);  // (row 15 of 3 x 5 wraps: unused)
             if (lane < 16) sbuf[lane] = e / total;
@@ -1888,7 +1901,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     finish(v);
 }
 __host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net) {
-    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads);
+    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads + 16);
 }
 
 }  // namespace cn
