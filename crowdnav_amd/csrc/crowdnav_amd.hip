@@ -455,6 +455,11 @@ static int drain_fill_streams(cn_engine* e) {
 // Upload the caller's io struct (ordered on the engine's stream) if it differs from the device copy.
 static int upload_io(cn_engine* e, const cn_rollout_io* io) {
     if (e->io_valid && std::memcmp(&e->io_host, io, sizeof(*io)) == 0) return CN_OK;
+    // the seed numbering belongs to cn_rollout_begin: the scenario cache was sized by seed_mod and filled for seed_base (a
+    // larger seed_mod would index past it, another seed_base would be served the old seeds' scenarios)
+    if (e->rollout_begun && (io->seed_base != e->begin_seed_base || io->seed_mod != e->begin_seed_mod))
+        return fail(CN_ERR_INVALID, "rollout io: seed_base / seed_mod (%u / %u) differ from cn_rollout_begin's (%u / %u); call "
+                    "cn_rollout_begin to renumber the episodes", io->seed_base, io->seed_mod, e->begin_seed_base, e->begin_seed_mod);
     int rc = drain_fill_streams(e);
     if (rc) return rc;
     e->io_host = *io;
@@ -479,7 +484,10 @@ static int check_io(const cn_engine* e, const cn_rollout_io* io) {
 int cn_rollout_begin(cn_engine* e, const cn_rollout_io* io) {
     int rc = bind(e);
     if (rc) return rc;
-    if ((rc = check_io(e, io)) || (rc = drain_fill_streams(e)) || (rc = upload_io(e, io))) return rc;
+    if ((rc = check_io(e, io)) || (rc = drain_fill_streams(e))) return rc;
+    e->rollout_begun = false;
+    if ((rc = upload_io(e, io))) return rc;
+    e->rollout_begun = true, e->begin_seed_base = io->seed_base, e->begin_seed_mod = io->seed_mod;
     cn::RolloutView R{e->io_dev, e->discount, e->discount_len};
     // scenario cache (step_kernels.h: cached_scenario_wave): on for the wave generators when the episode seeds come from a small
     // set; a new rollout may number its seeds differently, so it starts empty

@@ -64,6 +64,8 @@ struct cn_engine {
     hipEvent_t rollout_done;
     int next_fill_stream;
     bool io_valid;
+    bool rollout_begun = false;          // cn_rollout_begin has run: the seed numbering below is fixed until the next one
+    uint32_t begin_seed_base = 0, begin_seed_mod = 0;  // (the scenario cache is sized and keyed by them)
     int steps_since_fill;    // transitions launched since the scenario ring was last topped up; < 0 = never filled
     struct cn_sarl* sarl;    // SARL decision state (sarl_abi.hip), NULL until cn_sarl_configure
     bool orca_fresh;         // cn_sarl_sample_step: the humans' ORCA velocities of the CURRENT state are in sarl->orca_vel (left by the

@@ -283,9 +283,14 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         const int narrow_mode = env_int("CROWDNAV_AMD_SARL_NARROW", 1);
         const size_t per_tile = (size_t)(cn::kSarlGroups / (H < 1 ? 1 : H));
         s->narrow_tiles = per_tile ? (s->n_groups + per_tile - 1) / per_tile : 0;
-        s->narrow_lds = cn::sarl_narrow_lds_bytes(net);
+        s->narrow_lds = cn::sarl_narrow_lds_bytes(net, lstm);
         s->fused_step = env_int("CROWDNAV_AMD_SARL_FUSED_STEP", 1) != 0 && e->P.threads == 64 && !e->P.kd;
-        s->narrow = !lstm && !s->chunked && !s->reg_mlp && (in_dim == 13 || (C.with_om && !cadrl)) && !C.sort_lookahead && H >= 1 &&
+        // LSTM-RL (round 6): lstm_rl.ValueNetwork1 with the environment queried (the joint state LstmRL.predict sorted feeds the
+        // network only under the constant-velocity model); its straight-line k loops hold W_ih rows of up to 80 inputs and W_hh
+        // of up to 60 hidden units
+        const bool lstm_ok = !lstm || (!pairwise && net.L[cn::kL_mlp1_0].kpad <= 4 * cn::kSarlKChunk &&
+                                       net.L[cn::kL_mlp1_2].kpad <= 3 * cn::kSarlKChunk && net.L[cn::kL_mlp3_0].kpad <= cn::kNarrowK);
+        s->narrow = lstm_ok && !s->chunked && !s->reg_mlp && (in_dim == 13 || (C.with_om && !cadrl)) && !C.sort_lookahead && H >= 1 &&
                     H <= cn::kSarlMaxHumans && s->narrow_lds <= 160 * 1024 &&
                     (narrow_mode == 2 || (narrow_mode == 1 && s->narrow_tiles <= (size_t)s->n_cus));
     }
@@ -319,7 +324,7 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->ref.L[l] = cn::LayerRef{(uint32_t)(L.w - s->arena), (uint32_t)(L.bias - s->arena),
                                    (uint32_t)L.kpad | ((uint32_t)L.ctiles << 8) | ((uint32_t)L.ksteps << 16)};
     }
-    s->ref.nf = net.L[cn::kL_mlp2_2].N, s->ref.with_global = net.with_global;
+    s->ref.nf = lstm ? hid : net.L[cn::kL_mlp2_2].N, s->ref.with_global = net.with_global;  // (LSTM-RL: the hidden width)
     s->ref.ks_x = net.ks_x, s->ref.ks_a = net.ks_a, s->ref.ks_b = net.ks_b, s->ref.ks_c = net.ks_c, s->ref.ks_s = net.ks_s;
     e->sarl = s;
     guard.p = nullptr;
@@ -482,7 +487,8 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
                                e->S.vel, e->S.rv, s->orca_vel, s->next_obs, s->om);
         cn::SarlDecide D0{};
         D0.in_dim = s->net.in_dim;
-        hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
+        const auto narrow_kernel = s->cfg.model == CN_MODEL_LSTM_RL ? cn::sarl_narrow_kernel<true> : cn::sarl_narrow_kernel<false>;
+        hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)s->narrow_tiles), dim3(cn::kNarrowThreads), s->narrow_lds,
                            e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
                            s->next_obs, s->V, D0, C.with_om ? (const float*)s->om : (const float*)nullptr);
         e->launch_counts[CN_COUNT_SARL_NARROW] += 1;
@@ -662,7 +668,8 @@ int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* b
         // the replay-memory states on a workgroup of their own beside the tiles (CROWDNAV_AMD_SARL_SIDE_WG=0: on tile b's idle wave)
         static const bool side = env_int("CROWDNAV_AMD_SARL_SIDE_WG", 1) != 0;
         D.side_wg = (side && state_out) ? 1 : 0;
-        hipLaunchKernelGGL(cn::sarl_narrow_kernel, dim3((unsigned)s->narrow_tiles + (unsigned)D.side_wg), dim3(cn::kNarrowThreads), s->narrow_lds,
+        const auto narrow_kernel = s->cfg.model == CN_MODEL_LSTM_RL ? cn::sarl_narrow_kernel<true> : cn::sarl_narrow_kernel<false>;
+        hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)s->narrow_tiles + (unsigned)D.side_wg), dim3(cn::kNarrowThreads), s->narrow_lds,
                            e->stream, s->ref, C, e->S.pos, e->S.vel, e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel,
                            s->next_obs, s->V, D, C.with_om ? (const float*)s->om : (const float*)nullptr);
         e->launch_counts[CN_COUNT_SARL_NARROW] += 1;

@@ -1610,6 +1610,12 @@ __device__ __noinline__ double narrow_reward(const SarlCfg& C, const double2* po
     return sarl_reward_of(C, pos, vel, goal, rv, gtime, theta, actions, b, a);
 }
 
+// LSTM (compile time): lstm_rl.ValueNetwork1 (lstm_rl.py:9-33) instead — the tile's rows are its 16 / H GROUPS, the humans are
+// the LSTM's steps: X of step t is a row tile of its own (xs[t]), the input half of the gates of every step (W_ih x_t + b_ih)
+// is computed up front with each wave holding its column tile of W_ih across the steps, the recurrent half with W_hh held in
+// registers across them; then the joint MLP on [self_state | h].  dense_mfma<1>'s arithmetic layer by layer and the gate
+// expressions of lstm_mlp_kernel: V is bit-identical to that kernel's.
+template <bool LSTM = false>
 __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef net, SarlCfg C, const double2* pos, const double2* vel,
                                                                      const double2* goal, const double2* rv, const double* theta,
                                                                      const double* actions, const float* orca_vel, double* next_obs,
@@ -1625,9 +1631,23 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     float* mbuf = kbuf + net.ks_a * 64;       // [ks_a][64]  value-head pong
     float* sbuf = mbuf + net.ks_a * 64;       // [64]        attention scores -> weights (row r at word r)
     float* vbuf = sbuf + 64;                  // [kSarlThreads] partial sums of attention.4
+    // LSTM: xs [H][ks_x][64] | gx [H][ks_g][64] input half of every step's gates | gates [ks_g][64] | hbuf [ks_h][64] |
+    // cbuf [hid][16] | jbuf, kbuf [ks_a][64] | sbuf | vbuf   (net.nf = the hidden width; sarl_narrow_lds_bytes)
+    const int lstm_ks_g = LSTM ? (int)((net.L[kL_mlp1_0].dims >> 8) & 0xffu) * 4 : 0, lstm_hid = LSTM ? net.nf : 0;
+    float* const gx = xs + C.H * net.ks_x * 64;
+    float* const gates = gx + C.H * lstm_ks_g * 64;
+    float* const hbuf = gates + lstm_ks_g * 64;
+    float* const cbuf = hbuf + sarl_ks(lstm_hid) * 64;
+    if (LSTM) {
+        jbuf = cbuf + lstm_hid * kSarlGroups, kbuf = jbuf + net.ks_a * 64, mbuf = kbuf;
+        sbuf = kbuf + net.ks_a * 64, vbuf = sbuf + 64;
+    }
     int* hc = reinterpret_cast<int*>(vbuf + kSarlThreads);  // [16] humans present in the tile's groups (H unless the `mixed` rule)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = C.H, GT = kSarlGroups / H, rows = GT * H;
+    // where row r = (group r / H, human r % H) of the tile keeps its features: its own row of the one X tile, or (LSTM) row
+    // `group` of its human's X tile
+    const auto xrow = [&](int r) { return LSTM ? (r % H) * net.ks_x * 64 + r / H : r; };
     const int n_groups = C.B * C.n_actions;
     const size_t tile = blockIdx.x;
     const unsigned n_tiles = gridDim.x - (unsigned)D.side_wg;
@@ -1678,8 +1698,9 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     lds_barrier();
     CN_SARL_TICK(0);
     if (row_valid) {
+        float* const x = xs + xrow(tid);
 #pragma unroll
-        for (int k = 0; k < 13; ++k) xs[(k >> 2) * 64 + (k & 3) * 16 + tid] = f[k];
+        for (int k = 0; k < 13; ++k) x[(k >> 2) * 64 + (k & 3) * 16] = f[k];
     }
     if (om != nullptr) {
         // occupancy maps (multi_human_rl.py:46-49): columns 13.. of a row are its human's map among the humans' NEXT states —
@@ -1695,14 +1716,14 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int kk = 13 + 4 * q + j;
-                    xs[(kk >> 2) * 64 + (kk & 3) * 16 + r] = m[j];
+                    xs[(kk >> 2) * 64 + (kk & 3) * 16 + xrow(r)] = m[j];
                 }
             }
         }
         for (int i = tid; i < rows * (extra & 3); i += kNarrowThreads) {  // (a cell count that is not a multiple of four)
             const int r = i / (extra & 3), k = 4 * quads + i - r * (extra & 3);
             const int base = row_om[r], kk = 13 + k;
-            if (base >= 0) xs[(kk >> 2) * 64 + (kk & 3) * 16 + r] = om[base + k];
+            if (base >= 0) xs[(kk >> 2) * 64 + (kk & 3) * 16 + xrow(r)] = om[base + k];
         }
     }
     BTile nxt = narrow_fetch(layer_of(*n, C.cadrl ? kL_mlp3_2 : kL_mlp1_2), wave, lane);
@@ -1760,6 +1781,87 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
             }
         }
     };
+    if constexpr (LSTM) {
+        const int hid = lstm_hid, ks_g = lstm_ks_g;
+        const PackedLinear Pi = layer_of(*n, kL_mlp1_0), Ph = layer_of(*n, kL_mlp1_2);  // weight_ih_l0 + bias_ih, weight_hh_l0 + bias_hh
+        const int col = lane & 15, quad = lane >> 4;
+        // W_hh: 4 hid / 16 column tiles on eight waves — both of a wave's tiles stay in registers across the steps (`nxt`: tile `wave`)
+        BTile hh2 = narrow_fetch(Ph, wave + kNarrowWaves, lane);
+        {   // the input half of the gates of EVERY step: gx[t] = W_ih x_t + b_ih (dense_mfma<1> with no extra term)
+            BTile t = cur;
+            for (int ct = wave; ct < Pi.ctiles; ct += kNarrowWaves) {
+                const bool more = ct + kNarrowWaves < Pi.ctiles;
+                BTile t2;
+                if (more) t2 = narrow_fetch(Pi, ct + kNarrowWaves, lane);
+                const int frag_off = ((ct * 4 + (col >> 2)) * 64) + (col & 3) * 16 + quad * 4;
+                const f32x4 addend = {t.bias, t.bias, t.bias, t.bias};
+                for (int tt = 0; tt < H; ++tt) {
+                    const float* afrag = xs + tt * net.ks_x * 64 + lane;
+                    const f32x4 acc = Pi.kpad <= 3 * kSarlKChunk ? narrow_k_loop<3>(afrag, t) : narrow_k_loop<4>(afrag, t);
+                    *reinterpret_cast<f32x4*>(gx + tt * ks_g * 64 + frag_off) = acc + addend;
+                }
+                if (more) t = t2;
+            }
+        }
+        reward_of_my_group();      // (the value head's wave has one column tile of W_ih where waves 0..4 have two)
+        replay_state_of_my_env();
+        cur = narrow_fetch(layer_of(*n, kL_mlp3_0), wave, lane);
+        lds_barrier();
+        for (int t = 0; t < H; ++t) {
+            // gates = (W_hh h + b_hh) + gx[t]: h = 0 at the first step, multiplied out like every other (lstm_mlp_kernel does)
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int ct = wave + ci * kNarrowWaves;
+                if (ct < Ph.ctiles) {
+                    const BTile& w = ci ? hh2 : nxt;
+                    const int frag_off = ((ct * 4 + (col >> 2)) * 64) + (col & 3) * 16 + quad * 4;
+                    f32x4 addend = {w.bias, w.bias, w.bias, w.bias};
+                    addend += *reinterpret_cast<const f32x4*>(gx + t * ks_g * 64 + frag_off);
+                    const f32x4 acc = narrow_k_loop<3>(hbuf + lane, w);
+                    *reinterpret_cast<f32x4*>(gates + frag_off) = acc + addend;
+                }
+            }
+            lds_barrier();
+            for (int i = tid; i < hid * kSarlGroups; i += kNarrowThreads) {
+                const int g = i & 15, j = i >> 4;
+                if (g >= GT || t >= hc[g]) continue;  // (`mixed` rule: this group's episode has fewer humans)
+                auto at = [&](int k) { return gates[(k >> 2) * 64 + (k & 3) * 16 + g]; };
+                const float ig = 1.0f / (1.0f + expf(-at(j)));
+                const float fg = 1.0f / (1.0f + expf(-at(hid + j)));
+                const float gg = tanhf(at(2 * hid + j));
+                const float og = 1.0f / (1.0f + expf(-at(3 * hid + j)));
+                const float c = fg * cbuf[i] + ig * gg;
+                cbuf[i] = c;
+                hbuf[(j >> 2) * 64 + (j & 3) * 16 + g] = og * tanhf(c);
+            }
+            lds_barrier();
+        }
+        nxt = narrow_fetch(layer_of(*n, kL_mlp3_2), wave, lane);
+        // joint state [self_state = state[:, 0, :6] | h_n], row = group (lstm_rl.py:29-31)
+        if (tid < kSarlGroups * 6 && (tid & 15) < GT) {
+            const int g = tid & 15, f6 = tid >> 4;
+            jbuf[(f6 >> 2) * 64 + (f6 & 3) * 16 + g] = xs[(f6 >> 2) * 64 + (f6 & 3) * 16 + g];
+        }
+        for (int i = tid; i < hid * kSarlGroups; i += kNarrowThreads) {
+            const int g = i & 15, j = i >> 4, f = 6 + j;
+            if (g < GT) jbuf[(f >> 2) * 64 + (f & 3) * 16 + g] = hbuf[(j >> 2) * 64 + (j & 3) * 16 + g];
+        }
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_0), jbuf, kbuf, true, nullptr, wave, lane, cur);
+        cur = narrow_fetch(layer_of(*n, kL_mlp3_4), wave, lane);
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_2), kbuf, jbuf, true, nullptr, wave, lane, nxt);
+        nxt = narrow_fetch(layer_of(*n, kL_mlp3_6), wave, lane);
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_4), jbuf, kbuf, true, nullptr, wave, lane, cur);
+        lds_barrier();
+        dense_narrow(layer_of(*n, kL_mlp3_6), kbuf, jbuf, false, nullptr, wave, lane, nxt);  // column 0 of the tile: row r at word r
+        lds_barrier();
+        const float v = (wave == kNarrowWaves - 1 && lane < GT) ? jbuf[lane] : 0.0f;
+        CN_SARL_CLOCK_END();
+        finish(v);
+        return;
+    }
     if (C.cadrl) {
         // cadrl.ValueNetwork (cadrl.py:22-29): the same MLP for every (robot, human) row — cadrl_mlp_kernel's four layers on the
         // tile's 16 rows — then the minimum over the humans of a group (cadrl.py:162-163: the first minimum's value)
@@ -1900,7 +2002,12 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     CN_SARL_CLOCK_END();
     finish(v);
 }
-__host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net) {
+__host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net, bool lstm = false) {
+    if (lstm) {  // sarl_narrow_kernel<true>'s carve: xs, gx, gates, hbuf, cbuf, jbuf, kbuf, sbuf, vbuf, hc
+        const size_t H = (size_t)net.H, ks_g = (size_t)net.L[kL_mlp1_0].ctiles * 4, hid = (size_t)net.L[kL_mlp1_2].K;
+        return sizeof(float) * (64 * (H * net.ks_x + H * ks_g + ks_g + (size_t)sarl_ks((int)hid) + 2 * (size_t)net.ks_a + 1) +
+                                hid * kSarlGroups + kSarlThreads + 16);
+    }
     return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads + 16);
 }
 

@@ -231,6 +231,7 @@ struct EpisodeLds {  // at Smem::disc + 8 (one robot per workgroup)
     double gtime, cur_return, cur_dsum;
     int cur_steps, cur_danger, ep_count, ring_filled, state;
     unsigned int transitions;
+    unsigned int dyn_total;  // dynamic schedule: transitions of all the visits this workgroup ran (not a register held across them)
 };
 static_assert(sizeof(EpisodeLds) <= 8 * (kCompactScratchDoubles - 8), "EpisodeLds outgrew its LDS slot");
 
@@ -254,9 +255,9 @@ struct Lane {
     size_t gi;                // env * A + a
 };
 
-__device__ __forceinline__ Lane lane_of(const Params& P, int block = -1) {
+__device__ __forceinline__ Lane lane_of(const Params& P, int block = -1, int tid = -1) {
     Lane L;
-    L.lane = threadIdx.x;
+    L.lane = tid < 0 ? (int)threadIdx.x : tid;
     const int el = L.lane / P.A;
     L.a = L.lane - el * P.A;
     L.env = (block < 0 ? (int)blockIdx.x : block) * P.E + el;
@@ -816,8 +817,15 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
             }
             int rank = 0;
             if (KD) {
+                // squared distances are +0 .. +inf: their bit patterns order like the floats, and bit 31 of the 32-bit difference
+                // says v < mine.  v_sub_u32 + v_alignbit_b32 (shift the sign into a 20-bit word) per candidate and one popcount,
+                // instead of v_cmp -> vcc -> v_cndmask / v_addc with a two-state hazard s_nop between each pair (gfx950): 41
+                // issue slots per pass instead of 60, nothing through VCC.
+                const uint32_t mb = __float_as_uint(mine);
+                uint32_t nearer = 0u;
 #pragma unroll
-                for (int k = 0; k < 20; ++k) rank += v[k] < mine ? 1 : 0;
+                for (int k = 0; k < 20; ++k) nearer = __builtin_amdgcn_alignbit(nearer, __float_as_uint(v[k]) - mb, 31);
+                rank = __popc(nearer);
             } else {
 #pragma unroll
                 for (int k = 0; k < 20; ++k) rank += ((v[k] < mine) | ((v[k] == mine) & (k < c))) ? 1 : 0;
@@ -1757,7 +1765,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
     }
     constexpr bool kDyn = HEADLINE && MAXL == 10;
     const bool dynamic = kDyn && P.sched == kSchedDynamic;
-    unsigned int dyn_transitions = 0u;  // (lane 0) transitions of all the visits this workgroup ran
+    if (kDyn && threadIdx.x == 0) reinterpret_cast<EpisodeLds*>(s.disc + 8)->dyn_total = 0u;
     const int n_steps_call = n_steps;
     for (int visit_iter = 0; dynamic || visit_iter == 0; ++visit_iter) {
     int dyn_env = 0, dyn_k = 0;
@@ -1970,7 +1978,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
         if (robot) {
             const cn_rollout_io io = *R.io;
             if (io.env_transitions) io.env_transitions[L.env] += (uint64_t)transitions;
-            dyn_transitions += transitions;
+            eps->dyn_total += transitions;
         }
         // release: this env's state, bookkeeping and kd rows are in memory before its next visit may start anywhere
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1989,6 +1997,7 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
         io.blocks = nullptr, io.summary = nullptr, io.env_transitions = nullptr;
         Lane Le;
         Le.lane = threadIdx.x, Le.env = (int)blockIdx.x, Le.a = threadIdx.x == 0 ? 0 : 1, Le.ebase = 0, Le.valid = true, Le.gi = 0;
+        const unsigned int dyn_transitions = threadIdx.x == 0 ? reinterpret_cast<EpisodeLds*>(s.disc + 8)->dyn_total : 0u;
         rollout_epilogue(P, *Sd, io, Le, threadIdx.x == 0, dyn_transitions, 0, reinterpret_cast<double*>(s.lines));
     }
 }

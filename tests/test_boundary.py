@@ -239,3 +239,24 @@ def test_per_env_transition_counters_and_statistics_on_request(amd, monkeypatch,
     want = _np(bufs2['summary'])
     assert np.array_equal(got[:5], want[:5]) and got[7] == want[7] and got[0] == _np(bufs['ep_count']).sum() > 0
     assert np.abs(got[5:7] - want[5:7]).max() <= 1e-9 * max(1.0, np.abs(want[5:7]).max())
+
+
+def test_seed_numbering_is_fixed_by_rollout_begin(amd):
+    """cn_rollout / cn_rollout_step accept a changed io, but the scenario cache of a 20-human rollout was sized by
+    cn_rollout_begin's seed_mod and filled for its seed_base — a later io with other values is refused (CN_ERR_INVALID) instead
+    of indexing past the cache or being served the old seeds' scenarios; a new cn_rollout_begin renumbers."""
+    eng = amd.BatchedCrowdSim(num_envs=8, num_humans=20, robot_policy=amd.ROBOT_ORCA, robot_visible=1, circle_radius=12.0)
+    eng.rollout_begin(seed_base=1000, seed_mod=7, episode_limit=-1, record_capacity=2)
+    eng.rollout(30)
+    io = eng._rollout[0]
+    for field, value in (('seed_mod', 100000), ('seed_base', 5)):
+        keep = getattr(io, field)
+        setattr(io, field, value)
+        with pytest.raises(amd.CrowdNavAmdError, match='cn_rollout_begin'):
+            eng.rollout(3)
+        setattr(io, field, keep)
+    eng.rollout(3)  # the unchanged io still runs
+    eng.rollout_begin(seed_base=5, seed_mod=100000, episode_limit=-1, record_capacity=2)
+    eng.rollout(30)
+    eng.sync()
+    eng.close()

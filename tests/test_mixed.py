@@ -200,8 +200,8 @@ def test_value_networks_mask_the_absent_humans_of_a_mixed_episode(policy, kernel
     """SARL (attention: mean and softmax over the humans present), CADRL (minimum over them) and LSTM-RL (one LSTM step per
     human present) on episodes with 1, 2, 3 and 5 humans, vs the unmodified reference acting under test_sim = mixed.  At this
     batch size the LDS kernels run; CROWDNAV_AMD_SARL_REG=2 forces the register-resident ones; CROWDNAV_AMD_SARL_NARROW=2 the
-    narrow tiles of the single-episode sampling route (round 6: SARL and CADRL mask a group's absent humans there as well; LSTM-RL
-    has no narrow kernel) — the launch counter says which ran."""
+    narrow tiles of the single-episode sampling route (round 6: SARL and CADRL mask a group's absent humans there as well,
+    LSTM-RL skips their steps) — the launch counter says which ran."""
     import torch
     import crowdnav_amd
     if kernels == 'register-resident':
@@ -232,7 +232,7 @@ def test_value_networks_mask_the_absent_humans_of_a_mixed_episode(policy, kernel
     eng.sarl_set_weights(net.state_dict())
     out = eng.sarl_select()
     eng.sync()
-    assert eng.launch_counts()['sarl_narrow'] == (1 if kernels == 'narrow-tiles' and policy != 'lstm_rl' else 0)
+    assert eng.launch_counts()['sarl_narrow'] == (1 if kernels == 'narrow-tiles' else 0)
     values = out['values'].cpu().numpy()
     assert np.abs(values - g[pre + 'values']).max() <= 1e-6
     top2 = np.sort(g[pre + 'values'], axis=1)[:, -2:]

@@ -214,7 +214,8 @@ def test_transform_matches_host_transform(with_om):
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,humans,n_act,with_om', [(1, 5, 81, False), (3, 5, 81, False), (16, 5, 81, False), (2, 3, 81, False),
                                                     (40, 5, 81, False), (6, 1, 13, False), (9, 2, 5, False),
-                                                    (1, 5, 81, True), (3, 5, 81, True), (2, 3, 81, True), (9, 2, 5, True)])
+                                                    (1, 5, 81, True), (3, 5, 81, True), (2, 3, 81, True), (9, 2, 5, True),
+                                                    (1, 5, 81, 'lstm_rl'), (3, 4, 81, 'lstm_rl'), (2, 5, 81, 'lstm_rl + maps')])
 def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, monkeypatch):
     """cn_sarl_sample_step (ABI v8) = alive &= ~done; cn_sarl_select; cn_sarl_explore(mask = alive); cn_sarl_transform;
     cn_step.  Three engines on the same seeds and weights for 104 steps (every episode ends, envs leave `alive`, the epsilon-greedy
@@ -227,14 +228,24 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
     small action table — FEWER narrow tiles than envs (6 envs x 13 actions of one human are 5 tiles, 9 x 5 of two humans
     6): every env's replay-memory state must still be written.  with_om (round 6): occupancy maps on the narrow route — the
     maps of the next decision come from sarl_decide_step_kernel (streamed calls) or sarl_lookahead_kernel (after another entry
-    point); the launch counters prove which kernels ran."""
+    point); the launch counters prove which kernels ran.  'lstm_rl' (round 6): lstm_rl.ValueNetwork1 on the narrow tiles
+    (sarl_narrow_kernel<true>); its replay-memory states are in LstmRL.predict's order (humans by decreasing distance)."""
     import ctypes as C
     import crowdnav_amd
     from crowdnav_amd._lib import check
+    from crowdnav_amd.compat import lstm_rl
     from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
     torch.manual_seed(21)
+    lstm = isinstance(with_om, str)
+    if lstm:
+        with_om = with_om.endswith('maps')
     D = 61 if with_om else 13
-    net = ValueNetwork(D, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    if lstm:
+        net = lstm_rl.ValueNetwork1(D, 6, [150, 100, 100, 1], 50)
+        net_kwargs = dict(model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
+    else:
+        net = ValueNetwork(D, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+        net_kwargs = {}
     space, _, _ = build_action_space(1.0)
     T = 104
 
@@ -242,7 +253,7 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
         monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
         monkeypatch.setenv('CROWDNAV_AMD_SARL_FUSED_STEP', fused)
         eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=0)
-        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space[:n_act]]), with_om=with_om)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space[:n_act]]), with_om=with_om, **net_kwargs)
         eng.sarl_set_weights(net.state_dict())
         eng.reset(7000 + np.arange(B))
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
@@ -264,7 +275,7 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
                 best = V(act.data_ptr() + 4 * B * t)
                 check(lib.cn_sarl_select(h, None, best, V(action.data_ptr())))
                 check(lib.cn_sarl_explore(h, 0.3, V(alive.data_ptr()), best, V(action.data_ptr()), None))
-                check(lib.cn_sarl_transform(h, V(traj.data_ptr() + 4 * humans * D * t), T * humans * D, 0))
+                check(lib.cn_sarl_transform(h, V(traj.data_ptr() + 4 * humans * D * t), T * humans * D, 1 if lstm else 0))
                 check(lib.cn_step(h, V(action.data_ptr()), 1, V(rew.data_ptr() + 8 * B * t), V(done.data_ptr()), V(inf.data_ptr() + B * t),
                                   V(dmn.data_ptr() + 8 * B * t), None, None, None))
                 alive_hist.append(alive.clone())
@@ -285,7 +296,8 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,model_on_gpu', [('rl_sarl_plain.npz', False), ('rl_sarl_plain.npz', True), ('rl_cadrl.npz', True),
-                                               ('rl_lstm_rl.npz', True), ('rl_sarl_om.npz', False), ('rl_sarl_om.npz', True)])
+                                               ('rl_lstm_rl.npz', False), ('rl_lstm_rl.npz', True), ('rl_lstm_rl_om.npz', True),
+                                               ('rl_sarl_om.npz', False), ('rl_sarl_om.npz', True)])
 def test_single_episode_sampling_calls_reproduce_the_reference_memory(name, model_on_gpu):
     """train.py:156-170 samples ONE episode per call: the same fixtures with max_envs = 1 — every episode its own one-env batch
     (the narrow-tile route of cn_sarl_sample_step for SARL, one episode's slices of the histories as replay rows).  With the
@@ -323,16 +335,13 @@ def test_single_episode_sampling_calls_reproduce_the_reference_memory(name, mode
     if states.ndim == 2:
         states = states[:, None, :]
     assert np.abs(states - g['memory_states']).max() <= 5e-6 and np.abs(values - g['memory_values']).max() <= 1e-6
-    if model_on_gpu and name != 'rl_lstm_rl.npz':
+    if model_on_gpu and not name.startswith('rl_lstm_rl'):
         assert ex._td_graph is not None   # (an nn.LSTM forward may refuse capture: then the eager path ran, with a warning)
-    # which route sampled: SARL (with or without occupancy maps: round 6) and CADRL take the narrow tiles + the fused decision /
-    # transition kernel — two launches per streamed step; LSTM-RL runs the one-tile kernels inside the same call
+    # which route sampled: SARL and LSTM-RL (with or without occupancy maps: round 6) and CADRL take the narrow tiles + the fused
+    # decision / transition kernel — two launches per streamed step
     counts = ex._rl_engine_cache[1].launch_counts()
     steps_issued = counts['sarl_narrow']
-    if name == 'rl_lstm_rl.npz':
-        assert steps_issued == 0
-    else:
-        assert steps_issued >= int(g['ep_steps'].sum()) and counts['sarl_decide_steps'] == steps_issued
+    assert steps_issued >= int(g['ep_steps'].sum()) and counts['sarl_decide_steps'] == steps_issued
 
 
 @pytest.mark.gpu

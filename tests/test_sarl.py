@@ -179,6 +179,42 @@ def test_narrow_tile_cadrl_network_is_bit_identical_to_the_one_tile_kernel(human
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans,B,with_om', [(5, 1, False), (5, 3, False), (5, 1, True), (5, 2, True), (1, 3, False), (2, 3, True),
+                                              (3, 2, False), (4, 2, True), (8, 2, False)])
+def test_narrow_tile_lstm_rl_network_is_bit_identical_to_the_one_tile_kernel(humans, B, with_om, monkeypatch):
+    """lstm_rl.ValueNetwork1 on the narrow tiles (round 6; sarl_narrow_kernel<true>: rows = the tile's 16 / H groups, the humans
+    are the LSTM's steps, W_ih x_t of every step up front, W_hh held in registers across the steps): the same bits as
+    sarl_feature_kernel + lstm_mlp_kernel (CROWDNAV_AMD_SARL_NARROW=0), within 2e-5 of the torch module; the launch counter
+    proves which route ran (61-wide rows at 8 humans need more LDS than a workgroup has: both runs take the one-tile kernels)."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import lstm_rl
+    from crowdnav_amd.compat.sarl import build_action_space
+    torch.manual_seed(70 + humans)
+    d = 61 if with_om else 13
+    net = lstm_rl.ValueNetwork1(d, 6, [150, 100, 100, 1], 50)
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for narrow in ('2', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+        eng.reset(7000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='lstm_rl', mlp1_dims=(50, 1),
+                           mlp3_dims=(150, 100, 100, 1), with_om=with_om)
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        assert eng.launch_counts()['sarl_narrow'] == (1 if narrow == '2' else 0)
+        got[narrow] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), out['action'].cpu().numpy(),
+                       out['values'].cpu().numpy(), eng.sarl_export('X').cpu(), eng.sarl_export('next_obs').cpu().numpy())
+        eng.close()
+    with torch.no_grad():
+        want = net(got['2'][4].reshape(B * 81, humans, d)).reshape(B, 81).numpy()
+    assert np.abs(got['2'][0] - want).max() <= 2e-5
+    for a, b in zip(got['2'], got['0']):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True, 'maps inside the kernel'])
 def test_register_resident_and_lds_value_networks_agree(with_om, monkeypatch):
     """5 humans at the shipped widths run sarl_reg_kernel (activations in registers); CROWDNAV_AMD_SARL_REG=0 keeps the LDS
