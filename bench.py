@@ -430,7 +430,7 @@ def measure_policy_decision(B, H, policy, local_rank, iters=20):
                          'note': 'algorithmic flops (unpadded layer widths) over the HIP-event time of cn_sarl_select'}}
 
 
-def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False):
+def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False, policy='sarl'):
     """BASELINE configs[4]'s in-scope piece: one train-phase sampling step (train.py:156-170 -> explorer.py:56-65 with
     multi_human_rl.py:11-63 behind robot.act) of ONE env — cn_sarl_sample_step streamed `steps` times without a host check,
     HIP events around the stream, the median of `repeats` episodes.  SARL at the shipped widths, 5 humans, 81 actions, random-init
@@ -443,9 +443,15 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False)
                                        device=local_rank)
     torch.manual_seed(0)
     D = 61 if with_om else 13
-    net = ValueNetwork(D, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+    net_kwargs = {}
+    if policy == 'lstm_rl':  # lstm_rl.ValueNetwork1 at policy.config's widths (round 6: sarl_narrow_kernel<true>)
+        from crowdnav_amd.compat import lstm_rl
+        net = lstm_rl.ValueNetwork1(D, 6, [150, 100, 100, 1], 50)
+        net_kwargs = dict(model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
+    else:
+        net = ValueNetwork(D, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
     space, _, _ = build_action_space(1.0)
-    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om)
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), with_om=with_om, **net_kwargs)
     eng.sarl_set_weights(net.state_dict())
     z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
     traj, rew, inf, dmn = (z((envs, steps, 5, D), torch.float32), z((steps, envs), torch.float64), z((steps, envs), torch.uint8),
@@ -473,7 +479,8 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False)
     per_step = sorted(times[1:])[len(times[1:]) // 2]
     calls = (repeats + 1) * steps
     return {'workload': '%d env x 5 humans, 81 actions, %s: cn_sarl_sample_step (decision + epsilon-greedy + replay state + '
-                        'transition), %d steps streamed' % (envs, 'OM-SARL (occupancy maps)' if with_om else 'SARL', steps),
+                        'transition), %d steps streamed' % (envs, ('LSTM-RL' if policy == 'lstm_rl' else 'SARL') if not with_om else
+                                                            ('LSTM-RL with occupancy maps' if policy == 'lstm_rl' else 'OM-SARL (occupancy maps)'), steps),
             'value': envs / per_step, 'unit': 'env-steps/s', 'us_per_step': per_step * 1e6,
             'launches_per_step': 2 if (counts['sarl_narrow'], counts['sarl_decide_steps']) == (calls, calls) else None,
             'launch_counts': {k: counts[k] for k in ('sarl_narrow', 'sarl_decide_steps')}, 'calls': calls,
@@ -502,6 +509,8 @@ def secondary(B, local_rank):
     out['sample_step'] = measure_sample_step(local_rank)
     out['sample_step']['cpu_baseline'] = reference_sampling_baseline()
     out['sample_step']['om_sarl'] = measure_sample_step(local_rank, with_om=True)
+    out['sample_step']['lstm_rl'] = measure_sample_step(local_rank, policy='lstm_rl')
+    out['sample_step']['lstm_rl_om'] = measure_sample_step(local_rank, with_om=True, policy='lstm_rl')
     out['config5_schedule'] = config5_schedule_estimate()
     return out
 

@@ -40,7 +40,9 @@ for l in open('$OUT/bench_driver.log'):
             if k in s: print(k, round(s[k]['value'] / 1e6, 3), 'M env-steps/s, select ms', round(s[k]['roofline']['select_ms'], 3), 'mfma frac', round(s[k]['roofline']['frac'], 3))
         for k in ('cadrl', 'lstm_rl'):
             if k in s: print(k, 'select ms', round(s[k]['roofline']['select_ms'], 3), 'mfma frac', round(s[k]['roofline']['frac'], 3))
-        if 'sample_step' in s: print('sample_step', round(s['sample_step']['us_per_step'], 1), 'us per sampled step of one env,', s['sample_step']['launches_per_step'], 'launches')
+        if 'sample_step' in s:
+            print('sample_step', round(s['sample_step']['us_per_step'], 1), 'us per sampled step of one env,', s['sample_step']['launches_per_step'], 'launches;',
+                  ', '.join('%s %.1f us (%s launches)' % (k, v['us_per_step'], v['launches_per_step']) for k, v in s['sample_step'].items() if isinstance(v, dict) and 'us_per_step' in v))
         for k, v in (s.get('h20') or {}).items():
             if isinstance(v, dict) and 'value' in v: print('h20', k, round(v['value'] / 1e6, 2), 'M env-steps/s, paused', v.get('paused_env_steps'))
         print('cpu', {k: (round(v) if isinstance(v, float) else v) for k, v in (d.get('cpu_baseline') or {}).items() if k in ('value', 'cores', 'single_core_value')})

@@ -127,7 +127,8 @@ def test_secondary_rows_carry_their_cpu_baseline(monkeypatch):
         'config': {'workload': 'w'}})
     monkeypatch.setattr(bench, 'measure_policy_decision', lambda B, H, policy, lr: {'decisions_per_s': 1.0})
     monkeypatch.setattr(bench, 'measure_h20', lambda B, lr: {'r12': {}})
-    monkeypatch.setattr(bench, 'measure_sample_step', lambda lr, with_om=False: {'value': 2.0 if with_om else 1.0})
+    monkeypatch.setattr(bench, 'measure_sample_step',
+                        lambda lr, with_om=False, policy='sarl': {'value': (2.0 if with_om else 1.0) + (10.0 if policy == 'lstm_rl' else 0.0)})
     monkeypatch.setattr(bench, 'cpu_baseline_h20', lambda: {'kind': 'port'})
     seen = []
     monkeypatch.setattr(bench, 'reference_decision_baseline', lambda pol: seen.append(pol) or {'policy': pol})
@@ -140,6 +141,7 @@ def test_secondary_rows_carry_their_cpu_baseline(monkeypatch):
     assert out['cadrl']['cpu_baseline'] == {'policy': 'cadrl'} and out['lstm_rl']['cpu_baseline'] == {'policy': 'lstm_rl'}
     assert out['sample_step']['cpu_baseline'] == {'unit': 'env-steps/s'} and out['h20']['cpu_baseline'] == {'kind': 'port'}
     assert out['sample_step']['value'] == 1.0 and out['sample_step']['om_sarl']['value'] == 2.0
+    assert out['sample_step']['lstm_rl']['value'] == 11.0 and out['sample_step']['lstm_rl_om']['value'] == 12.0
     assert 'reference_estimate_s' in out['config5_schedule']
 
 
