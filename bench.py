@@ -430,11 +430,13 @@ def measure_policy_decision(B, H, policy, local_rank, iters=20):
                          'note': 'algorithmic flops (unpadded layer widths) over the HIP-event time of cn_sarl_select'}}
 
 
-def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False, policy='sarl'):
+def measure_sample_step(local_rank, envs=1, steps=28, repeats=24, with_om=False, policy='sarl'):
     """BASELINE configs[4]'s in-scope piece: one train-phase sampling step (train.py:156-170 -> explorer.py:56-65 with
     multi_human_rl.py:11-63 behind robot.act) of ONE env — cn_sarl_sample_step streamed `steps` times without a host check,
-    HIP events around the stream, the median of `repeats` episodes.  SARL at the shipped widths, 5 humans, 81 actions, random-init
-    weights, epsilon 0.1."""
+    HIP events around the stream, the median of the `repeats` episodes that were still running at their last timed step (round
+    6: the kernels skip an env whose episode is over, and a skipped step is not a sampled step; the goal is 8 m away at 1 m/s
+    and 0.25 s per step, so 28 steps end an episode only by a collision).  The shipped widths, 5 humans, 81 actions,
+    random-init weights, epsilon 0.1."""
     import numpy as np
     import torch
     import crowdnav_amd
@@ -471,12 +473,15 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False,
                 step(t, 0.1)
             b.record()
             torch.cuda.synchronize()
-        times.append(a.elapsed_time(b) / 1e3 / steps)
+        if rep > 0 and not bool(done.any().item()):  # every timed step was a sampled one
+            times.append(a.elapsed_time(b) / 1e3 / steps)
     counts = eng.launch_counts()
     eng.close()
     del eng
     torch.cuda.empty_cache()
-    per_step = sorted(times[1:])[len(times[1:]) // 2]
+    if not times:
+        raise RuntimeError('measure_sample_step: every one of %d episodes ended within %d steps' % (repeats, steps))
+    per_step = sorted(times)[len(times) // 2]
     calls = (repeats + 1) * steps
     return {'workload': '%d env x 5 humans, 81 actions, %s: cn_sarl_sample_step (decision + epsilon-greedy + replay state + '
                         'transition), %d steps streamed' % (envs, ('LSTM-RL' if policy == 'lstm_rl' else 'SARL') if not with_om else
@@ -484,6 +489,7 @@ def measure_sample_step(local_rank, envs=1, steps=100, repeats=5, with_om=False,
             'value': envs / per_step, 'unit': 'env-steps/s', 'us_per_step': per_step * 1e6,
             'launches_per_step': 2 if (counts['sarl_narrow'], counts['sarl_decide_steps']) == (calls, calls) else None,
             'launch_counts': {k: counts[k] for k in ('sarl_narrow', 'sarl_decide_steps')}, 'calls': calls,
+            'episodes_timed': len(times),
             'kernels': 'cn::sarl_narrow_kernel (value network on 27 workgroups, reward, replay state), '
                                                'cn::sarl_decide_step_kernel (arg-max, draw, transition, next ORCA)',
             'note': 'round 4: ten launches, 70-80 us per step; the reference schedule of configs[4] samples 10 000 episodes this way '

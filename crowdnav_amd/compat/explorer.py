@@ -386,25 +386,46 @@ class Explorer(object):
                 # reward / min-distance / action / info histories are four regions of ONE byte buffer: one blocking copy
                 # brings all of them to the host (four of them were a tenth of a millisecond per sampled episode)
                 n = max_steps * B
-                packed = z((21 * n,), torch.uint8)
+                packed = z((20 * n,), torch.uint8)
                 rew_, dmn_ = packed[:8 * n].view(torch.float64).view(max_steps, B), packed[8 * n:16 * n].view(torch.float64).view(max_steps, B)
-                act_, inf_ = packed[16 * n:20 * n].view(torch.int32).view(max_steps, B), packed[20 * n:].view(max_steps, B)
+                act_ = packed[16 * n:20 * n].view(torch.int32).view(max_steps, B)
+                # the info codes go to PINNED host memory: the kernels only write them, and the host watches the episode ends
+                # arrive while it keeps issuing steps — no device synchronisation inside an episode (round 6; a check every 8
+                # steps was a bubble of ~40 us each time and 3.5 wasted steps per episode on average)
+                inf_ = torch.empty((max_steps, B), dtype=torch.uint8).pin_memory()
                 self._rl_hist = (hkey, z((B, max_steps, human_num, D), torch.float32), rew_, inf_, dmn_, act_,
                                  z((B,), torch.uint8), z((B,), torch.uint8), z((B, 2), torch.float64), packed)
             _, traj, rew, inf, dmn, act, alive, done, action, packed = self._rl_hist
             alive.fill_(1)
             done.zero_()
+            kUnwritten = 255
+            inf_np = inf.numpy()
+            inf_np.fill(kUnwritten)
             T = 0
             lap('weights + reset')
             # Per step: ONE library call (cn_sarl_sample_step: two launches at one env) and no torch kernel — every result
-            # lands in its row of the histories, and an env leaves `alive` at the start of the step after its episode ended
-            # (so "somebody still samples" is alive & ~done here)
+            # lands in its row of the histories, and an env leaves `alive` at the start of the step after its episode ended.
+            # The host runs at most `ahead` steps in front of the device (the rows of info it has seen arrive tell it where the
+            # device is) and stops issuing once every env's episode-end code is there; the steps already issued for an env
+            # that has finished are skipped by the kernels (two-launch route) or step a retired env (general route).
             step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
             eps = float(policy.epsilon)
+            ahead, seen, spins = int(os.environ.get('CROWDNAV_AMD_RL_AHEAD', '4')), 0, 0
+            finished = np.zeros(B, dtype=bool)
             for t in range(max_steps):
                 step(t, eps)
                 T = t + 1
-                if t % 8 == 7 and not bool((alive > done).any().item()):
+                while seen < T:  # rows the device has completed: every env that still samples has written its code
+                    row = inf_np[seen]
+                    if ((row != kUnwritten) | finished).all():
+                        finished |= (row != kUnwritten) & (row >= _lib.REACH_GOAL)
+                        seen += 1
+                        spins = 0
+                    elif T - seen > ahead and spins < 20000000:
+                        spins += 1   # (bounded: a device error surfaces at eng.sync() below instead of hanging here)
+                    else:
+                        break
+                if finished.all():
                     break
             eng.sync()
             lap('steps')
@@ -412,7 +433,8 @@ class Explorer(object):
                 prof['n_steps_issued'] = prof.get('n_steps_issued', 0) + T
             host, n = packed.cpu().numpy(), max_steps * B
             R, Dm = host[:8 * n].view(np.float64).reshape(max_steps, B)[:T], host[8 * n:16 * n].view(np.float64).reshape(max_steps, B)[:T]
-            Ac, I = host[16 * n:20 * n].view(np.int32).reshape(max_steps, B)[:T], host[20 * n:].reshape(max_steps, B)[:T]
+            Ac, I = host[16 * n:20 * n].view(np.int32).reshape(max_steps, B)[:T], inf_np[:T].copy()
+            I[I == kUnwritten] = _lib.NOTHING   # (rows behind an env's last step on the two-launch route)
             terminal = I >= _lib.REACH_GOAL
             if not terminal.any(axis=0).all():
                 raise ValueError('Invalid end signal from environment')

@@ -1643,8 +1643,15 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         sbuf = kbuf + net.ks_a * 64, vbuf = sbuf + 64;
     }
     int* hc = reinterpret_cast<int*>(vbuf + kSarlThreads);  // [16] humans present in the tile's groups (H unless the `mixed` rule)
+    int* const hl = hc + kSarlGroups;                       // [16] cn_sarl_sample_step: the group's env is still sampling
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = C.H, GT = kSarlGroups / H, rows = GT * H;
+    // cn_sarl_sample_step on the two-launch route: an env whose episode is over (alive[b] && !done[b] is false: the flags as the
+    // PREVIOUS call left them) needs no decision — a tile none of whose groups samples returns behind its prologue, the replay
+    // state of such an env is not written, sarl_decide_step_kernel skips its transition.  A caller that streams calls past the
+    // end of an episode (it cannot know the end without a round trip) pays two near-empty launches per dead step.
+    const bool skip_dead = D.value != nullptr && D.counter == nullptr && D.alive != nullptr;
+    const auto sampling = [&](int b) { return !skip_dead || (D.alive[b] != 0 && !(D.done != nullptr && D.done[b] != 0)); };
     // where row r = (group r / H, human r % H) of the tile keeps its features: its own row of the one X tile, or (LSTM) row
     // `group` of its human's X tile
     const auto xrow = [&](int r) { return LSTM ? (r % H) * net.ks_x * 64 + r / H : r; };
@@ -1659,6 +1666,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         const bool coop = C.with_om && !D.sort_humans && occupancy_coop_ok(C, occupancy_coop_bytes(H), 1);
         char* scratch = reinterpret_cast<char*>(lds) + (size_t)wave * ((occupancy_coop_bytes(H) + 15) & ~(size_t)15);
         for (int b = wave; b < C.B; b += kNarrowWaves) {
+            if (!sampling(b)) continue;
             if (lane < H) narrow_transform(C, D, pos, vel, goal, rv, theta, b, lane, !coop);
             if (coop) narrow_transform_maps(C, D, pos, vel, b, lane, scratch);
         }
@@ -1691,12 +1699,18 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
                 for (int j = 0; j < H; ++j) present += is_parked(pos[e0 + 1 + j]) ? 0 : 1;
             }
             hc[g] = present;
+            hl[g] = (row_valid && sampling((int)(G / C.n_actions))) ? 1 : 0;
         }
         // (occupancy maps) where this row's map starts in `om`; vbuf is not part of the zeroed region
         if (om != nullptr) reinterpret_cast<int*>(vbuf)[tid] = row_valid ? (int)(((G / C.n_actions) * H + h) * (size_t)(D.in_dim - 13)) : -1;
     }
     lds_barrier();
     CN_SARL_TICK(0);
+    if (skip_dead) {
+        int live = 0;
+        for (int g = 0; g < GT; ++g) live |= hl[g];
+        if (live == 0) return;  // (uniform: every thread reads the same words)
+    }
     if (row_valid) {
         float* const x = xs + xrow(tid);
 #pragma unroll
@@ -1776,6 +1790,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
             // (occupancy maps: the wave's lanes share them; mbuf — the value head's pong buffer — is idle until mlp3.0)
             const bool coop = C.with_om && !D.sort_humans && occupancy_coop_ok(C, sizeof(float) * 64 * (size_t)net.ks_a, 1);
             for (size_t b = tile; b < (size_t)C.B; b += n_tiles) {
+                if (!sampling((int)b)) continue;
                 if (lane < H) narrow_transform(C, D, pos, vel, goal, rv, theta, (int)b, lane, !coop);
                 if (coop) narrow_transform_maps(C, D, pos, vel, (int)b, lane, reinterpret_cast<char*>(mbuf));
             }
@@ -2006,9 +2021,9 @@ __host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net, bool lstm = fal
     if (lstm) {  // sarl_narrow_kernel<true>'s carve: xs, gx, gates, hbuf, cbuf, jbuf, kbuf, sbuf, vbuf, hc
         const size_t H = (size_t)net.H, ks_g = (size_t)net.L[kL_mlp1_0].ctiles * 4, hid = (size_t)net.L[kL_mlp1_2].K;
         return sizeof(float) * (64 * (H * net.ks_x + H * ks_g + ks_g + (size_t)sarl_ks((int)hid) + 2 * (size_t)net.ks_a + 1) +
-                                hid * kSarlGroups + kSarlThreads + 16);
+                                hid * kSarlGroups + kSarlThreads + 2 * kSarlGroups);
     }
-    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads + 16);
+    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads + 2 * kSarlGroups);
 }
 
 }  // namespace cn

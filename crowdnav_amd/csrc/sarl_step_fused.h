@@ -22,6 +22,7 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     if (L.valid) load_agent(S, L.gi, r);  // (requested in front of the decision's own loads: one round trip for both)
     // ---- the decision: the env's lanes stride over its actions, the robot's lane folds them in lane order (the largest value,
     // the lowest index on ties = the first strict maximum of the reference's loop; NaN and -inf never win)
+    bool samples = false;  // (robot lanes) this env's episode is still running
     {
         double bv = -__builtin_inf();
         int bi = -1;
@@ -53,9 +54,13 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
             D.action[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
             const bool keep = D.alive[b] && !(D.done && D.done[b]);  // (the previous call's flags: this call's are written below)
             D.alive[b] = keep ? 1 : 0;
+            samples = keep;
             sarl_explore_env(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, actions, !keep, D.best, D.action, nullptr, D.error, b);
         }
     }
+    // every env of this (one-wave) workgroup has finished its episode: nothing to step — a caller that streams calls past an
+    // episode's end pays an almost empty launch; the env's state, done flag and histories stay as its last step left them
+    if (blockDim.x == kWave && __ballot(samples) == 0ull) return;
     // ---- the transition: step_kernel's body (the robot's lane reads the action it has just written)
     float robot_max_speed = 0.0f;
     build_pairs(P, s);
@@ -63,7 +68,9 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     double theta = (L.valid && L.a == 0) ? S.theta[L.env] : 0.0;
     StepResult res;
     double nvx, nvy;
-    step_core<MAXL, UNI, false>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta);
+    // (the humans' velocities for this transition are the ones the previous call — or cn_launch_orca — left for the decision's
+    // lookahead: one ORCA pass per step, the one behind the transition, instead of two)
+    step_core<MAXL, UNI, false>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta, nullptr, next_orca_vel);
     if (L.valid) {
         if (L.a == 0) {
             io.reward[L.env] = res.reward;

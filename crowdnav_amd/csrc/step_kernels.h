@@ -984,10 +984,21 @@ template <int MAXL, bool UNI, bool KD, bool COMPACT = false>
 __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
                                           double& gtime, float robot_max_speed, const double* ext_action,
                                           int update, StepResult& res, double& new_vx, double& new_vy,
-                                          double* theta_io = nullptr, PhaseClock* clk = nullptr) {
+                                          double* theta_io = nullptr, PhaseClock* clk = nullptr, const float* known_vel = nullptr) {
     (void)clk;
-    float ovx, ovy;
-    orca_phases<MAXL, KD, COMPACT>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
+    float ovx = 0.0f, ovy = 0.0f;
+    if (known_vel != nullptr) {
+        // the humans' ORCA velocities of THIS state are known already ([B][A][2], orca_kernel's output: sarl_decide_step_kernel
+        // computed them behind the previous transition for the decision's lookahead — the same function of the same state);
+        // what the phases below read from LDS besides them: the agents' float64 positions and radii
+        if (L.lane < P.nA) {
+            s.posd[L.lane] = make_double2(r.px, r.py);
+            if (!COMPACT) s.rad[L.lane] = r.rad;
+        }
+        if (L.valid && L.a > 0) ovx = known_vel[2 * L.gi], ovy = known_vel[2 * L.gi + 1];
+    } else {
+        orca_phases<MAXL, KD, COMPACT>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
+    }
     new_vx = ovx;
     new_vy = ovy;
     // unicycle robot (ActionRot v, r): the collision test uses v (cos, sin)(r + theta) (crowd_sim.py:339-341), the

@@ -420,7 +420,8 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     alive &= ~done (the previous step's episode ends; zero `done` before an episode's first step), then cn_sarl_select ->
     cn_sarl_explore (mask = alive) -> cn_sarl_transform -> cn_step — with row t of the caller's histories (traj [B, T, H, D]
     float32; rew / dmin [T, B] float64; info [T, B] uint8; act [T, B] int32: the chosen action index) as outputs, addresses
-    precomputed.  For a few envs a streamed loop of these calls is two launches per step (include/crowdnav_amd.h)."""
+    precomputed.  For a few envs a streamed loop of these calls is two launches per step (include/crowdnav_amd.h); on that
+    route the kernels skip an env whose episode is over (its rows of the histories are not written any more)."""
     B, T, H, D = traj.shape
     if B != self.B or H != self.H:
         raise ValueError('traj is [%d, T, %d, D]; the engine holds %d envs x %d humans' % (B, H, self.B, self.H))
@@ -428,7 +429,10 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
              (dmin, torch.float64, (T, B)), (info, torch.uint8, (T, B)), (alive, torch.uint8, (B,)), (done, torch.uint8, (B,)),
              (action, torch.float64, (B, 2)))
     for t_, dt, shape in specs:  # raw addresses go to the C ABI below: every tensor on the engine's device, dense, as declared
-        if t_.device != self.device or t_.dtype != dt or tuple(t_.shape) != shape or not t_.is_contiguous():
+        # (info may live in PINNED host memory instead: the kernels only write it — posted stores over the host link — and a
+        # caller that streams steps can watch the episode-end codes arrive without a device synchronisation)
+        on_device = t_.device == self.device or (t_ is info and t_.device.type == 'cpu' and t_.is_pinned())
+        if not on_device or t_.dtype != dt or tuple(t_.shape) != shape or not t_.is_contiguous():
             raise ValueError('sarl_sampler: expected a contiguous %s %s tensor on %s, got %s %s on %s (contiguous: %s)'
                              % (dt, shape, self.device, t_.dtype, tuple(t_.shape), t_.device, t_.is_contiguous()))
     # the closure owns the tensors its addresses point into, but only a WEAK reference to the engine: stored on the engine or on

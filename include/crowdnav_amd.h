@@ -348,7 +348,15 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
  * calls above in every case (tests/test_rl_pipeline.py).  cn_sarl_select takes the same network kernel at these sizes (two
  * launches less).  CROWDNAV_AMD_SARL_NARROW=0 keeps the one-tile kernels, 2 takes the narrow tiles at any size the
  * configuration allows; CROWDNAV_AMD_SARL_FUSED_STEP=0 (and workgroups of several waves / simulators of more than 10
- * agents): ORCA, the network with the decision by its last workgroup, the transition — three launches. */
+ * agents): ORCA, the network with the decision by its last workgroup, the transition — three launches.
+ * Round 6: CN_MODEL_LSTM_RL (lstm_rl.ValueNetwork1, the environment queried) takes the two launches as well; the transition
+ * kernel reuses the humans' ORCA velocities the decision's lookahead was given (one ORCA pass per step); and on the two-launch
+ * route an env OUTSIDE alive (its episode is over) is SKIPPED: no decision, no replay-memory state, no transition — its
+ * state, its done flag and its entries of reward / info / dmin / best / state_out stay as its last sampled step left them
+ * (the other routes keep stepping such an env, as cn_step does; either way those outputs mean nothing).  A caller that
+ * cannot know an episode's end without a round trip may therefore stream a few calls past it at the price of two
+ * near-empty launches each; info (written, never read, by the kernels) may point into pinned host memory so that the host
+ * sees the episode-end codes arrive without synchronising (compat.Explorer._run_batched_rl). */
 int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
                         int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin);
 /* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):

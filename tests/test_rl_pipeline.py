@@ -219,7 +219,7 @@ def test_transform_matches_host_transform(with_om):
 def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, monkeypatch):
     """cn_sarl_sample_step (ABI v8) = alive &= ~done; cn_sarl_select; cn_sarl_explore(mask = alive); cn_sarl_transform;
     cn_step.  Three engines on the same seeds and weights for 104 steps (every episode ends, envs leave `alive`, the epsilon-greedy
-    draws continue each env's numpy stream): (a) the one call on the narrow-tile route (two launches per step — the network, then decision + transition + the
+    draws continue each env's numpy stream; the histories start from zero): (a) the one call on the narrow-tile route (two launches per step — the network, then decision + transition + the
     next decision's ORCA velocities in one kernel, with another entry point in between every 13 steps — and, with
     CROWDNAV_AMD_SARL_FUSED_STEP=0, three: ORCA, the network with the decision by its last workgroup, the transition; forced with
     CROWDNAV_AMD_SARL_NARROW=2: by size it is taken up to one workgroup per CU, 9 envs of 5 humans; 40 envs are 1080 tiles and
@@ -290,8 +290,16 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
 
     a, a2, b, c = run('2', True), run('2', True, fused='0'), run('0', True), run('0', False)
     assert (a[5][-1] == 0).all() and (a[5][0] == 1).all()   # every episode ended (time_limit / time_step = 100 steps at the latest)
-    for x, x2, y, w in zip(a, a2, b, c):
-        assert np.array_equal(x, x2) and np.array_equal(x, y) and np.array_equal(x, w)
+    # the three routes that step every env at every call agree everywhere; the two-launch route skips an env once its episode is
+    # over (round 6: its rows of the histories are not written any more, its state stays as the last step left it), so it is
+    # compared where the env was still sampling: alive after call t = the env took step t
+    for x2, y, w in zip(a2, b, c):
+        assert np.array_equal(x2, y) and np.array_equal(x2, w)
+    sampled = a[5].astype(bool)                               # [T, B]
+    assert np.array_equal(a[5], b[5])
+    assert np.array_equal(a[0][sampled.T], b[0][sampled.T])   # replay-memory states [B, T, H, D]
+    for k in (1, 2, 3, 4):                                    # reward, info, dmin, chosen action [T, B]
+        assert np.array_equal(a[k][sampled], b[k][sampled]), k
 
 
 @pytest.mark.gpu
