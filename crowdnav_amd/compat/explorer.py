@@ -376,7 +376,16 @@ class Explorer(object):
                 lap = lambda name: None  # noqa: E731
             eng = self._rl_engine(B, human_num, rule)
             eng.sarl_set_weights(policy.model.state_dict())
-            eng.reset(offset + start + c0 + np.arange(B))
+            # the seeds go up from a pinned buffer behind the weight re-pack, without a synchronisation (engine.reset waits
+            # for the scenarios: ~0.1 ms per sampled episode of device idle time in front of the first step)
+            skey = (id(eng), B)
+            if getattr(self, '_rl_seeds', (None,))[0] != skey:
+                self._rl_seeds = (skey, torch.empty(B, dtype=torch.int32).pin_memory(), torch.empty(B, dtype=torch.int32, device=eng.device))
+            _, seeds_host, seeds_dev = self._rl_seeds
+            seeds_host.numpy()[:] = (offset + start + c0 + np.arange(B)).astype(np.uint32).view(np.int32)
+            with torch.cuda.stream(eng._stream):
+                seeds_dev.copy_(seeds_host, non_blocking=True)
+            eng.reset_async(seeds_dev, None)
             # the histories live as long as the engine (one allocation + fill per shape, not five per sampled episode); every row
             # that is read below has been written by this call's steps, except traj's row T, which only feeds a value that
             # torch.where discards (stale rows are finite)
@@ -410,7 +419,7 @@ class Explorer(object):
             # that has finished are skipped by the kernels (two-launch route) or step a retired env (general route).
             step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
             eps = float(policy.epsilon)
-            ahead, seen, spins = int(os.environ.get('CROWDNAV_AMD_RL_AHEAD', '4')), 0, 0
+            ahead, seen, spins = int(os.environ.get('CROWDNAV_AMD_RL_AHEAD', '2')), 0, 0
             finished = np.zeros(B, dtype=bool)
             for t in range(max_steps):
                 step(t, eps)
