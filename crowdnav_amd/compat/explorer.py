@@ -46,6 +46,7 @@ class Explorer(object):
                 if src.keys() == dst.keys() and all(src[k].shape == dst[k].shape and src[k].dtype == dst[k].dtype and
                                                     src[k].device == dst[k].device for k in src):
                     old.load_state_dict(src)
+                    old.train(target_model.training)  # (what copy.deepcopy would have carried over besides the parameters)
                     return
             except RuntimeError:
                 pass
@@ -63,7 +64,9 @@ class Explorer(object):
                 or os.environ.get('CROWDNAV_AMD_TD_GRAPH', '1') == '0'):
             return model(x).reshape(-1)
         g = getattr(self, '_td_graph', None)
-        key = (id(model), tuple(x.shape[1:]), x.dtype)
+        # the graph replays reads of the parameters' STORAGE: a model whose parameters moved (.to(), .half(), load_state_dict(
+        # assign=True), another module at a recycled id) must be captured again, not replayed on the old weights
+        key = (id(model), tuple(x.shape[1:]), x.dtype, tuple(p.data_ptr() for p in model.parameters()), model.training)
         if g is None or g['key'] != key or g['x'].shape[0] < n:
             rows = max(128, 2 * n if g is not None and g['key'] == key else n)
             try:

@@ -1792,13 +1792,23 @@ __global__ __launch_bounds__(kMaxBlock, (MAXL == 10 && HEADLINE ? kGeom20Waves :
                     __builtin_amdgcn_s_sleep(16);
                     ++spins;
                 }
-                if (spins == (1 << 22)) atomicOr(Sd->error, 4);  // ~2 s: never in a healthy run; cn_sync reports it
+                // ~2 s: never in a healthy run; cn_sync reports it.  The visit is then NOT run on state its predecessor may still
+                // be writing: it is handed on as if complete, so that the env's later visits do not wait in turn —
+                // the env loses those steps, the error bit says so
+                if (spins == (1 << 22)) {
+                    atomicOr(Sd->error, 4);
+                    __hip_atomic_store(queue + 1 + env, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    s.flag[2] = 1;
+                } else {
+                    s.flag[2] = 0;
+                }
             }
             s.flag[1] = v;
         }
         __syncthreads();
         const int v = s.flag[1];
         if (v >= P.dyn_visits * P.B) break;
+        if (s.flag[2] != 0) continue;  // (the wait gave up)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: what the previous visit's workgroup wrote is visible
         dyn_env = v % P.B, dyn_k = v / P.B;
         env_block = dyn_env;

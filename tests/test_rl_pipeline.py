@@ -75,9 +75,39 @@ def test_target_model_updates_in_place_and_td_values_cpu():
     x = torch.randn(7, 5, 13)
     with torch.no_grad():
         assert torch.equal(ex._td_values(x), first(x).reshape(-1))
+    b.eval()
+    ex.update_target_model(b)                                # in place, and the mode travels with it as it would with deepcopy
+    assert ex.target_model is first and not first.training
+    b.train()
+    ex.update_target_model(b)
+    assert first.training
     other = ValueNetwork(13, 6, [64, 32], [32, 16], [64, 32, 32, 1], [32, 32, 1], True, 1.0, 4)
     ex.update_target_model(other)
     assert ex.target_model is not first and ex.target_model is not other
+
+
+@pytest.mark.gpu
+def test_td_value_graph_follows_parameters_that_move():
+    """the captured forward of the target network reads the parameters' storage — parameters that get NEW storage
+    (.to(), .half(), load_state_dict(assign=True), a user assigning explorer.target_model) must be captured again, not replayed
+    on the old weights."""
+    import crowdnav_amd.compat as c
+    from crowdnav_amd.compat.sarl import ValueNetwork
+    torch.manual_seed(4)
+    dev = torch.device('cuda:0')
+    net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4).to(dev)
+    ex = c.Explorer(None, None, dev, None, 0.9)
+    ex.update_target_model(net)
+    x = torch.randn(9, 5, 13, device=dev)
+    with torch.no_grad():
+        v0 = ex._td_values(x).clone()
+        assert ex._td_graph is not None and torch.allclose(v0, ex.target_model(x).reshape(-1), atol=1e-6)
+        graph0 = ex._td_graph['graph']
+        for p_ in ex.target_model.parameters():              # the same module, other storage, other values
+            p_.data = p_.data.clone() * 0.5
+        v1 = ex._td_values(x)
+        assert ex._td_graph['graph'] is not graph0
+        assert torch.allclose(v1, ex.target_model(x).reshape(-1), atol=1e-6) and not torch.allclose(v1, v0)
 
 
 def test_rl_fixture_is_self_consistent_cpu():
@@ -249,6 +279,14 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
     space, _, _ = build_action_space(1.0)
     T = 104
 
+    def nudge(eng, t):
+        # the humans' ORCA velocities the fused kernel left for the next decision belong to the state it wrote; any
+        # other entry point may change that state (here: every human 1-3 cm aside, alternating cn_set_state and a plain cn_step
+        # every route gets the same nudge at the same step)
+        st, gt = eng.get_state()
+        st[:, 1:, 0] += 0.01 * (1 + (t // 13) % 3)
+        eng.set_state(st, gt)
+
     def run(narrow, one_call, fused='1'):
         monkeypatch.setenv('CROWDNAV_AMD_SARL_NARROW', narrow)
         monkeypatch.setenv('CROWDNAV_AMD_SARL_FUSED_STEP', fused)
@@ -267,7 +305,7 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
                 step(t, 0.3)
                 alive_hist.append(alive.clone())
                 if t % 13 == 12:
-                    eng.get_state()   # any other entry point: the next call must not trust the velocities the last one left
+                    nudge(eng, t)   # another entry point CHANGES the state: the next call must not trust the velocities the last one left
         else:
             lib, h, V = eng._lib, eng._h, C.c_void_p
             for t in range(T):
@@ -279,6 +317,8 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
                 check(lib.cn_step(h, V(action.data_ptr()), 1, V(rew.data_ptr() + 8 * B * t), V(done.data_ptr()), V(inf.data_ptr() + B * t),
                                   V(dmn.data_ptr() + 8 * B * t), None, None, None))
                 alive_hist.append(alive.clone())
+                if t % 13 == 12:
+                    nudge(eng, t)
         eng.sync()
         counts = eng.launch_counts()
         if one_call:  # the route: narrow tiles for every step; decision + transition + next ORCA (+ maps) as one kernel when fused
