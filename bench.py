@@ -707,6 +707,7 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
     gc.collect()  # (before the warm-up launches: see no_gc)
     run(args.warmup)
     snap_t, snap_e = snapshot()
+    shard_boundary()  # once more behind everything else that runs before the clock starts (the snapshot's torch kernels)
     events = []
     fence()  # barrier + synchronize ...
     fence()  # ... twice: the first drains the warm-up launches and the snapshot copies, the second finds an idle device
@@ -717,13 +718,35 @@ def measure_orca(args, world, rank, local_rank, comm, inkernel, backend, fill_pr
         run(args.steps, events)
         drain(events[-1][1])  # this rank's K steps are done (synchronize) ...
         elapsed = time.perf_counter() - t0
-    counts1 = eng.launch_counts()
-    comm.barrier()  # ... and every rank's, before anything else is launched
-    with no_gc():
+        # (the collector stays off between the two regions: re-enabled here, the first allocation — the dict below — runs the
+        # collection the timed region deferred, and the boundary then opens on a device that has idled for that long:
+        # scripts/probes/boundary_probe2.py, 21.8 us behind a rollout launch, 25.4 after 200 us of idling, 32-37 here)
+        comm.barrier()  # ... and every rank's, before anything else is launched
         tb = time.perf_counter()
         summary = shard_boundary()
         spin()  # the event behind the boundary's last kernel has completed: its results are on the device
         boundary = time.perf_counter() - tb
+        counts1 = eng.launch_counts()  # (host-side counters; the boundary launches nothing they count)
+        if os.environ.get('CROWDNAV_AMD_BENCH_BOUNDARY_DEBUG'):  # further samples of the same call, back to back (stderr)
+            extra = []
+            for _ in range(4):
+                tb2 = time.perf_counter()
+                shard_boundary()
+                spin()
+                extra.append((time.perf_counter() - tb2) * 1e6)
+            tb2 = time.perf_counter()
+            spin()
+            empty = (time.perf_counter() - tb2) * 1e6
+            again = []
+            for _ in range(4):  # the same pattern once more: a 20-step launch, drained, then the boundary
+                run(args.steps)
+                drain()
+                tb2 = time.perf_counter()
+                shard_boundary()
+                spin()
+                again.append((time.perf_counter() - tb2) * 1e6)
+            print('boundary debug: first %.1f us, then %s, an empty event round trip %.1f us; behind further launches %s' %
+                  (boundary * 1e6, ' '.join('%.1f' % v for v in extra), empty, ' '.join('%.1f' % v for v in again)), file=sys.stderr)
     torch.cuda.synchronize()
     now_t, now_e = snapshot()
     own_episodes = int((now_e - snap_e).sum().item())

@@ -141,21 +141,38 @@ __global__ __launch_bounds__(kSummarySmallThreads) void records_summary_small_ke
     __shared__ double part[kSummaryFields][kSummarySmallThreads / kWave];
     double acc[kSummaryFields] = {};
     const int64_t items = n_envs * K;
-    for (int64_t it = threadIdx.x; it < items; it += kSummarySmallThreads) {
-        const int64_t b = it / K;
-        const int j = (int)(it - b * K);
-        double n, r0, r2, r3, r4;
-        src.get(b, j, n, r0, r2, r3, r4);
-        const bool held = (double)j < n && j < capacity;
-        const int outcome = (int)r0;
-        if (j == 0) acc[0] += n;
-        acc[1] += held ? 1.0 : 0.0;
-        acc[2] += (held && outcome == CN_REACH_GOAL) ? 1.0 : 0.0;
-        acc[3] += (held && outcome == CN_COLLISION) ? 1.0 : 0.0;
-        acc[4] += (held && outcome == CN_TIMEOUT) ? 1.0 : 0.0;
-        acc[5] += (held && outcome == CN_REACH_GOAL) ? r3 : 0.0;
-        acc[6] += held ? r2 : 0.0;
-        acc[7] += held ? r4 : 0.0;
+    // four items of a thread at a time, every load of the four requested before the first sum: behind a rollout launch the
+    // records sit in memory (written through other XCDs' L2s), and one round trip per item was the larger part of this
+    // kernel at the shard boundary.  The items are still added in increasing order: the same bits.
+    constexpr int kBatch = 4;
+    for (int64_t it0 = threadIdx.x; it0 < items; it0 += (int64_t)kBatch * kSummarySmallThreads) {
+        double n[kBatch], r0[kBatch], r2[kBatch], r3[kBatch], r4[kBatch];
+        int jj[kBatch];
+        bool have[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t it = it0 + (int64_t)u * kSummarySmallThreads;
+            have[u] = it < items;
+            const int64_t itc = have[u] ? it : it0;
+            const int64_t b = itc / K;
+            jj[u] = (int)(itc - b * K);
+            src.get(b, jj[u], n[u], r0[u], r2[u], r3[u], r4[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (!have[u]) continue;
+            const int j = jj[u];
+            const bool held = (double)j < n[u] && j < capacity;
+            const int outcome = (int)r0[u];
+            if (j == 0) acc[0] += n[u];
+            acc[1] += held ? 1.0 : 0.0;
+            acc[2] += (held && outcome == CN_REACH_GOAL) ? 1.0 : 0.0;
+            acc[3] += (held && outcome == CN_COLLISION) ? 1.0 : 0.0;
+            acc[4] += (held && outcome == CN_TIMEOUT) ? 1.0 : 0.0;
+            acc[5] += (held && outcome == CN_REACH_GOAL) ? r3[u] : 0.0;
+            acc[6] += held ? r2[u] : 0.0;
+            acc[7] += held ? r4[u] : 0.0;
+        }
     }
     // lanes of a wave by a fixed shuffle tree, the 16 waves in index order
 #pragma unroll
