@@ -96,9 +96,15 @@ def pmc_issue(rec, envs, steps_per_launch, launch_seconds):
            'valu_per_env_step': rec['sq_insts_valu'] / (envs * steps_per_launch),
            'counters_from': src, 'note': 'SQ_INSTS_VALU is NOT measured in this run: committed rocprofv3 PMC pass of the same '
                                          'launch shape (counters_from) over the launch time of this run'}
-    for k in ('f64_share', 'trans_share', 'lane_occupancy'):
+    for k in ('f64_share', 'trans_share', 'lane_occupancy', 'salu_per_valu', 'insts_per_env_step', 'issue_slot_share'):
         if k in rec:
             out[k] = rec[k]
+    if 'issue_slot_share' in rec:
+        out['issue_slot_note'] = ('round 6 (profiles/r06_valu_rate.txt, measured on this chip): a SIMD takes a plain f32 VALU '
+                                  'instruction every 2 cycles, but ONE wave issues an instruction of any class (VALU, SALU, LDS, '
+                                  's_waitcnt, s_nop ...) only every ~5 cycles; issue_slot_share = all instructions (SQ_INSTS) x 5 '
+                                  'cycles over the waves\' resident cycles — the share of its life a wave spends issuing; the '
+                                  'rest it waits for operands.  At 2-3 waves per SIMD that, not the VALU pipe, is what runs out')
     return out
 
 
@@ -354,6 +360,17 @@ def measure_h20(B, local_rank):
         torch.cuda.empty_cache()
         return res
 
+    def with_counters(res):
+        # the committed PMC record of this very shape (4096 x 20, 12 m circle, 999-step calls: scripts/gpu.sh pmc), if it is of
+        # these kernel sources: VALU issue, scalar overhead, all-instruction issue slots, HBM traffic (FETCH doubled: gfx950)
+        rec = pmc_profile(B, H, 999, 12.0)
+        issue = pmc_issue(rec, B, 999, res['seconds'] / len(res['launches']))
+        if issue is not None:
+            res['issue_roofline'] = issue
+            res['traffic'] = pmc_traffic_bytes(rec)
+            res['algorithmic_bytes'] = algorithmic_bytes_per_env_step(H) * B * 999
+        return res
+
     # the first 1021 'test' phase seeds, on which the reference's own rejection sampling terminates.  A PRIME modulus: episode c
     # of the shard is seeded 1000 + c % 1021 with c = env + 4096 x ordinal, so every env walks through all of them; with the
     # 1024 of rounds 2-3 (4096 = 4 x 1024) every env replayed ONE scenario for ever, and the envs that drew a hard one (up to
@@ -369,7 +386,7 @@ def measure_h20(B, local_rank):
         # ... and with the cache switched off: every scenario generated afresh (rounds 2-4's figure; generator-throughput-bound)
         'r4_async_fill_no_scenario_cache': one(4.0, ASYNC, seeds[0], seeds[1], [501], [999] * 6, scenario_cache=False),
         'r4_resets_excluded': one(4.0, 0, seeds[0], seeds[1], [1, 47], [47] * 30, refill_before_each=True),
-        'r12': one(12.0, 0, 2000, 2 ** 32 - 2000, [201, 999], [999, 999, 999]),
+        'r12': with_counters(one(12.0, 0, 2000, 2 ** 32 - 2000, [201, 999], [999, 999, 999])),
         'episode_seeds_r4': '%d + c %% %d' % seeds,
         'note': 'r4: 4 m circle (env.config), resets included, synchronous ring fill, three 999-step calls under one event pair; '
                 'r4_async_fill: the same with CN_FLAG_ASYNC_SCENARIO_FILL, six calls (envs whose next scenario is not ready pause: '

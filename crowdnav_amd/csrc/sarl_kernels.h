@@ -1561,9 +1561,15 @@ __device__ __forceinline__ void dense_narrow(const PackedLinear& P, const float*
     }
 }
 
+// -DCN_NARROW_INLINE (experiment builds): the four float64 helpers below inlined into sarl_narrow_kernel instead of called
+#ifdef CN_NARROW_INLINE
+#define CN_NARROW_CALL __forceinline__
+#else
+#define CN_NARROW_CALL __noinline__
+#endif
 // The decision behind the network (cn_sarl_sample_step), by the last workgroup of sarl_narrow_kernel: one wave per env.  Not
 // inlined: its float64 reward / rotation code (registers, the libm's private arrays) stays out of the network's allocation.
-__device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* goal,
+__device__ CN_NARROW_CALL void narrow_decide(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* goal,
                                            const double2* rv, int wave, int lane, const double* actions) {
     for (int b = wave; b < C.B; b += kNarrowWaves) {
         double bv = -__builtin_inf();
@@ -1586,13 +1592,13 @@ __device__ __noinline__ void narrow_decide(const SarlCfg& C, const SarlDecide& D
     }
 }
 // The joint state of env b for the replay memory (sarl_transform_row), on the idle wave of tile b
-__device__ __noinline__ void narrow_transform(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel,
+__device__ CN_NARROW_CALL void narrow_transform(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel,
                                               const double2* goal, const double2* rv, const double* theta, int b, int h, bool maps) {
     sarl_transform_row(C, D.in_dim, D.sort_humans, pos, vel, goal, rv, theta, D.state_out, D.env_stride, b, h, maps);
 }
 // ... and its occupancy maps (the CURRENT human states, multi_human_rl.py:96-105) shared by the 64 lanes of that wave: a human's
 // lane alone needs 30 us of float64 trigonometry for its map — longer than the whole network beside it
-__device__ __noinline__ void narrow_transform_maps(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel, int b,
+__device__ CN_NARROW_CALL void narrow_transform_maps(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* vel, int b,
                                                    int lane, char* scratch) {
     const size_t g0 = (size_t)b * (C.H + 1);
     occupancy_maps_cooperative(
@@ -1604,7 +1610,7 @@ __device__ __noinline__ void narrow_transform_maps(const SarlCfg& C, const SarlD
         [&](int, int i) { return D.state_out + (size_t)b * D.env_stride + (size_t)i * D.in_dim + 13; });
 }
 // onestep_lookahead's reward of one (env, action) group, for the tile that holds it (not inlined: float64, the libm's arrays)
-__device__ __noinline__ double narrow_reward(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
+__device__ CN_NARROW_CALL double narrow_reward(const SarlCfg& C, const double2* pos, const double2* vel, const double2* goal,
                                              const double2* rv, const double* gtime, const double* theta, const double* actions,
                                              int b, int a) {
     return sarl_reward_of(C, pos, vel, goal, rv, gtime, theta, actions, b, a);

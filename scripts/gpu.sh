@@ -83,6 +83,7 @@ trace)
 pmc)
   SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"
   SQ2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU"
+  SQ3="SQ_INSTS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_SENDMSG SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
   MF="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   declare -A CMD
   CMD[default]="$REPO/bench.py --no-cpu-baseline --no-secondary --no-r3-definition --no-fill-probe"
@@ -94,6 +95,7 @@ pmc)
     prof pmc_${shape}_write --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${shape}_write -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_sq1 --pmc $SQ1 --output-format csv -d $OUT/pmc_${shape}_sq1 -o p -- python ${CMD[$shape]}
     prof pmc_${shape}_sq2 --pmc $SQ2 --output-format csv -d $OUT/pmc_${shape}_sq2 -o p -- python ${CMD[$shape]}
+    prof pmc_${shape}_sq3 --pmc $SQ3 --output-format csv -d $OUT/pmc_${shape}_sq3 -o p -- python ${CMD[$shape]}
   done
   for v in sarl om_sarl; do
     a=""; [ $v = om_sarl ] && a="--om 1"
@@ -103,9 +105,9 @@ pmc)
   done
   rm -f $OUT/${TAG}_traffic.json
   P="python scripts/pmc_to_traffic.py $OUT/${TAG}_traffic.json"
-  $P 4096 5 1000 rollout_fused_kernel tail $OUT/pmc_default_fetch $OUT/pmc_default_write $OUT/pmc_default_sq1 $OUT/pmc_default_sq2 > /dev/null
-  $P 4096 5 20 rollout_fused_kernel 2 $OUT/pmc_driver_fetch $OUT/pmc_driver_write $OUT/pmc_driver_sq1 $OUT/pmc_driver_sq2 > /dev/null
-  CN_PMC_RADIUS=12 $P 4096 20 999 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 > /dev/null
+  $P 4096 5 1000 rollout_fused_kernel tail $OUT/pmc_default_fetch $OUT/pmc_default_write $OUT/pmc_default_sq1 $OUT/pmc_default_sq2 $OUT/pmc_default_sq3 > /dev/null
+  $P 4096 5 20 rollout_fused_kernel 2 $OUT/pmc_driver_fetch $OUT/pmc_driver_write $OUT/pmc_driver_sq1 $OUT/pmc_driver_sq2 $OUT/pmc_driver_sq3 > /dev/null
+  CN_PMC_RADIUS=12 $P 4096 20 999 rollout_kernel tail $OUT/pmc_h20_fetch $OUT/pmc_h20_write $OUT/pmc_h20_sq1 $OUT/pmc_h20_sq2 $OUT/pmc_h20_sq3 > /dev/null
   python scripts/prof_summary.py $OUT/pmc_sarl_mfma | tail -n 4; python scripts/prof_summary.py $OUT/pmc_om_sarl_mfma | tail -n 4
   head -c 1500 $OUT/${TAG}_traffic.json ;;
 h20ab)

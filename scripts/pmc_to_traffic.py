@@ -45,6 +45,15 @@ if 'sq_insts_valu' in rec:
     tr = rec.get('sq_insts_valu_trans_f32', 0.0) + rec.get('sq_insts_valu_trans_f64', 0.0)
     if tr:
         rec['trans_share'] = tr / rec['sq_insts_valu']
+if 'sq_insts_salu' in rec and rec.get('sq_insts_valu'):
+    rec['salu_per_valu'] = rec['sq_insts_salu'] / rec['sq_insts_valu']
+if 'sq_insts' in rec:
+    # round 6 (profiles/r06_valu_rate.txt): ONE wave issues an instruction of any class every ~5 cycles, whatever the SIMD's
+    # pipes could take — the per-wave issue slots are what a latency-bound kernel at 2-3 waves per SIMD runs out of first.
+    # issue_slot_share = instructions x 5 cycles over the waves' resident cycles (SQ_WAVE_CYCLES counts quad-cycles)
+    rec['insts_per_env_step'] = rec['sq_insts'] / n
+    if rec.get('sq_wave_cycles'):
+        rec['issue_slot_share'] = 5.0 * rec['sq_insts'] / (4.0 * rec['sq_wave_cycles'])
 if 'sq_thread_cycles_valu' in rec and 'sq_active_inst_valu' in rec and rec['sq_active_inst_valu']:
     # lanes active per VALU issue cycle / 64 (both counters in quad-cycles of the same unit)
     rec['lane_occupancy'] = rec['sq_thread_cycles_valu'] / (64.0 * rec['sq_active_inst_valu'])

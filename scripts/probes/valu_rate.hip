@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <vector>
 #define REP8(x) x x x x x x x x
-#define ITER 2000
+#define ITER 20000
 template <int KIND>
 __global__ __launch_bounds__(64) void k(float* out, unsigned long long* ticks) {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
