@@ -23,6 +23,7 @@ constexpr int kWave = 64;      // gfx950 wavefront width; one workgroup = one wa
 constexpr int kMaxNb = 10;     // RVO2 maxNeighbors supported (the reference hard-codes 10, orca.py:62)
 constexpr int kLineStride = kMaxNb + 1;  // float4 slots per agent in LDS (+1 pad: conflict-free b128 reads)
 constexpr float kRvoEps = 0.00001f;
+constexpr int kLazyCandFloat4 = (kWave / (kMaxNb - 1)) * ((kMaxNb - 1) + 4);  // lp_relaxed_lazy<10>'s scratch per wave: 7 x (9 + 4) float4
 
 // "Barrier" of a ONE-wave workgroup (the fused rollout, the 20-human shard's rollout, a scenario generator wave): a wave's
 // LDS instructions execute in order, so between one lane's write and another lane's read no s_barrier — and none of the
@@ -515,6 +516,62 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
     }
 }
 
+// lp_line_candidate<8> for the 9 lanes of an agent in the lazy fallback, PAIR-LANE form (round 6).  Lane l's candidate needs the
+// intersections of projected line l with lines 0 .. l-1: 36 (line, earlier line) pairs per agent, which the masked loop above
+// spreads as 8 per lane, half of them switched off.  Here every lane takes exactly 4 pairs: lanes 4..8 the first four entries
+// (j = 0..3) of their own row, lanes 0..3 their own (short) row and the REST of row 8 - l (j = 4 .. 7 - l), whose private
+// interval goes to the row's lane through one more LDS exchange.  Private intervals start from +-inf and are folded onto the speed
+// disc's in line order with RVO2's strict comparisons — own part first, then the helper's (the later j) — which selects exactly the
+// element the sequential loop keeps (as lp_planar_tri folds its three lanes); the emptiness test after the fold is equivalent to
+// RVO2's early exit (t_lo only grows, t_hi only shrinks).  Four IEEE divisions per lane and round instead of eight.
+//   lk: this lane's projected line (row l, also at prow[l]); bpart: 4 float4 of scratch of this lane's GROUP (rows 5..8);
+//   all 64 lanes call it (one wave_lds_sync inside); returns what lp_line_candidate<8>(lk, prow, l, radius, ox, oy, true) returns
+__device__ __forceinline__ float4 lp_line_candidate_pairs9(const float4 lk, const float4* prow, float4* bpart, int l, bool live,
+                                                           float radius, float ox, float oy) {
+    const float px = lk.x, py = lk.y, dx = lk.z, dy = lk.w;
+    const float dp = px * dx + py * dy;
+    const float disc = (dp * dp + radius * radius) - (px * px + py * py);
+    bool ok = !(disc < 0.0f);
+    const float root = sqrtf(disc);
+    float t_lo = -dp - root;
+    float t_hi = -dp + root;
+    const float inf = __builtin_inff();
+    const bool helper = l < 4;
+    const float4 hk = prow[helper ? 8 - l : l];  // the row this lane helps with (lanes 4..8: their own again, unused)
+    float hi_own = inf, lo_own = -inf, hi_help = inf, lo_help = -inf;
+    bool bad_own = false, bad_help = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bool own = !helper || s < l;        // slot s of this lane: pair (row l, j = s) or (row 8 - l, j = 4 + s - l)
+        const float4 lj = prow[own ? s : 4 + s - l];
+        const float kx = own ? px : hk.x, ky = own ? py : hk.y, kdx = own ? dx : hk.z, kdy = own ? dy : hk.w;
+        const float den = kdx * lj.w - kdy * lj.z;
+        const float num = lj.z * (ky - lj.y) - lj.w * (kx - lj.x);
+        const bool parallel = fabsf(den) <= kRvoEps;
+        const float t = num / den;
+        const bool bad = parallel && num < 0.0f;
+        const bool upper = !parallel && den >= 0.0f;
+        const bool lower = !parallel && !(den >= 0.0f);
+        hi_own = (own && upper && t < hi_own) ? t : hi_own;
+        lo_own = (own && lower && lo_own < t) ? t : lo_own;
+        bad_own = bad_own || (own && bad);
+        hi_help = (!own && upper && t < hi_help) ? t : hi_help;
+        lo_help = (!own && lower && lo_help < t) ? t : lo_help;
+        bad_help = bad_help || (!own && bad);
+    }
+    if (live && helper) bpart[3 - l] = make_float4(hi_help, lo_help, bad_help ? 1.0f : 0.0f, 0.0f);  // row 8 - l -> slot (8 - l) - 5
+    wave_lds_sync();
+    const bool has_help = l >= 5;
+    const float4 hb = bpart[has_help ? l - 5 : 0];
+    t_hi = (hi_own < t_hi) ? hi_own : t_hi;
+    t_lo = (t_lo < lo_own) ? lo_own : t_lo;
+    t_hi = (has_help && hb.x < t_hi) ? hb.x : t_hi;
+    t_lo = (has_help && t_lo < hb.y) ? hb.y : t_lo;
+    ok = ok && !bad_own && !(has_help && hb.z != 0.0f) && !(t_lo > t_hi);
+    const float t = (ox * dx + oy * dy > 0.0f) ? t_hi : t_lo;
+    return make_float4(px + t * dx, py + t * dy, ok ? 1.0f : 0.0f, 0.0f);
+}
+
 // ------------------------------------------------------------------ 3-D fallback, candidate form evaluated lazily
 // linearProgram3 (Appendix A.6) for 10 half-planes.  The all-pairs candidate form (lp3_scan at 5 half-planes) would compute the projections and 1-D
 // solutions of ALL 45 (i, j) pairs of an infeasible agent up front — at 5 half-planes (10 pairs) that is what makes the
@@ -527,8 +584,8 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
 // 0 .. l-1 (lp_line_candidate, direction objective), both through the agent's LDS rows; then every lane of the agent runs the
 // same short scan over the ≤ 9 candidates (no broadcast needed).  Same operations on the same operands as the sequential
 // program: bit-identical.  One round costs ~300 instructions whatever the number of violated projected lines.
-//   lines [nA][kLineStride]; proj [nA][kLineStride] scratch rows; cand: (kWave / MAXL) * (MAXL - 1) float4 of scratch per WAVE
-//   (one row per agent of the pass); res [nA] in: (result, int bits: first infeasible line), out: result; todo [n_todo]: the
+//   lines [nA][kLineStride]; proj [nA][kLineStride] scratch rows; cand: kLazyCandFloat4 float4 of scratch per WAVE
+//   (one row of MAXL - 1 per agent of the pass + 4 float4 per agent for the pair-lane candidates); res [nA] in: (result, int bits: first infeasible line), out: result; todo [n_todo]: the
 //   agents that need the fallback, compacted (kWave / MAXL of them share a pass)
 //   GROUP_ROWS: proj holds one row of MAXL - 1 projected half-planes per lane GROUP of the wave (kWave / (MAXL - 1) rows: the
 //   compact LDS layout of the 20-human shard's kernel) instead of one row of kLineStride per agent
@@ -554,6 +611,8 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
     const int gbase = g * W;
     const int waves = (threads + kWave - 1) / kWave;
     float4* const crow = cand + ((tid / kWave) * G + (g < G ? g : 0)) * W;
+    // (pair-lane candidates: the helpers' private intervals of rows 5..8, 4 float4 per group behind the waves' candidate rows)
+    float4* const bpart = cand + (size_t)waves * G * W + ((tid / kWave) * G + (g < G ? g : 0)) * 4;
 #ifdef CN_PHASE_TIMING
     unsigned long long pt_rounds = 0ull, pt_hand = 0ull;
     const unsigned long long pt_t0 = __builtin_readcyclecounter();
@@ -615,7 +674,13 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
             const float4 pr = (act && l < i) ? lp3_project(li, my) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) prow[l] = pr;
             // 1-D solution on projected line l against projected lines 0 .. l-1, optimising along the normal of half-plane i
+            // (CN_EXP_LAZY_MASKED: the masked 8-iteration form of rounds 3-5, for A/B builds)
+#ifdef CN_EXP_LAZY_MASKED
             const float4 cd = lp_line_candidate<MAXL - 2>(pr, prow, l, radius, -li.w, li.z, true);
+#else
+            static_assert(W == 9, "lp_line_candidate_pairs9 deals the 36 pairs of 9 projected lines");
+            const float4 cd = lp_line_candidate_pairs9(pr, prow, bpart, l, live, radius, -li.w, li.z);
+#endif
             if (live) crow[l] = cd;
             // linearProgram2 over the projected lines as a scan of the candidates (every lane of the agent, identically)
             float r2x = -li.w * radius, r2y = li.z * radius;

@@ -948,7 +948,7 @@ __device__ __forceinline__ void orca_phases(const Params& P, const Smem& s, cons
         } else {
             // (the lazy fallback's candidate rows — 7 agents x 9 float4 per wave — live in d2, free after the pair phases: enough
             // for one wave of a crowd of 12+ agents; otherwise the shuffle-round form)
-            if (P.threads == kWave && P.pairs * 4 >= (kWave / (MAXL - 1)) * (MAXL - 1) * 16)
+            if (P.threads == kWave && P.pairs * 4 >= kLazyCandFloat4 * 16)
                 lp_relaxed_lazy<10, COMPACT>(s.lines, s.proj, reinterpret_cast<float4*>(s.d2), s.count, s.sol, s.res, s.todo,
                                              s.todo[P.nA], P.threads);
             else

@@ -94,7 +94,10 @@ typedef struct cn_engine cn_engine;
 
 /* message of the last failed call on this thread ("" if none) */
 const char* cn_last_error(void);
-/* ABI version of this header (bumped on any signature change) */
+/* ABI version of this header (bumped on any change of a signature or of what a call does).  v10 (round 6): no new symbol —
+ * cn_sarl_sample_step skips the envs outside `alive` on its two-launch route, takes CN_MODEL_LSTM_RL there and accepts `info` in
+ * pinned host memory; cn_rollout / cn_rollout_step / the boundary calls refuse an io whose seed_base / seed_mod differ from
+ * cn_rollout_begin's. */
 int cn_abi_version(void);
 
 /* replaces gym.make('CrowdSim-v0') + CrowdSim.configure + set_robot (crowd_sim.py:13-82): allocates the

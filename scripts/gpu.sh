@@ -149,5 +149,11 @@ print('decisions', sum(r['decisions'] for r in rows), 'arg-max flips vs the refe
 for r in rows: print(' %-110s %4d decisions %3d flips  largest reference gap of a flip %.2e' % (r['fixture'][:110], r['decisions'], r['argmax_flips'], r['largest_reference_gap_of_a_flip']))
 PY
   ;;
+config5)
+  # BASELINE configs[4] on the reference's own schedule (train.config: 3000 IL episodes + 50 epochs, 10 000 single-episode RL
+  # sampling calls with 100 SGD batches each, evaluations): ~14 minutes, of which the in-scope sampling is ~35 s
+  ( timeout 1500 python examples/train_sarl.py --gpu --seed 0 --timing-json $OUT/config5.json > $OUT/config5.log 2>&1 < /dev/null ); echo "config5 rc=$?"
+  grep -E "TEST|VAL" $OUT/config5.log | tail -n 4
+  python -c "import json; d = json.load(open('$OUT/config5.json')); print({k: round(v, 2) if isinstance(v, float) else v for k, v in d['timing'].items()})" ;;
 *) echo "unknown stage $stage" ;;
 esac; done
