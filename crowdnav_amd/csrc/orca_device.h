@@ -516,6 +516,66 @@ __device__ __forceinline__ void lp_relaxed_coop(const float4* lines, const int* 
     }
 }
 
+// lp_line_candidate<4> for the 5 lanes (agent, half-plane k) of the fused kernel's candidate stage, PAIR-LANE form (round 6; see
+// lp_line_candidate_pairs9 below for the idea): the 10 (line, earlier line) pairs of an agent are dealt two per lane —
+//   lane 0: (4, 2) (4, 3)   lane 1: (1, 0) (3, 2)   lane 2: (2, 0) (2, 1)   lane 3: (3, 0) (3, 1)   lane 4: (4, 0) (4, 1)
+// — instead of four masked ones; rows 3 and 4 receive the later part of their interval from lanes 1 and 0 of their group through
+// wave shuffles and fold it behind their own part (line order, RVO2's strict comparisons).  lq: the agent's half-planes in LDS;
+// called by lanes (agent, k) that are contiguous in the wave, k fastest; returns what lp_line_candidate<4>(lq[k], lq, k, ...,
+// dir_opt = false) returns.
+__device__ __forceinline__ float4 lp_line_candidate_pairs5(const float4* lq, int k, int lane, float radius, float ox, float oy) {
+    const float inf = __builtin_inff();
+    const float4 lk = lq[k];
+    const int row0 = k == 0 ? 4 : k, j0 = k == 0 ? 2 : 0;
+    const int row1 = k == 0 ? 4 : (k == 1 ? 3 : k), j1 = k == 0 ? 3 : (k == 1 ? 2 : 1);
+    const bool own0 = k != 0, own1 = k >= 2;
+    const float4 K0 = lq[row0], J0 = lq[j0], K1 = lq[row1], J1 = lq[j1];
+    float hi_c[2], lo_c[2];
+    bool bad_c[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float4 K = s ? K1 : K0, J = s ? J1 : J0;
+        const float den = K.z * J.w - K.w * J.z;
+        const float num = J.z * (K.y - J.y) - J.w * (K.x - J.x);
+        const bool parallel = fabsf(den) <= kRvoEps;
+        const float t = num / den;
+        bad_c[s] = parallel && num < 0.0f;
+        hi_c[s] = (!parallel && den >= 0.0f) ? t : inf;
+        lo_c[s] = (!parallel && !(den >= 0.0f)) ? t : -inf;
+    }
+    // own part (slots in line order) and the part this lane computes for another row
+    float hi_o = own0 ? hi_c[0] : inf, lo_o = own0 ? lo_c[0] : -inf;
+    bool bad_o = own0 && bad_c[0];
+    float hi_h = own0 ? inf : hi_c[0], lo_h = own0 ? -inf : lo_c[0];
+    bool bad_h = !own0 && bad_c[0];
+    hi_o = (own1 && hi_c[1] < hi_o) ? hi_c[1] : hi_o;
+    lo_o = (own1 && lo_o < lo_c[1]) ? lo_c[1] : lo_o;
+    bad_o = bad_o || (own1 && bad_c[1]);
+    hi_h = (!own1 && hi_c[1] < hi_h) ? hi_c[1] : hi_h;
+    lo_h = (!own1 && lo_h < lo_c[1]) ? lo_c[1] : lo_h;
+    bad_h = bad_h || (!own1 && bad_c[1]);
+    // rows 3 and 4 fetch the later part of their interval: from lane 1 / lane 0 of the agent's group
+    const int src = lane - (k == 3 ? 2 : (k == 4 ? 4 : 0));
+    const float hi_r = __shfl(hi_h, src), lo_r = __shfl(lo_h, src);
+    const int bad_r = __shfl(bad_h ? 1 : 0, src);
+    const bool has = k >= 3;
+    const float px = lk.x, py = lk.y, dx = lk.z, dy = lk.w;
+    const float dp = px * dx + py * dy;
+    const float disc = (dp * dp + radius * radius) - (px * px + py * py);
+    bool ok = !(disc < 0.0f);
+    const float root = sqrtf(disc);
+    float t_lo = -dp - root;
+    float t_hi = -dp + root;
+    t_hi = (hi_o < t_hi) ? hi_o : t_hi;
+    t_lo = (t_lo < lo_o) ? lo_o : t_lo;
+    t_hi = (has && hi_r < t_hi) ? hi_r : t_hi;
+    t_lo = (has && t_lo < lo_r) ? lo_r : t_lo;
+    ok = ok && !bad_o && !(has && bad_r != 0) && !(t_lo > t_hi);
+    float t = dx * (ox - px) + dy * (oy - py);
+    t = (t < t_lo) ? t_lo : ((t > t_hi) ? t_hi : t);
+    return make_float4(px + t * dx, py + t * dy, ok ? 1.0f : 0.0f, 0.0f);
+}
+
 // lp_line_candidate<8> for the 9 lanes of an agent in the lazy fallback, PAIR-LANE form (round 6).  Lane l's candidate needs the
 // intersections of projected line l with lines 0 .. l-1: 36 (line, earlier line) pairs per agent, which the masked loop above
 // spreads as 8 per lane, half of them switched off.  Here every lane takes exactly 4 pairs: lanes 4..8 the first four entries

@@ -247,7 +247,11 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             const int q = L.lane / MAXL, k = L.lane - q * MAXL;
             const float4 so = s.sol[q];
             const float4* lq = s.lines + q * kLineStride;
+#ifdef CN_EXP_CAND_MASKED
             s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
+#else
+            s.cand2[q * kLineStride + k] = lp_line_candidate_pairs5(lq, k, L.lane, so.z, so.x, so.y);
+#endif
         }
         CN_FUSED_SYNC();
 
