@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
             const float odx = me.x - other.x, ody = me.y - other.y;
             const float mine = odx * odx + ody * ody;
             int rank = 0, within = 0;
+#ifdef CN_EXP_RANK_VCC
 #pragma unroll
             for (int k = 0; k < kFusedMaxNC; ++k) {
                 const float dx = me.x - ot[k].x, dy = me.y - ot[k].y;
@@ -227,6 +228,26 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 within += in;
                 rank += in & before;
             }
+#else
+            {
+                // squared distances are +0 .. +inf: their bit patterns order like the floats, so "v < mine, or v == mine and
+                // k < c" is bit 31 of v - (mine + [k < c]) and "v < range" is bit 31 of v - range as 32-bit integers: the sign
+                // bits are shifted into two words (v_alignbit_b32) and counted once — no compare through VCC / SGPR pairs, no
+                // scalar mask logic, none of the hazard s_nop between them (round 6; the shard's rank loop does the same)
+                const uint32_t mb = __float_as_uint(mine), rb = __float_as_uint(range_sq);
+                uint32_t before = 0u, inside = 0u;
+#pragma unroll
+                for (int k = 0; k < kFusedMaxNC; ++k) {
+                    const float dx = me.x - ot[k].x, dy = me.y - ot[k].y;
+                    const uint32_t vb = __float_as_uint(dx * dx + dy * dy);  // +inf for a pair that does not exist: never in range
+                    const uint32_t tie = (uint32_t)(k - c) >> 31;           // k < c
+                    before = __builtin_amdgcn_alignbit(before, vb - mb - tie, 31);
+                    inside = __builtin_amdgcn_alignbit(inside, vb - rb, 31);
+                }
+                within = __popc(inside);
+                rank = __popc(before & inside);
+            }
+#endif
             // (agent lanes are pair lanes too: their preferred velocity, same block)
             float4 sol4, start4;
             preferred_velocity(r, (L.a == 0) ? robot_max_speed : (float)r.vpref, solve, sol4, start4);
