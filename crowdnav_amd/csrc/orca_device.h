@@ -311,6 +311,12 @@ __device__ __forceinline__ void tri_gather(float v, int m, float& v0, float& v1,
     v1 = m == 0 ? b1 : (m == 1 ? v : a1);
     v2 = m == 0 ? b2 : (m == 1 ? b1 : v);
 }
+#ifdef CN_PHASE_TIMING
+// profiling builds: lp_relaxed_lazy [0] calls, [1] rounds that solved a projected program, [2] iterations that only handed
+// agents out, [3] agents taken, [4] clock ticks inside the function (wave 0 lane 0 of every workgroup); lp_planar_tri [5] calls,
+// [6] rounds, [7] agents still active summed over the rounds
+static __device__ unsigned long long cn_lazy_counts[8];
+#endif
 constexpr int kTriAgents = kWave / 3;  // 21 agents per wave pass
 __device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* count, const float4* sol, float4* res, int nA,
                                               int threads) {
@@ -320,6 +326,9 @@ __device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* co
     const int g = wl / 3, m = wl - 3 * g;
     const int waves = (threads + kWave - 1) / kWave;
     const float inf = __builtin_inff();
+#ifdef CN_PHASE_TIMING
+    if (tid == 0) atomicAdd(&cn_lazy_counts[5], 1ull);
+#endif
     for (int chunk = tid / kWave; chunk * kTriAgents < nA; chunk += waves) {
         const int a = chunk * kTriAgents + g;
         const bool live = g < kTriAgents && a < nA;
@@ -347,6 +356,15 @@ __device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* co
             const int i0 = __float_as_int(f0), i1 = __float_as_int(f1), i2 = __float_as_int(f2);
             const int first = i0 < i1 ? (i0 < i2 ? i0 : i2) : (i1 < i2 ? i1 : i2);
             const bool act = live && first != kNone;
+#ifdef CN_PHASE_TIMING
+            {
+                const unsigned long long am = __ballot(act && m == 0);
+                if (tid == 0) {
+                    atomicAdd(&cn_lazy_counts[6], 1ull);
+                    atomicAdd(&cn_lazy_counts[7], (unsigned long long)__popcll(am));
+                }
+            }
+#endif
             if (__ballot(act) == 0ull) break;
             const int i = act ? first : 0;
             const float4 li = lq[i];
@@ -649,11 +667,6 @@ __device__ __forceinline__ float4 lp_line_candidate_pairs9(const float4 lk, cons
 //   agents that need the fallback, compacted (kWave / MAXL of them share a pass)
 //   GROUP_ROWS: proj holds one row of MAXL - 1 projected half-planes per lane GROUP of the wave (kWave / (MAXL - 1) rows: the
 //   compact LDS layout of the 20-human shard's kernel) instead of one row of kLineStride per agent
-#ifdef CN_PHASE_TIMING
-// profiling builds: [0] calls, [1] rounds that solved a projected program, [2] iterations that only handed agents out,
-// [3] agents taken, [4] clock ticks inside the function (wave 0 lane 0 of every workgroup)
-static __device__ unsigned long long cn_lazy_counts[8];
-#endif
 template <int MAXL, bool GROUP_ROWS = false>
 __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* proj, float4* cand, const int* count,
                                                 const float4* sol, float4* res, const int* todo, int n_todo, int threads) {

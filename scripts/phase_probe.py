@@ -67,6 +67,9 @@ def main():
             print('  lazy fallback (10 half-planes): %d calls, %.2f agents, %.2f solve rounds + %.2f hand-out iterations per call, '
                   '%.0f ticks per call, %.0f per round' % (lz[0], lz[3] / lz[0], lz[1] / lz[0], lz[2] / lz[0], lz[4] / lz[0],
                                                            lz[4] / max(1, lz[1] + lz[2])))
+        if lz[5]:
+            print('  planar program on three lanes per agent: %d calls, %.2f rounds per call (the last one finds nobody active), '
+                  '%.2f agents active per round' % (lz[5], lz[6] / lz[5], lz[7] / max(1, lz[6])))
 
 
 if __name__ == '__main__':
