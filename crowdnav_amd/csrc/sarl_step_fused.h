@@ -20,30 +20,42 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);  // (requested in front of the decision's own loads: one round trip for both)
-    // ---- the decision: the env's lanes stride over its actions, the robot's lane folds them in lane order (the largest value,
-    // the lowest index on ties = the first strict maximum of the reference's loop; NaN and -inf never win)
+    // ---- the decision: arg-max of reward + gamma V over the env's actions (the largest value, the lowest index on ties = the
+    // first strict maximum of the reference's loop; NaN and -inf never win)
     bool samples = false;  // (robot lanes) this env's episode is still running
     {
-        double bv = -__builtin_inf();
-        int bi = -1;
-        if (L.valid) {
-            for (int a = L.a; a < C.n_actions; a += P.A) {
-                const double v = D.value[(size_t)L.env * C.n_actions + a];
-                if (v > bv) {
-                    bv = v;
-                    bi = a;
-                }
+        // Round 6: ALL 64 lanes of the (one-wave) workgroup fetch an env's K values — two independent loads per lane at 81
+        // actions — and a shuffle butterfly folds (value, index) pairs under the reference's order (the largest value, the lowest
+        // index on ties: a total order, so every lane ends with the same winner).  The env's own A lanes striding over its
+        // actions were ceil(K / A) = 14 DEPENDENT global loads of values other XCDs had just written: half of this kernel.
+        double best_v = -__builtin_inf();
+        int best_i = -1;
+        const int wl = (int)threadIdx.x & (kWave - 1);
+        const int my_el = L.valid ? L.ebase / P.A : -1;
+        for (int el = 0; el < P.E; ++el) {  // (uniform)
+            const int env = (int)blockIdx.x * P.E + el;
+            if (env >= C.B) break;
+            const double* val = D.value + (size_t)env * C.n_actions;
+            double bv = -__builtin_inf();
+            int bi = -1;
+            for (int a = wl; a < C.n_actions; a += 2 * kWave) {
+                const int a2 = a + kWave;
+                const double v1 = val[a];
+                const double v2 = a2 < C.n_actions ? val[a2] : -__builtin_inf();
+                if (v1 > bv) bv = v1, bi = a;
+                if (v2 > bv) bv = v2, bi = a2;
             }
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                const double ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi));
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+            if (el == my_el) best_v = bv, best_i = bi;
         }
-        double best_v = bv;
-        int best_i = bi;
-        for (int j = 1; j < P.A; ++j) {
-            const double ov = __shfl(bv, L.ebase + j);
-            const int oi = __shfl(bi, L.ebase + j);
-            const bool take = oi >= 0 && (best_i < 0 || ov > best_v || (ov == best_v && oi < best_i));
-            best_v = take ? ov : best_v;
-            best_i = take ? oi : best_i;
-        }
+        (void)best_v;
         if (L.valid && L.a == 0) {
             const int b = L.env;
             // sarl_pick_tail on the robot's own registers (the same doubles): a robot already at its goal stops (:22-23)
