@@ -675,29 +675,38 @@ __global__ void sarl_transform_kernel(SarlCfg C, int in_dim, int sort_humans, co
 // np.random.choice(K) of the legacy RandomState is randint(0, K): 32-bit draws masked to the next power of two minus
 // one, rejected while > K - 1.  An env already at its goal (best == -1) returned before the draw (:22-23).
 // lane = env.  explored (optional) receives 1 where the random action replaced the greedy one.
+// the draw itself: returns the random action's index, or -1 when the greedy action stands (or the env has no stream)
+__device__ __forceinline__ int sarl_explore_draw(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos, int* error, int b) {
+    if (mt_pos[b] < 0) {  // the env was not (re)started by cn_reset: there is no stream to continue
+        atomicOr(error, 2);
+        return -1;
+    }
+    Mt19937 rng{mt_key + b, B, mt_pos[b]};
+    const double probability = rng.random();
+    int picked = -1;
+    if (probability < epsilon) {
+        uint32_t bits = (uint32_t)(K - 1);
+        bits |= bits >> 1, bits |= bits >> 2, bits |= bits >> 4, bits |= bits >> 8, bits |= bits >> 16;
+        uint32_t k = 0;
+        if (K > 1) do k = rng.next32() & bits; while (k > (uint32_t)(K - 1));  // randint(0, 1) draws nothing
+        picked = (int)k;
+    }
+    mt_pos[b] = rng.pos;
+    return picked;
+}
 __device__ __forceinline__ void sarl_explore_env(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos,
                                                  const double* actions, bool masked_out, int32_t* best, double* action,
                                                  uint8_t* explored, int* error, int b) {
     if (explored) explored[b] = 0;
     if (masked_out) return;
     if (best[b] == -1) return;
-    if (mt_pos[b] < 0) {  // the env was not (re)started by cn_reset: there is no stream to continue
-        atomicOr(error, 2);
-        return;
-    }
-    Mt19937 rng{mt_key + b, B, mt_pos[b]};
-    const double probability = rng.random();
-    if (probability < epsilon) {
-        uint32_t bits = (uint32_t)(K - 1);
-        bits |= bits >> 1, bits |= bits >> 2, bits |= bits >> 4, bits |= bits >> 8, bits |= bits >> 16;
-        uint32_t k = 0;
-        if (K > 1) do k = rng.next32() & bits; while (k > (uint32_t)(K - 1));  // randint(0, 1) draws nothing
+    const int k = sarl_explore_draw(B, K, epsilon, mt_key, mt_pos, error, b);
+    if (k >= 0) {
         best[b] = (int32_t)k;
         action[2 * b] = actions[2 * k];
         action[2 * b + 1] = actions[2 * k + 1];
         if (explored) explored[b] = 1;
     }
-    mt_pos[b] = rng.pos;
 }
 __global__ void sarl_explore_kernel(int B, int K, double epsilon, uint32_t* mt_key, int* mt_pos, const double* actions,
                                     const uint8_t* mask, int32_t* best, double* action, uint8_t* explored,

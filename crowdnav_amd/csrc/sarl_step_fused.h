@@ -23,6 +23,7 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     // ---- the decision: arg-max of reward + gamma V over the env's actions (the largest value, the lowest index on ties = the
     // first strict maximum of the reference's loop; NaN and -inf never win)
     bool samples = false;  // (robot lanes) this env's episode is still running
+    double robot_action[2] = {0.0, 0.0};  // (robot lanes) the action of this step
     {
         // Round 6: ALL 64 lanes of the (one-wave) workgroup fetch an env's K values — two independent loads per lane at 81
         // actions — and a shuffle butterfly folds (value, index) pairs under the reference's order (the largest value, the lowest
@@ -61,13 +62,22 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
             // sarl_pick_tail on the robot's own registers (the same doubles): a robot already at its goal stops (:22-23)
             const bool arrived = norm2(r.py - r.gy, r.px - r.gx) < r.rad;
             const int arg = arrived ? -1 : best_i;
-            D.best[b] = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
-            D.action[2 * b] = arg >= 0 ? actions[2 * arg] : 0.0;
-            D.action[2 * b + 1] = arg >= 0 ? actions[2 * arg + 1] : 0.0;
+            int picked = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
             const bool keep = D.alive[b] && !(D.done && D.done[b]);  // (the previous call's flags: this call's are written below)
             D.alive[b] = keep ? 1 : 0;
             samples = keep;
-            sarl_explore_env(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, actions, !keep, D.best, D.action, nullptr, D.error, b);
+            // sarl_explore_env on registers: best / action are stored once and the transition below takes the action from the
+            // registers (written to memory and read back by the same lane they were two global round trips of this kernel)
+            int act_i = arg;
+            if (keep && picked != -1) {
+                const int k = sarl_explore_draw(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, D.error, b);
+                if (k >= 0) picked = k, act_i = k;
+            }
+            robot_action[0] = act_i >= 0 ? actions[2 * act_i] : 0.0;
+            robot_action[1] = act_i >= 0 ? actions[2 * act_i + 1] : 0.0;
+            D.best[b] = picked;
+            D.action[2 * b] = robot_action[0];
+            D.action[2 * b + 1] = robot_action[1];
         }
     }
     // every env of this (one-wave) workgroup has finished its episode: nothing to step — a caller that streams calls past an
@@ -82,7 +92,8 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     double nvx, nvy;
     // (the humans' velocities for this transition are the ones the previous call — or cn_launch_orca — left for the decision's
     // lookahead: one ORCA pass per step, the one behind the transition, instead of two)
-    step_core<MAXL, UNI, false>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta, nullptr, next_orca_vel);
+    step_core<MAXL, UNI, false>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta, nullptr, next_orca_vel,
+                                robot_action);
     if (L.valid) {
         if (L.a == 0) {
             io.reward[L.env] = res.reward;

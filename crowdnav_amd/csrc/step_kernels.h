@@ -984,7 +984,8 @@ template <int MAXL, bool UNI, bool KD, bool COMPACT = false>
 __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const Lane& L, AgentRegs& r,
                                           double& gtime, float robot_max_speed, const double* ext_action,
                                           int update, StepResult& res, double& new_vx, double& new_vy,
-                                          double* theta_io = nullptr, PhaseClock* clk = nullptr, const float* known_vel = nullptr) {
+                                          double* theta_io = nullptr, PhaseClock* clk = nullptr, const float* known_vel = nullptr,
+                                          const double* robot_action_regs = nullptr /* the robot lane's action, in registers */) {
     (void)clk;
     float ovx = 0.0f, ovy = 0.0f;
     if (known_vel != nullptr) {
@@ -1007,8 +1008,8 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
     double rot_v = 0.0, rot_r = 0.0, theta0 = 0.0;
     if (L.valid && L.a == 0) {
         if (!P.robot_orca) {
-            new_vx = ext_action[2 * (size_t)L.env];
-            new_vy = ext_action[2 * (size_t)L.env + 1];
+            new_vx = robot_action_regs ? robot_action_regs[0] : ext_action[2 * (size_t)L.env];
+            new_vy = robot_action_regs ? robot_action_regs[1] : ext_action[2 * (size_t)L.env + 1];
         }
         if (unicycle) {
             rot_v = new_vx, rot_r = new_vy, theta0 = *theta_io;
