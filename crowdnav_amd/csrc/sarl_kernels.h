@@ -1934,12 +1934,15 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     lds_barrier();
     CN_SARL_TICK(3);
     if (n->with_global) {
-        for (int i = tid; i < n->ks_b * 64; i += kNarrowThreads) {
-            const int r = i & 15, first = (i & ~15) + (r / H) * H;
-            const int cnt = r < rows ? hc[r / H] : H;
+        // the mean of h2 over a group's humans, once per (feature word, group) and copied to the group's H rows (it was summed
+        // again for every row: five times the loads and divisions; rows beyond the tile's stay zero from the start)
+        for (int i = tid; i < n->ks_b * 4 * GT; i += kNarrowThreads) {
+            const int g = i % GT, first = (i / GT) * 16 + g * H;
+            const int cnt = hc[g];
             float sum = 0.0f;
             for (int h = 0; h < H; ++h) sum += h < cnt ? bufB[first + h] : 0.0f;  // (as sarl_mlp_pipe_kernel masks a `mixed` episode)
-            gbuf[i] = r < rows ? sum / (float)cnt : 0.0f;  // (row 15 of 3 x 5: reads past the tile's rows, result unused)
+            const float mean = sum / (float)cnt;
+            for (int h = 0; h < H; ++h) gbuf[first + h] = mean;
         }
     }
     dense_narrow(layer_of(*n, kL_mlp2_0), bufB, bufA, true, nullptr, wave, lane, cur);
@@ -1961,6 +1964,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     cur = narrow_fetch(layer_of(*n, kL_mlp3_2), wave, lane);
     lds_barrier();
     CN_SARL_TICK(7);
+    float* const wrow = reinterpret_cast<float*>(hl + kSarlGroups) + wave * 16;  // this wave's copy of the attention weights
     {   // attention.4 (one output) as dense_vec1<H> slices it: kSarlThreads / (16 H) k slices per row, summed in slice order
         const PackedLinear P = layer_of(*n, kL_att_4);
         const int slices = kSarlThreads / (H * 16);
@@ -1976,7 +1980,10 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         }
         lds_barrier();
         CN_SARL_TICK(8);
-        if (wave == 0) {  // lane = row: its score, then the softmax without max subtraction over the group's humans (sarl.py:52-53)
+        // EVERY wave: lane = row (four copies per wave): its score, then the softmax without max subtraction over the group's
+        // humans (sarl.py:52-53) — into the wave's OWN copy of the weights, so that the joint state below follows without another
+        // workgroup barrier (round 6: wave 0 alone computed them and seven waves waited at a barrier of their own)
+        {
             const int r = lane & 15;
             float v = as_global(P.bias)[0];
             for (int s = 0; s < slices; ++s) v += vbuf[s * 16 + r];
@@ -1985,20 +1992,19 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
             const float e = present ? expf(v) * (v != 0.0f ? 1.0f : 0.0f) : 0.0f;
             float total = 0.0f;
             for (int h = 0; h < H; ++h) total += __shfl(e, (g0 + h) & 15);  // (row 15 of 3 x 5 wraps: unused)
-            if (lane < 16) sbuf[lane] = e / total;
+            if (lane < 16) wrow[lane] = e / total;
         }
     }
-    lds_barrier();
+    wave_lds_sync();
     CN_SARL_TICK(9);
     // the joint state, row = group: self features, weighted feature sum (sarl.py:60); everything else of jbuf is zero
     if (tid < kSarlGroups * 6 && sg < GT) jbuf[(sf >> 2) * 64 + (sf & 3) * 16 + sg] = self_val;
     const int nf = n->nf;
-    for (int i = tid; i < kSarlGroups * nf; i += kNarrowThreads) {
-        const int g = i & 15, c = i >> 4;
-        if (g >= GT) continue;
+    for (int i = tid; i < GT * nf; i += kNarrowThreads) {  // (group, feature): the groups the tile really holds
+        const int g = i % GT, c = i / GT;
         const int src = (c >> 2) * 64 + (c & 3) * 16 + g * H;
         float sum = 0.0f;
-        for (int h = 0; h < H; ++h) sum += sbuf[g * H + h] * bufC[src + h];
+        for (int h = 0; h < H; ++h) sum += wrow[g * H + h] * bufC[src + h];
         const int f = 6 + c;
         jbuf[(f >> 2) * 64 + (f & 3) * 16 + g] = sum;
     }
@@ -2036,9 +2042,9 @@ __host__ inline size_t sarl_narrow_lds_bytes(const SarlNet& net, bool lstm = fal
     if (lstm) {  // sarl_narrow_kernel<true>'s carve: xs, gx, gates, hbuf, cbuf, jbuf, kbuf, sbuf, vbuf, hc
         const size_t H = (size_t)net.H, ks_g = (size_t)net.L[kL_mlp1_0].ctiles * 4, hid = (size_t)net.L[kL_mlp1_2].K;
         return sizeof(float) * (64 * (H * net.ks_x + H * ks_g + ks_g + (size_t)sarl_ks((int)hid) + 2 * (size_t)net.ks_a + 1) +
-                                hid * kSarlGroups + kSarlThreads + 2 * kSarlGroups);
+                                hid * kSarlGroups + kSarlThreads + (2 + kNarrowWaves) * kSarlGroups);
     }
-    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads + 2 * kSarlGroups);
+    return sizeof(float) * (64 * (size_t)(net.ks_x + 4 * net.ks_a + 2 * net.ks_b + net.ks_c + 1) + kSarlThreads + (2 + kNarrowWaves) * kSarlGroups);
 }
 
 }  // namespace cn
