@@ -20,6 +20,37 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     const Lane L = lane_of(P);
     AgentRegs r = {};
     if (L.valid) load_agent(S, L.gi, r);  // (requested in front of the decision's own loads: one round trip for both)
+    // Everything else this kernel will need from global memory that does not depend on the decision is requested HERE, beside
+    // the values: one wave runs the whole kernel, and every load it meets on the way is a round trip nothing hides (round 6) —
+    //   the robot lane's flags and its position in the env's numpy stream, then the five generator words one
+    //   np.random.random() call reads (key[i], key[i + 1], key[i + 2], key[i + 397], key[i + 398], indices mod 624);
+    //   every human lane's ORCA velocity for this transition; the captured robot-simulator view of the ORCA pass behind it.
+    const bool robot_lane = L.valid && L.a == 0;
+    uint8_t pre_alive = 0, pre_done = 0;
+    int pre_pos = -1;
+    uint32_t pw[5] = {0u, 0u, 0u, 0u, 0u};
+    int pi0 = 0, pi1 = 0, pi2 = 0;
+    if (robot_lane) {
+        pre_alive = D.alive[L.env];
+        pre_done = D.done ? D.done[L.env] : 0;
+        pre_pos = D.mt_pos[L.env];
+        if (pre_pos >= 0) {
+            const uint32_t* key = D.mt_key + L.env;
+            const auto wrap = [](int i) { return i >= 624 ? i - 624 : i; };
+            pi0 = pre_pos, pi1 = wrap(pre_pos + 1), pi2 = wrap(pre_pos + 2);
+            pw[0] = key[(size_t)pi0 * C.B], pw[1] = key[(size_t)pi1 * C.B], pw[2] = key[(size_t)pi2 * C.B];
+            pw[3] = key[(size_t)wrap(pre_pos + 397) * C.B], pw[4] = key[(size_t)wrap(pre_pos + 398) * C.B];
+        }
+    }
+    float lane_vel[2] = {0.0f, 0.0f};
+    if (next_orca_vel != nullptr && L.valid && L.a > 0) lane_vel[0] = next_orca_vel[2 * L.gi], lane_vel[1] = next_orca_vel[2 * L.gi + 1];
+    uint8_t view_have = 0;
+    float view_rr = 0.0f, view_ms = 0.0f;
+    if (next_orca_vel != nullptr && L.valid) {
+        view_have = S.rsim_valid[L.env];
+        view_rr = S.rsim_radius[L.gi];
+        if (L.a == 0) view_ms = S.rsim_max_speed[L.env];
+    }
     // ---- the decision: arg-max of reward + gamma V over the env's actions (the largest value, the lowest index on ties = the
     // first strict maximum of the reference's loop; NaN and -inf never win)
     bool samples = false;  // (robot lanes) this env's episode is still running
@@ -63,15 +94,46 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
             const bool arrived = norm2(r.py - r.gy, r.px - r.gx) < r.rad;
             const int arg = arrived ? -1 : best_i;
             int picked = (arrived || arg < 0) ? (arrived ? -1 : -2) : arg;  // -2: every value was NaN / -inf (:57-58)
-            const bool keep = D.alive[b] && !(D.done && D.done[b]);  // (the previous call's flags: this call's are written below)
+            const bool keep = pre_alive && !pre_done;  // (the previous call's flags: this call's are written below)
             D.alive[b] = keep ? 1 : 0;
             samples = keep;
             // sarl_explore_env on registers: best / action are stored once and the transition below takes the action from the
-            // registers (written to memory and read back by the same lane they were two global round trips of this kernel)
+            // registers (written to memory and read back by the same lane they were two global round trips of this kernel);
+            // np.random.random() from the five prefetched words (Mt19937::next32 twice: words i and i + 1 are regenerated and
+            // stored, the position moves on by two), np.random.choice through the memory-backed generator behind it
             int act_i = arg;
             if (keep && picked != -1) {
-                const int k = sarl_explore_draw(C.B, C.n_actions, D.epsilon, D.mt_key, D.mt_pos, D.error, b);
-                if (k >= 0) picked = k, act_i = k;
+                if (pre_pos < 0) {  // the env was not (re)started by cn_reset: there is no stream to continue
+                    atomicOr(D.error, 2);
+                } else {
+                    uint32_t* key = D.mt_key + b;
+                    const auto twist = [](uint32_t hi, uint32_t lo, uint32_t m) {
+                        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+                        return m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    };
+                    const auto temper = [](uint32_t v) {
+                        v ^= (v >> 11);
+                        v ^= (v << 7) & 0x9d2c5680u;
+                        v ^= (v << 15) & 0xefc60000u;
+                        v ^= (v >> 18);
+                        return v;
+                    };
+                    const uint32_t v0 = twist(pw[0], pw[1], pw[3]), v1 = twist(pw[1], pw[2], pw[4]);
+                    key[(size_t)pi0 * C.B] = v0;
+                    key[(size_t)pi1 * C.B] = v1;
+                    const double probability = ((double)(temper(v0) >> 5) * 67108864.0 + (double)(temper(v1) >> 6)) / 9007199254740992.0;
+                    int pos = pi2;
+                    if (probability < D.epsilon) {
+                        Mt19937 rng{key, C.B, pos};
+                        uint32_t bits = (uint32_t)(C.n_actions - 1);
+                        bits |= bits >> 1, bits |= bits >> 2, bits |= bits >> 4, bits |= bits >> 8, bits |= bits >> 16;
+                        uint32_t k = 0;
+                        if (C.n_actions > 1) do k = rng.next32() & bits; while (k > (uint32_t)(C.n_actions - 1));  // randint(0, 1) draws nothing
+                        picked = (int)k, act_i = (int)k;
+                        pos = rng.pos;
+                    }
+                    D.mt_pos[b] = pos;
+                }
             }
             robot_action[0] = act_i >= 0 ? actions[2 * act_i] : 0.0;
             robot_action[1] = act_i >= 0 ? actions[2 * act_i + 1] : 0.0;
@@ -93,7 +155,7 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     // (the humans' velocities for this transition are the ones the previous call — or cn_launch_orca — left for the decision's
     // lookahead: one ORCA pass per step, the one behind the transition, instead of two)
     step_core<MAXL, UNI, false>(P, s, L, r, gtime, robot_max_speed, io.action, io.update, res, nvx, nvy, &theta, nullptr, next_orca_vel,
-                                robot_action);
+                                robot_action, lane_vel);
     if (L.valid) {
         if (L.a == 0) {
             io.reward[L.env] = res.reward;
@@ -113,7 +175,7 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
     // ---- orca_kernel's body on the new state (r holds what was just stored)
     if (next_orca_vel == nullptr) return;
     block_sync(P);
-    load_robot_view(P, S, s, L, r, robot_max_speed);
+    load_robot_view(P, S, s, L, r, robot_max_speed, true, view_have != 0, view_rr, view_ms);
     float vx, vy;
     orca_phases<MAXL, false>(P, s, L, r, robot_max_speed, L.valid, vx, vy);
     if (L.valid) {

@@ -317,14 +317,16 @@ __device__ __forceinline__ void build_pairs(const Params& P, const Smem& s, bool
 
 // The robot's ORCA policy object outlives episodes and keeps the radii / max speed it saw when its rvo2
 // simulator was first built (orca.py:95-104).  Load or capture them.
+//   preloaded: the caller requested rsim_valid / rsim_radius / rsim_max_speed earlier (sarl_decide_step_kernel, at its top)
 __device__ __forceinline__ void load_robot_view(const Params& P, const StateView& S, const Smem& s,
-                                                const Lane& L, const AgentRegs& r, float& robot_max_speed) {
+                                                const Lane& L, const AgentRegs& r, float& robot_max_speed, bool preloaded = false,
+                                                bool pre_have = false, float pre_radius = 0.0f, float pre_max_speed = 0.0f) {
     robot_max_speed = 0.0f;
     if (!L.valid) return;
-    const bool have = S.rsim_valid[L.env] != 0;
+    const bool have = preloaded ? pre_have : S.rsim_valid[L.env] != 0;
     float rr;
     if (have) {
-        rr = S.rsim_radius[L.gi];
+        rr = preloaded ? pre_radius : S.rsim_radius[L.gi];
     } else {
         rr = (float)(r.rad + 0.01 + P.robot_safety);
         S.rsim_radius[L.gi] = rr;
@@ -332,7 +334,7 @@ __device__ __forceinline__ void load_robot_view(const Params& P, const StateView
     s.rview[L.lane] = rr;
     if (L.a == 0) {
         if (have) {
-            robot_max_speed = S.rsim_max_speed[L.env];
+            robot_max_speed = preloaded ? pre_max_speed : S.rsim_max_speed[L.env];
         } else {
             robot_max_speed = (float)r.vpref;
             S.rsim_max_speed[L.env] = robot_max_speed;
@@ -985,7 +987,8 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
                                           double& gtime, float robot_max_speed, const double* ext_action,
                                           int update, StepResult& res, double& new_vx, double& new_vy,
                                           double* theta_io = nullptr, PhaseClock* clk = nullptr, const float* known_vel = nullptr,
-                                          const double* robot_action_regs = nullptr /* the robot lane's action, in registers */) {
+                                          const double* robot_action_regs = nullptr /* the robot lane's action, in registers */,
+                                          const float* lane_vel_regs = nullptr /* this lane's entry of known_vel, requested earlier */) {
     (void)clk;
     float ovx = 0.0f, ovy = 0.0f;
     if (known_vel != nullptr) {
@@ -996,7 +999,10 @@ __device__ __forceinline__ void step_core(const Params& P, const Smem& s, const 
             s.posd[L.lane] = make_double2(r.px, r.py);
             if (!COMPACT) s.rad[L.lane] = r.rad;
         }
-        if (L.valid && L.a > 0) ovx = known_vel[2 * L.gi], ovy = known_vel[2 * L.gi + 1];
+        if (L.valid && L.a > 0) {
+            ovx = lane_vel_regs ? lane_vel_regs[0] : known_vel[2 * L.gi];
+            ovy = lane_vel_regs ? lane_vel_regs[1] : known_vel[2 * L.gi + 1];
+        }
     } else {
         orca_phases<MAXL, KD, COMPACT>(P, s, L, r, robot_max_speed, L.valid && (L.a > 0 || P.robot_orca), ovx, ovy, clk);
     }
