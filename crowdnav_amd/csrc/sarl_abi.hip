@@ -42,6 +42,8 @@ struct cn_sarl {
     bool fused_step;      // cn_sarl_sample_step on the narrow route: decision + transition + next ORCA as one kernel (CROWDNAV_AMD_SARL_FUSED_STEP)
     int* narrow_counter;  // cn_sarl_sample_step: workgroups of sarl_narrow_kernel that have written their V
     double* narrow_value; // ... and reward + gamma V per (env, action), each written by the tile that computed V
+    cn::PackJobs pack_jobs = {};  // cn_sarl_set_weights: the layers to repack, run as one launch (sarl_pack_flush)
+    int pack_blocks = 0;
 };
 
 void cn_sarl_release(cn_engine* e) {
@@ -51,12 +53,28 @@ void cn_sarl_release(cn_engine* e) {
 
 namespace {
 
+// the packing jobs of one cn_sarl_set_weights call are collected and run as ONE launch (sarl_pack_flush)
+int sarl_pack_flush(cn_engine* e) {
+    cn::PackJobs& jobs = e->sarl->pack_jobs;
+    if (jobs.n > 0) {
+        hipLaunchKernelGGL(cn::sarl_pack_many_kernel, dim3((unsigned)e->sarl->pack_blocks), dim3(256), 0, e->stream, jobs);
+        jobs.n = 0, e->sarl->pack_blocks = 0;
+        CN_HIP(hipGetLastError());
+    }
+    return CN_OK;
+}
 int sarl_pack(cn_engine* e, cn::PackedLinear& L, const float* W, const float* bias, int N, int K, int k_off, int k_cnt) {
     (void)k_cnt;
+    cn::PackJobs& jobs = e->sarl->pack_jobs;
+    if (jobs.n == cn::kPackJobs) {
+        const int rc = sarl_pack_flush(e);
+        if (rc) return rc;
+    }
     const int total = L.ctiles * L.kpad * 64;
-    hipLaunchKernelGGL(cn::sarl_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, W, bias, N, K, k_off,
-                       L.K, L.kpad, L.ctiles, const_cast<float*>(L.w), const_cast<float*>(L.bias));
-    CN_HIP(hipGetLastError());
+    cn::PackJob& J = jobs.job[jobs.n++];
+    J.W = W, J.bias = bias, J.wp = const_cast<float*>(L.w), J.bp = const_cast<float*>(L.bias);
+    J.N = N, J.K = K, J.k_offset = k_off, J.k_count = L.K, J.kpad = L.kpad, J.ctiles = L.ctiles, J.first_block = e->sarl->pack_blocks;
+    e->sarl->pack_blocks += (total + 255) / 256;
     return CN_OK;
 }
 
@@ -339,6 +357,7 @@ int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array) {
     if (!params_host_array) return fail(CN_ERR_INVALID, "cn_sarl_set_weights: NULL");
     const bool cadrl = s->cfg.model == CN_MODEL_CADRL, lstm = s->cfg.model == CN_MODEL_LSTM_RL;
     const bool pairwise = lstm && s->cfg.interaction_dims[0] > 0;
+    s->pack_jobs.n = 0, s->pack_blocks = 0;  // (a call that failed half-way leaves nothing queued)
     for (int i = 0; i < (cadrl ? 8 : (lstm ? (pairwise ? 20 : 12) : 22)); ++i)
         if (!params_host_array[i]) return fail(CN_ERR_INVALID, "cn_sarl_set_weights: parameter %d is NULL", i);
     const float* const* p = params_host_array;  // W0, b0, W1, b1, ... in state_dict order
@@ -392,6 +411,7 @@ int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array) {
             hipLaunchKernelGGL(cn::sarl_reg_pack_kernel, dim3((th + 255) / 256), dim3(256), 0, e->stream, headp, s->reg_stream2);
             CN_HIP(hipGetLastError());
         }
+        if ((rc = sarl_pack_flush(e))) return rc;
         s->weights_set = true;
         return CN_OK;
     }
@@ -458,6 +478,7 @@ int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array) {
             hipLaunchKernelGGL(cn::sarl_om_weights_kernel, dim3((160 * 49 + 255) / 256), dim3(256), 0, e->stream, p[0], p[1], s->om_w);
         CN_HIP(hipGetLastError());
     }
+    if ((rc = sarl_pack_flush(e))) return rc;
     s->weights_set = true;
     return CN_OK;
 }

@@ -165,6 +165,37 @@ __global__ void sarl_pack_kernel(const float* W, const float* bias, int N, int K
     if (idx < ctiles * 16) bp[idx] = (bias && idx < N) ? bias[idx] : 0.0f;
 }
 
+// All layers of a network in ONE launch (cn_sarl_set_weights runs once per sampled episode in the RL phase: eleven launches of
+// the kernel above were ~50 us of host and device time each time).  Block b belongs to the job whose block range holds it.
+constexpr int kPackJobs = 16;
+struct PackJob {
+    const float* W;
+    const float* bias;
+    float* wp;
+    float* bp;
+    int N, K, k_offset, k_count, kpad, ctiles, first_block;
+};
+struct PackJobs {
+    PackJob job[kPackJobs];
+    int n;
+};
+__global__ void sarl_pack_many_kernel(PackJobs jobs) {
+    int j = 0;
+    for (int i = 1; i < jobs.n; ++i) j = (int)blockIdx.x >= jobs.job[i].first_block ? i : j;
+    const PackJob J = jobs.job[j];
+    const int idx = ((int)blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;
+    const int total = J.ctiles * J.kpad * 64;
+    if (idx < total) {
+        const int lane = idx & 63;
+        const int frag = idx >> 6;
+        const int ct = frag / J.kpad, ks = frag - ct * J.kpad;
+        const int n = ct * 16 + (lane & 15);
+        const int k = ks * 4 + (lane >> 4);
+        J.wp[idx] = (n < J.N && k < J.k_count) ? J.W[(size_t)n * J.K + J.k_offset + k] : 0.0f;
+    }
+    if (idx < J.ctiles * 16) J.bp[idx] = (J.bias && idx < J.N) ? J.bias[idx] : 0.0f;
+}
+
 // ------------------------------------------------------------------------------------ lookahead / reward
 // Occupancy map human i sees among the H humans of one env (multi_human_rl.py:109-163; the robot is not in it).
 // state_of(j, px, py, vx, vy) yields human j's state; m receives cells * channels float32 values.

@@ -338,15 +338,22 @@ def _sarl_set_weights(self, state_dict):
     order = {'cadrl': CADRL_PARAM_ORDER, 'lstm_rl': LSTM_PARAM_ORDER}.get(self.sarl['model'], SARL_PARAM_ORDER)
     if self.sarl.get('pairwise'):  # lstm_rl.ValueNetwork2: mlp1 first, as in its state_dict
         order = LSTM_PAIRWISE_MLP1_ORDER + order
-    tensors = [state_dict[k].detach().to(device=self.device, dtype=torch.float32).contiguous() for k in order]
+    # parameters that live on the engine's device as dense float32 are read in place (the RL phase uploads weights once per
+    # sampled episode: 22 conversions and stream records were ~0.1 ms of host time each time); anything else goes through a copy
+    tensors, temporaries = [], []
+    for k in order:
+        t = state_dict[k]
+        if not (t.device == self.device and t.dtype == torch.float32 and t.is_contiguous()):
+            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            temporaries.append(t)
+        tensors.append(t)
     ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     check(self._lib.cn_sarl_set_weights(self._h, ptrs))
-    # the tensors above (temporaries when the model lives elsewhere or in another dtype) must outlive the repack kernels: kept
-    # until the next call — by then those kernels are long behind on the engine's stream; no synchronize per call (the RL phase
-    # uploads weights once per sampled episode).  The caching allocator is told that the engine's stream reads them: were
-    # the caller inside another torch.cuda.stream(...) context, a freed temporary could otherwise be handed out again on THAT
-    # stream while the repack kernels, on the stream captured at construction / use_current_stream(), still read it.
-    for t in tensors:
+    # the tensors above must outlive the repack kernel: kept until the next call — by then it is long behind on the engine's
+    # stream; no synchronize per call.  The caching allocator is told that the engine's stream reads the TEMPORARIES: were the
+    # caller inside another torch.cuda.stream(...) context, a freed temporary could otherwise be handed out again on THAT stream
+    # while the repack kernel, on the stream captured at construction / use_current_stream(), still reads it.
+    for t in temporaries:
         t.record_stream(self._stream)
     self._sarl_weights_keepalive = tensors
 
