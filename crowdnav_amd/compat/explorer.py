@@ -87,7 +87,7 @@ class Explorer(object):
                 return model(x).reshape(-1)
         g['x'][:n].copy_(x)
         g['graph'].replay()
-        return g['y'][:n].reshape(-1).clone()
+        return g['y'][:n].reshape(-1)  # (a view of the graph's output: consumed before the next replay — update_memory converts it at once)
 
     # ------------------------------------------------------------------ explorer.py:21-90
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
@@ -479,13 +479,13 @@ class Explorer(object):
                 if single:
                     states, nxt = states[:, 0], nxt[:, 0]
                 with torch.no_grad():
-                    v_next = self._td_values(nxt).to(eng.device).double()
-                values = r + gamma_bar * v_next
-                if len(ends) == 1:
-                    values[-1] = r[-1]
-                else:
-                    e_idx = torch.as_tensor(ends, device=eng.device)
-                    values[e_idx] = r[e_idx]
+                    v_next = self._td_values(nxt).to(eng.device)
+                    values = torch.add(r, v_next.double(), alpha=gamma_bar)   # float64, as the reference's Python floats
+                    if len(ends) == 1:
+                        values[-1:].copy_(r[-1:])
+                    else:
+                        e_idx = torch.as_tensor(ends, device=eng.device)
+                        values[e_idx] = r[e_idx]
                 self._push_all(states, values.float())
             lap('read-back + TD targets + push')
             for b in range(B):

@@ -67,9 +67,12 @@ class DeviceReplayMemory(Dataset):
             states, values, n_eff = states[-self.capacity:], values[-self.capacity:], self.capacity
         else:
             n_eff = n
-        idx = (self.position + torch.arange(n_eff, device=self.device)) % self.capacity
-        self.states.index_copy_(0, idx, states)
-        self.values.index_copy_(0, idx, values)
+        head = min(n_eff, self.capacity - self.position)  # rows up to the end of the ring: two plain copies, not five kernels
+        self.states[self.position:self.position + head].copy_(states[:head])
+        self.values[self.position:self.position + head].copy_(values[:head])
+        if head < n_eff:  # the rest wraps round
+            self.states[:n_eff - head].copy_(states[head:])
+            self.values[:n_eff - head].copy_(values[head:])
         self.position = (self.position + n_eff) % self.capacity
         self.size = min(self.capacity, self.size + n)
 
