@@ -786,9 +786,9 @@ extern "C" int cn_debug_phase_cycles(unsigned long long* out16, int reset) {
 #endif
 #ifdef CN_PHASE_TIMING
 extern "C" int cn_debug_lazy_counts(unsigned long long* out8, int reset) {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(cn::cn_lazy_counts), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(cn::cn_lazy_counts), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long zero[8] = {};
+        unsigned long long zero[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(cn::cn_lazy_counts), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;

@@ -315,7 +315,7 @@ __device__ __forceinline__ void tri_gather(float v, int m, float& v0, float& v1,
 // profiling builds: lp_relaxed_lazy [0] calls, [1] rounds that solved a projected program, [2] iterations that only handed
 // agents out, [3] agents taken, [4] clock ticks inside the function (wave 0 lane 0 of every workgroup); lp_planar_tri [5] calls,
 // [6] rounds, [7] agents still active summed over the rounds
-static __device__ unsigned long long cn_lazy_counts[8];
+static __device__ unsigned long long cn_lazy_counts[16];  // [8..11]: planar rounds whose largest violated index is <= 3 / <= 6 / <= 9, sum of it
 #endif
 constexpr int kTriAgents = kWave / 3;  // 21 agents per wave pass
 __device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* count, const float4* sol, float4* res, int nA,
@@ -367,6 +367,17 @@ __device__ __forceinline__ void lp_planar_tri(const float4* lines, const int* co
 #endif
             if (__ballot(act) == 0ull) break;
             const int i = act ? first : 0;
+#ifdef CN_PHASE_TIMING
+            {
+                int mx = i;  // largest violated index among the wave's active agents
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+                if (tid == 0) {
+                    atomicAdd(&cn_lazy_counts[mx <= 3 ? 8 : (mx <= 6 ? 9 : 10)], 1ull);
+                    atomicAdd(&cn_lazy_counts[11], (unsigned long long)mx);
+                }
+            }
+#endif
             const float4 li = lq[i];
             const float px = li.x, py = li.y, dx = li.z, dy = li.w;
             // half-plane i inside the speed disc

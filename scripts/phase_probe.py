@@ -61,7 +61,7 @@ def main():
     print('  agents in the 3-D fallback per wave-step: %.3f (of %d agent lanes)' % (out[9] / out[15] / 500, eng.A * max(1, a.envs // int(waves))))
     print('  transitions', int(bufs['transitions'].cpu()[0]))
     if lazy is not None:
-        lz = (C.c_ulonglong * 8)()
+        lz = (C.c_ulonglong * 16)()
         lazy(lz, 0)
         if lz[0]:
             print('  lazy fallback (10 half-planes): %d calls, %.2f agents, %.2f solve rounds + %.2f hand-out iterations per call, '
@@ -70,6 +70,9 @@ def main():
         if lz[5]:
             print('  planar program on three lanes per agent: %d calls, %.2f rounds per call (the last one finds nobody active), '
                   '%.2f agents active per round' % (lz[5], lz[6] / lz[5], lz[7] / max(1, lz[6])))
+            work = max(1, lz[8] + lz[9] + lz[10])
+            print('    largest violated half-plane index of a working round: <= 3 in %.1f %%, <= 6 in %.1f %%, 7..9 in %.1f %% of them (mean %.2f)'
+                  % (100.0 * lz[8] / work, 100.0 * lz[9] / work, 100.0 * lz[10] / work, lz[11] / work))
 
 
 if __name__ == '__main__':
