@@ -83,7 +83,12 @@ static __device__ unsigned long long cn_wave_trace[8192 * 6];
 #endif
 
 template <bool HEADLINE>
-__global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
+#ifdef CN_EXP_NO_FUSED_BOUND
+__global__ __launch_bounds__(kWave) void rollout_fused_kernel(
+#else
+__global__ __launch_bounds__(kWave, (HEADLINE ? 3 : 1)) void rollout_fused_kernel(
+#endif
+Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                               RolloutView R, int n_steps, const double* ext_action) {
 #ifdef CN_WAVE_TRACE
     const unsigned long long wt_entry = __builtin_amdgcn_s_memrealtime();
@@ -317,11 +322,19 @@ __global__ __launch_bounds__(kWave) void rollout_fused_kernel(Params P_in, const
                 const float4* la = s.lines + a * kLineStride;
                 const float4 li = la[i], lj = la[m - base];
                 const float radius = s.sol[a].z;
-                if (item) s.proj[a * kLineStride + m] = lp3_project(li, lj);
+                const float4 pr = lp3_project(li, lj);
+                if (item) s.proj[a * kLineStride + m] = pr;
                 CN_FUSED_SYNC();
                 if (item) {
+                    // (CN_EXP_CAND3_PAIRS: one (projected line, earlier line) pair per item lane + two shuffle rounds instead of three
+                    // masked pairs — lp3_candidate_pairs10; measured neutral in round 6: 1 229.6 / 1 238.8 vs 1 229.9 / 1 233.7 M)
+#ifdef CN_EXP_CAND3_PAIRS
+                    static_assert(MAXL == 5, "lp3_candidate_pairs10 deals the ten pairs of four programs");
+                    s.cand3[a * kLineStride + m] = lp3_candidate_pairs10(s.proj + a * kLineStride, pr, m, L.lane, radius, -li.w, li.z);
+#else
                     const float4* pa = s.proj + a * kLineStride + base;
                     s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, radius, -li.w, li.z, true);
+#endif
                 }
                 CN_FUSED_SYNC();
                 // the four planar programs of an infeasible agent side by side: the item lane of slot (i, 0) runs program i
