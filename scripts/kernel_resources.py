@@ -13,7 +13,7 @@ SRC = os.path.join(ROOT, 'crowdnav_amd', 'csrc', 'crowdnav_amd.hip')
 
 
 def report(extra=()):
-    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize',
            '-fno-fast-math', '-Rpass-analysis=kernel-resource-usage', '-c', SRC, '-o', '/dev/null'] + list(extra)
     err = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, cwd=os.path.dirname(SRC)).stderr
     rows, cur = [], None
