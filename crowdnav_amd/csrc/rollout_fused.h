@@ -83,10 +83,13 @@ static __device__ unsigned long long cn_wave_trace[8192 * 6];
 #endif
 
 template <bool HEADLINE>
-#ifdef CN_EXP_NO_FUSED_BOUND
+#ifndef CN_EXP_FUSED_WAVES
+#define CN_EXP_FUSED_WAVES 3  // waves per SIMD the headline instantiation is compiled for (experiment builds: 0 = no hint, 2, 4)
+#endif
+#if CN_EXP_FUSED_WAVES == 0
 __global__ __launch_bounds__(kWave) void rollout_fused_kernel(
 #else
-__global__ __launch_bounds__(kWave, (HEADLINE ? 3 : 1)) void rollout_fused_kernel(
+__global__ __launch_bounds__(kWave, (HEADLINE ? CN_EXP_FUSED_WAVES : 1)) void rollout_fused_kernel(
 #endif
 Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                               RolloutView R, int n_steps, const double* ext_action) {
