@@ -605,62 +605,6 @@ __device__ __forceinline__ float4 lp_line_candidate_pairs5(const float4* lq, int
     return make_float4(px + t * dx, py + t * dy, ok ? 1.0f : 0.0f, 0.0f);
 }
 
-// lp_line_candidate<3> for the ten item lanes (program i, projected line kk) of an infeasible agent in the fused kernel's one-pass
-// fallback, PAIR-LANE form: the ten (projected line, earlier projected line) pairs of the four programs — 0 + 1 + 3 + 6 — one per
-// lane instead of three masked ones.  Slot of (i, kk) in the agent's proj row: i (i - 1) / 2 + kk.  Lane m computes
-//   m: 0 (4;3,1)  1 (4;3,2)  2 (2;1,0)  3 (4;2,1)  4 (3;1,0)  5 (3;2,0)  6 (3;2,1)  7 (4;1,0)  8 (4;2,0)  9 (4;3,0)      (i; kk, j)
-// i.e. the first pair of its own row where that has one, and lanes 0, 1, 3, 6 (rows without pairs) the later pairs of rows 9, 9, 8
-// and 5, which fetch them by shuffle in line order (row 5 from lane +1, row 8 from lane -5, row 9 from lanes -9 then -8) and fold
-// them behind their own with RVO2's strict comparisons.  proj: the agent's ten projected lines; own: this lane's (slot m);
-// returns what lp_line_candidate<3>(proj[base + kk], proj + base, kk, radius, ox, oy, true) returns.  Item lanes of an agent are
-// ten consecutive lanes of the wave, all active.
-__device__ __forceinline__ float4 lp3_candidate_pairs10(const float4* proj, const float4 own, int m, int lane, float radius, float ox,
-                                                        float oy) {
-    const float inf = __builtin_inff();
-    const int ks = (int)((0x9875548299ull >> (4 * m)) & 15ull), js = (int)((0x6664337187ull >> (4 * m)) & 15ull);
-    const bool mine = ((0x3b4u >> m) & 1u) != 0u;  // the pair belongs to this lane's own row (m = 2, 4, 5, 7, 8, 9)
-    const float4 K = proj[ks], J = proj[js];
-    const float den = K.z * J.w - K.w * J.z;
-    const float num = J.z * (K.y - J.y) - J.w * (K.x - J.x);
-    const bool parallel = fabsf(den) <= kRvoEps;
-    const float t = num / den;
-    const bool bad_c = parallel && num < 0.0f;
-    const float hi_c = (!parallel && den >= 0.0f) ? t : inf;
-    const float lo_c = (!parallel && !(den >= 0.0f)) ? t : -inf;
-    float hi = mine ? hi_c : inf, lo = mine ? lo_c : -inf;
-    bool bad = mine && bad_c;
-    {   // the second pair of rows 5, 8, 9
-        const int src = lane + (m == 5 ? 1 : (m == 8 ? -5 : (m == 9 ? -9 : 0)));
-        const float h1 = __shfl(hi_c, src), l1 = __shfl(lo_c, src);
-        const int b1 = __shfl(bad_c ? 1 : 0, src);
-        const bool has = m == 5 || m == 8 || m == 9;
-        hi = (has && h1 < hi) ? h1 : hi;
-        lo = (has && lo < l1) ? l1 : lo;
-        bad = bad || (has && b1 != 0);
-    }
-    {   // the third pair of row 9
-        const int src = lane + (m == 9 ? -8 : 0);
-        const float h2 = __shfl(hi_c, src), l2 = __shfl(lo_c, src);
-        const int b2 = __shfl(bad_c ? 1 : 0, src);
-        const bool has = m == 9;
-        hi = (has && h2 < hi) ? h2 : hi;
-        lo = (has && lo < l2) ? l2 : lo;
-        bad = bad || (has && b2 != 0);
-    }
-    const float px = own.x, py = own.y, dx = own.z, dy = own.w;
-    const float dp = px * dx + py * dy;
-    const float disc = (dp * dp + radius * radius) - (px * px + py * py);
-    bool ok = !(disc < 0.0f);
-    const float root = sqrtf(disc);
-    float t_lo = -dp - root;
-    float t_hi = -dp + root;
-    t_hi = (hi < t_hi) ? hi : t_hi;
-    t_lo = (t_lo < lo) ? lo : t_lo;
-    ok = ok && !bad && !(t_lo > t_hi);
-    const float tt = (ox * dx + oy * dy > 0.0f) ? t_hi : t_lo;
-    return make_float4(px + tt * dx, py + tt * dy, ok ? 1.0f : 0.0f, 0.0f);
-}
-
 // lp_line_candidate<8> for the 9 lanes of an agent in the lazy fallback, PAIR-LANE form (round 6).  Lane l's candidate needs the
 // intersections of projected line l with lines 0 .. l-1: 36 (line, earlier line) pairs per agent, which the masked loop above
 // spreads as 8 per lane, half of them switched off.  Here every lane takes exactly 4 pairs: lanes 4..8 the first four entries
@@ -814,13 +758,8 @@ __device__ __forceinline__ void lp_relaxed_lazy(const float4* lines, float4* pro
             const float4 pr = (act && l < i) ? lp3_project(li, my) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) prow[l] = pr;
             // 1-D solution on projected line l against projected lines 0 .. l-1, optimising along the normal of half-plane i
-            // (CN_EXP_LAZY_MASKED: the masked 8-iteration form of rounds 3-5, for A/B builds)
-#ifdef CN_EXP_LAZY_MASKED
-            const float4 cd = lp_line_candidate<MAXL - 2>(pr, prow, l, radius, -li.w, li.z, true);
-#else
             static_assert(W == 9, "lp_line_candidate_pairs9 deals the 36 pairs of 9 projected lines");
             const float4 cd = lp_line_candidate_pairs9(pr, prow, bpart, l, live, radius, -li.w, li.z);
-#endif
             if (live) crow[l] = cd;
             // linearProgram2 over the projected lines as a scan of the candidates (every lane of the agent, identically)
             float r2x = -li.w * radius, r2y = li.z * radius;

@@ -83,15 +83,9 @@ static __device__ unsigned long long cn_wave_trace[8192 * 6];
 #endif
 
 template <bool HEADLINE>
-#ifndef CN_EXP_FUSED_WAVES
-#define CN_EXP_FUSED_WAVES 3  // waves per SIMD the headline instantiation is compiled for (experiment builds: 0 = no hint, 2, 4)
-#endif
-#if CN_EXP_FUSED_WAVES == 0
-__global__ __launch_bounds__(kWave) void rollout_fused_kernel(
-#else
-__global__ __launch_bounds__(kWave, (HEADLINE ? CN_EXP_FUSED_WAVES : 1)) void rollout_fused_kernel(
-#endif
-Params P_in, const StateView* Sd, const int* ring_filled_in,
+// (the headline instantiation is compiled for three waves per SIMD: with the hint hipcc settles on 163-167 VGPRs and a schedule
+// worth 1.2 % at 4096 envs, 2.6 % in the 20-step shape; compiled for two it loses 3 %, for four — 128 VGPRs, 42 spilled — 11 %)
+__global__ __launch_bounds__(kWave, (HEADLINE ? 3 : 1)) void rollout_fused_kernel(Params P_in, const StateView* Sd, const int* ring_filled_in,
                                                               RolloutView R, int n_steps, const double* ext_action) {
 #ifdef CN_WAVE_TRACE
     const unsigned long long wt_entry = __builtin_amdgcn_s_memrealtime();
@@ -226,17 +220,6 @@ Params P_in, const StateView* Sd, const int* ring_filled_in,
             const float odx = me.x - other.x, ody = me.y - other.y;
             const float mine = odx * odx + ody * ody;
             int rank = 0, within = 0;
-#ifdef CN_EXP_RANK_VCC
-#pragma unroll
-            for (int k = 0; k < kFusedMaxNC; ++k) {
-                const float dx = me.x - ot[k].x, dy = me.y - ot[k].y;
-                const float v = dx * dx + dy * dy;  // +inf for a pair that does not exist: never in range
-                const int in = v < range_sq ? 1 : 0;
-                const int before = (v < mine ? 1 : 0) | ((v == mine ? 1 : 0) & (k < c ? 1 : 0));
-                within += in;
-                rank += in & before;
-            }
-#else
             {
                 // squared distances are +0 .. +inf: their bit patterns order like the floats, so "v < mine, or v == mine and
                 // k < c" is bit 31 of v - (mine + [k < c]) and "v < range" is bit 31 of v - range as 32-bit integers: the sign
@@ -255,7 +238,6 @@ Params P_in, const StateView* Sd, const int* ring_filled_in,
                 within = __popc(inside);
                 rank = __popc(before & inside);
             }
-#endif
             // (agent lanes are pair lanes too: their preferred velocity, same block)
             float4 sol4, start4;
             preferred_velocity(r, (L.a == 0) ? robot_max_speed : (float)r.vpref, solve, sol4, start4);
@@ -276,11 +258,7 @@ Params P_in, const StateView* Sd, const int* ring_filled_in,
             const int q = L.lane / MAXL, k = L.lane - q * MAXL;
             const float4 so = s.sol[q];
             const float4* lq = s.lines + q * kLineStride;
-#ifdef CN_EXP_CAND_MASKED
-            s.cand2[q * kLineStride + k] = lp_line_candidate<MAXL - 1>(lq[k], lq, k, so.z, so.x, so.y, false);
-#else
             s.cand2[q * kLineStride + k] = lp_line_candidate_pairs5(lq, k, L.lane, so.z, so.x, so.y);
-#endif
         }
         CN_FUSED_SYNC();
 
@@ -329,15 +307,10 @@ Params P_in, const StateView* Sd, const int* ring_filled_in,
                 if (item) s.proj[a * kLineStride + m] = pr;
                 CN_FUSED_SYNC();
                 if (item) {
-                    // (CN_EXP_CAND3_PAIRS: one (projected line, earlier line) pair per item lane + two shuffle rounds instead of three
-                    // masked pairs — lp3_candidate_pairs10; measured neutral in round 6: 1 229.6 / 1 238.8 vs 1 229.9 / 1 233.7 M)
-#ifdef CN_EXP_CAND3_PAIRS
-                    static_assert(MAXL == 5, "lp3_candidate_pairs10 deals the ten pairs of four programs");
-                    s.cand3[a * kLineStride + m] = lp3_candidate_pairs10(s.proj + a * kLineStride, pr, m, L.lane, radius, -li.w, li.z);
-#else
+                    // (one (projected line, earlier line) pair per item lane + two shuffle rounds instead of these three masked pairs
+                    // was built and measured neutral in round 6: 1 229.6 / 1 238.8 vs 1 229.9 / 1 233.7 M — profiles/HISTORY.md)
                     const float4* pa = s.proj + a * kLineStride + base;
                     s.cand3[a * kLineStride + m] = lp_line_candidate<MAXL - 2>(pa[m - base], pa, m - base, radius, -li.w, li.z, true);
-#endif
                 }
                 CN_FUSED_SYNC();
                 // the four planar programs of an infeasible agent side by side: the item lane of slot (i, 0) runs program i

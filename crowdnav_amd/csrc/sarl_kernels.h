@@ -1601,12 +1601,9 @@ __device__ __forceinline__ void dense_narrow(const PackedLinear& P, const float*
     }
 }
 
-// -DCN_NARROW_INLINE (experiment builds): the four float64 helpers below inlined into sarl_narrow_kernel instead of called
-#ifdef CN_NARROW_INLINE
-#define CN_NARROW_CALL __forceinline__
-#else
+// (the four float64 helpers below are CALLED: inlined — tried in round 6 — the 2 KB / lane of scratch stays, it is the libm's
+// private arrays, and 105 VGPRs of the network spill; the reservation costs nothing at launch: profiles/r06_scratch_launch.txt)
 #define CN_NARROW_CALL __noinline__
-#endif
 // The decision behind the network (cn_sarl_sample_step), by the last workgroup of sarl_narrow_kernel: one wave per env.  Not
 // inlined: its float64 reward / rotation code (registers, the libm's private arrays) stays out of the network's allocation.
 __device__ CN_NARROW_CALL void narrow_decide(const SarlCfg& C, const SarlDecide& D, const double2* pos, const double2* goal,
