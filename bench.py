@@ -419,6 +419,11 @@ def measure_policy_decision(B, H, policy, local_rank, iters=20):
         net = cadrl.ValueNetwork(13, [150, 100, 100, 1])
         eng.sarl_configure(actions=acts, model='cadrl', mlp3_dims=(150, 100, 100, 1))
         flop = 2 * 81 * H * (13 * 150 + head) * B
+    elif policy == 'lstm_rl+pairwise':  # [lstm_rl] with_interaction_module = true: lstm_rl.ValueNetwork2 (lstm_rl.py:36-66)
+        net = lstm_rl.ValueNetwork2(13, 6, [150, 100, 100, 50], [150, 100, 100, 1], 50)
+        eng.sarl_configure(actions=acts, model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1),
+                           interaction_dims=(150, 100, 100, 50))
+        flop = 2 * 81 * (H * (13 * 150 + 150 * 100 + 100 * 100 + 100 * 50 + 200 * (50 + 50)) + 56 * 150 + head) * B
     else:
         net = lstm_rl.ValueNetwork1(13, 6, [150, 100, 100, 1], 50)
         eng.sarl_configure(actions=acts, model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
@@ -443,7 +448,7 @@ def measure_policy_decision(B, H, policy, local_rank, iters=20):
             'roofline': {'bound': 'mfma', 'achieved': flop / select_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s',
                          'frac': flop / select_s / 1e12 / 157.3, 'select_ms': select_s * 1e3,
                          'kernel': 'cn_sarl_select; the value network is cn::%s' %
-                                   ('cadrl_reg_kernel' if policy == 'cadrl' else 'lstm_reg_kernel'),
+                                   {'cadrl': 'cadrl_reg_kernel', 'lstm_rl+pairwise': 'lstm2_reg_kernel'}.get(policy, 'lstm_reg_kernel'),
                          'note': 'algorithmic flops (unpadded layer widths) over the HIP-event time of cn_sarl_select'}}
 
 
@@ -524,9 +529,10 @@ def secondary(B, local_rank):
         out[key]['workload'] = r['config']['workload']
         out[key]['decisions_per_s'] = B / (r['roofline']['select_ms'] / 1e3)
         out[key]['cpu_baseline'] = reference_decision_baseline('sarl+om' if om else 'sarl')
-    for policy in ('cadrl', 'lstm_rl'):
-        out[policy] = measure_policy_decision(B, 5, policy, local_rank)
-        out[policy]['cpu_baseline'] = reference_decision_baseline(policy)
+    for policy in ('cadrl', 'lstm_rl', 'lstm_rl+pairwise'):
+        key = policy.replace('+', '_')
+        out[key] = measure_policy_decision(B, 5, policy, local_rank)
+        out[key]['cpu_baseline'] = reference_decision_baseline(policy)
     out['h20'] = measure_h20(B, local_rank)
     out['h20']['cpu_baseline'] = cpu_baseline_h20()
     out['sample_step'] = measure_sample_step(local_rank)
@@ -895,7 +901,7 @@ def reference_python_baseline():
 def reference_decision_baseline(policy):
     """cpu_baseline of one secondary decision row: the reference's own robot.act -> predict (multi_human_rl.py:11-63 /
     cadrl.py:130-176 / lstm_rl.py:69-104: 81 onestep_lookahead + 81 batch-1 forwards) on one core of this host.
-    policy: 'sarl' | 'sarl+om' | 'cadrl' | 'lstm_rl'."""
+    policy: 'sarl' | 'sarl+om' | 'cadrl' | 'lstm_rl' | 'lstm_rl+pairwise'."""
     run = reference_python_run()
     r = run['raw']
     for rec in ((r or {}).get('decision') or {}).get('runs', []):

@@ -226,10 +226,13 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
             net.ks_c = ks_of(max2(id[1], id[3]));
         }
         // more than kSarlMaxHumans humans: lstm_mlp_anyh_kernel stages one human's row tile per LSTM step (nothing sized by H)
-        const size_t row_tiles = H > cn::kSarlMaxHumans ? 1 : (size_t)H;
-        s->chunked = H > cn::kSarlMaxHumans;
-        s->lds_bytes = sizeof(float) * (64 * (row_tiles * (net.ks_x + net.ks_b + net.ks_c) + ks_g + ks_h + 2 * net.ks_a + net.ks_s) +
-                                        (size_t)hid * cn::kSarlGroups);
+        // (... and whenever H row tiles do not fit: ValueNetwork2's ping-pong buffers from 6 humans on)
+        const auto lds_for = [&](size_t row_tiles) {
+            return sizeof(float) * (64 * (row_tiles * (net.ks_x + net.ks_b + net.ks_c) + ks_g + ks_h + 2 * net.ks_a + net.ks_s) +
+                                    (size_t)hid * cn::kSarlGroups);
+        };
+        s->chunked = H > cn::kSarlMaxHumans || lds_for((size_t)H) > 160 * 1024;
+        s->lds_bytes = lds_for(s->chunked ? 1 : (size_t)H);
     } else if (cadrl) {  // ping-pong between A (first / third hidden layer) and B (X staging, second hidden layer)
         net.ks_a = ks_of(max2(j0, j2));
         net.ks_b = max2(ks_of(j1), net.ks_x);
@@ -286,6 +289,15 @@ int cn_sarl_configure(cn_engine* e, const cn_sarl_config* c, const double* actio
         s->reg_mlp = true, s->reg_xks = cn::kRegLstmGates + (in_dim == 13 ? 4 : 16);
         if ((rc = dev_alloc(e, &s->reg_stream, (size_t)cn::reg_total_quads(s->reg_xks) * 256)) ||
             (rc = dev_alloc(e, &s->reg_stream2, (size_t)cn::reg_total_quads(cn::kRegLstmHead) * 256)))
+            return rc;
+    }
+    if (pairwise && hid == cn::kRegLstmHid && (in_dim == 13 || in_dim == 61) && c->interaction_dims[0] == 150 &&
+        c->interaction_dims[1] == 100 && c->interaction_dims[2] == 100 && c->interaction_dims[3] == cn::kRegLstmHid && j0 == 150 &&
+        j1 == 100 && j2 == 100 && (reg_mode == 2 || (reg_mode == 1 && tiles_here > 512))) {  // lstm2_reg_kernel (ValueNetwork2)
+        s->reg_mlp = true, s->reg_xks = cn::kRegLstmMlp1 + (in_dim == 13 ? 4 : 16);
+        if ((rc = dev_alloc(e, &s->reg_stream, (size_t)cn::reg_total_quads(s->reg_xks) * 256)) ||
+            (rc = dev_alloc(e, &s->reg_stream2, (size_t)cn::reg_total_quads(cn::kRegLstmHead) * 256)) ||
+            (rc = dev_alloc(e, &s->reg_stream3, (size_t)cn::reg_total_quads(cn::kRegLstmGates + cn::kRegLstmKs) * 256)))
             return rc;
     }
     if (s->lds_bytes > 160 * 1024)
@@ -401,13 +413,29 @@ int cn_sarl_set_weights(cn_engine* e, const float* const* params_host_array) {
             cn::RegPackLayer& G = gates.L[0];
             G.W = p[8], G.W2 = p[9], G.b = p[10], G.b2 = p[11];
             G.N = 4 * cn::kRegLstmHid, G.K = net.in_dim, G.ldw = net.in_dim, G.k_split = s->reg_xks - cn::kRegLstmGates;
+            float* gate_stream = s->reg_stream;
+            if (pairwise) {  // lstm2_reg_kernel: mlp1's stream (the parameters in front of the head's), gates on mlp1's 50 outputs
+                cn::RegPackPlan m1{};
+                m1.xks = s->reg_xks;
+                const int dims[5] = {net.in_dim, s->cfg.interaction_dims[0], s->cfg.interaction_dims[1], s->cfg.interaction_dims[2],
+                                     s->cfg.interaction_dims[3]};
+                for (int l = 0; l < 4; ++l) {
+                    cn::RegPackLayer& R = m1.L[l];
+                    R.W = p[2 * l - 8], R.b = p[2 * l - 7], R.N = dims[l + 1], R.K = dims[l], R.ldw = dims[l], R.k_off = 0, R.replicate = 0;
+                }
+                const int tm = cn::reg_total_quads(s->reg_xks) * 256;
+                hipLaunchKernelGGL(cn::sarl_reg_pack_kernel, dim3((tm + 255) / 256), dim3(256), 0, e->stream, m1, s->reg_stream);
+                gates.xks = cn::kRegLstmGates + cn::kRegLstmKs;
+                G.K = cn::kRegLstmHid, G.ldw = cn::kRegLstmHid, G.k_split = cn::kRegLstmKs;
+                gate_stream = s->reg_stream3;
+            }
             for (int l = 0; l < 4; ++l) {
                 const cn::PackedLinear& L = net.L[head[l]];
                 cn::RegPackLayer& R = headp.L[l];
                 R.W = p[2 * l], R.b = p[2 * l + 1], R.N = L.N, R.K = L.K, R.ldw = L.K, R.k_off = 0, R.replicate = l == 3 ? 1 : 0;
             }
-            const int tg = cn::reg_total_quads(s->reg_xks) * 256, th = cn::reg_total_quads(cn::kRegLstmHead) * 256;
-            hipLaunchKernelGGL(cn::sarl_reg_pack_kernel, dim3((tg + 255) / 256), dim3(256), 0, e->stream, gates, s->reg_stream);
+            const int tg = cn::reg_total_quads(gates.xks) * 256, th = cn::reg_total_quads(cn::kRegLstmHead) * 256;
+            hipLaunchKernelGGL(cn::sarl_reg_pack_kernel, dim3((tg + 255) / 256), dim3(256), 0, e->stream, gates, gate_stream);
             hipLaunchKernelGGL(cn::sarl_reg_pack_kernel, dim3((th + 255) / 256), dim3(256), 0, e->stream, headp, s->reg_stream2);
             CN_HIP(hipGetLastError());
         }
@@ -572,6 +600,14 @@ int cn_sarl_select(cn_engine* e, double* values, int32_t* best, double* action) 
                 else CN_SARL_CHUNK(4, false);
             }
 #undef CN_SARL_CHUNK
+        } else if (cn::reg_is_lstm_mlp1(s->reg_xks)) {
+            const dim3 lgrid(wgs < (unsigned)s->n_cus ? wgs : (unsigned)s->n_cus);
+            if (s->reg_xks == cn::kRegLstmMlp1 + 4)
+                hipLaunchKernelGGL(cn::lstm2_reg_kernel<4>, lgrid, rblock, 0, e->stream, s->reg_stream, s->reg_stream3, s->reg_stream2, s->X,
+                                   s->V, ng, (int)s->n_tiles, H, s->net.ks_x, s->hcount);
+            else
+                hipLaunchKernelGGL(cn::lstm2_reg_kernel<16>, lgrid, rblock, 0, e->stream, s->reg_stream, s->reg_stream3, s->reg_stream2, s->X,
+                                   s->V, ng, (int)s->n_tiles, H, s->net.ks_x, s->hcount);
         } else if (cn::reg_is_gates(s->reg_xks)) {
             const dim3 lgrid(wgs < (unsigned)s->n_cus ? wgs : (unsigned)s->n_cus);
             if (s->reg_xks == cn::kRegLstmGates + 4)

@@ -58,13 +58,18 @@ constexpr int kRegCadrl = 1004;
 // kRegLstmGates + k-steps of the input) and the value head on [self (6) | h_n (50)] (4 layers).
 constexpr int kRegLstmGates = 2000, kRegLstmHead = 2100, kRegLstmHid = 50, kRegLstmKs = 13;  // 13 k-steps / output tiles of 50 units
 __host__ __device__ constexpr bool reg_is_gates(int key) { return key > kRegLstmGates && key < kRegLstmHead; }
+// lstm_rl.ValueNetwork2 (lstm_rl.py:36-66, with_interaction_module = true at the shipped widths mlp1_dims = 150, 100, 100, 50):
+// every human's row passes mlp1 in front of the LSTM — a third stream (kRegLstmMlp1 + k-steps of the input: 4 layers, the last
+// without ReLU, re-read for every human like the gate layer), and the gate layer's input is mlp1's 50 outputs (13 k-steps).
+constexpr int kRegLstmMlp1 = 2200;
+__host__ __device__ constexpr bool reg_is_lstm_mlp1(int key) { return key > kRegLstmMlp1 && key < kRegLstmMlp1 + 100; }
 // sarl.ValueNetwork for MORE than 5 humans (sarl_reg_chunk_kernel): the humans pass in chunks of NT, so the network is three
 // streams — A: mlp1.0, mlp1.2 (re-read per chunk, first pass; APre: mlp1.0 starts from the hoisted occupancy-map term),
 // G: attention.0's global half, then — after the second pass — the value head (read once per tile, in this order),
 // B: mlp2.0, mlp2.2, attention.0 local, attention.2, attention.4 (re-read per chunk, second pass).
 constexpr int kRegChunkA = 3001, kRegChunkAPre = 3002, kRegChunkB = 3003, kRegChunkG = 3004;
 __host__ __device__ constexpr int reg_layers(int key) {
-    return key == kRegCadrl || key == kRegLstmHead ? 4
+    return key == kRegCadrl || key == kRegLstmHead || reg_is_lstm_mlp1(key) ? 4
            : reg_is_gates(key)                       ? 1
            : key == kRegChunkA || key == kRegChunkAPre ? 2
            : key == kRegChunkB || key == kRegChunkG    ? 5
@@ -73,6 +78,14 @@ __host__ __device__ constexpr int reg_layers(int key) {
 
 __host__ __device__ constexpr RegShape reg_shape(int l, int xks) {
     if (reg_is_gates(xks)) return {xks - kRegLstmGates + kRegLstmKs, kRegLstmKs, 1, 0};  // [x_t | h_(t-1)] -> i, f, g, o of 4 units per tile
+    if (reg_is_lstm_mlp1(xks)) {
+        switch (l) {
+            case 0: return {xks - kRegLstmMlp1, 10, 1, 0};
+            case 1: return {38, 7, 1, 0};
+            case 2: return {25, 7, 1, 0};
+            default: return {25, 4, 1, 0};  // 50 outputs: k-steps 0..12 of the gate layer (units 50..63 of the last tile are zero)
+        }
+    }
     if (xks == kRegChunkA || xks == kRegChunkAPre)
         return l == 0 ? (xks == kRegChunkAPre ? RegShape{4, 10, 0, 0} : RegShape{4, 10, 1, 0}) : RegShape{38, 7, 1, 0};
     if (xks == kRegChunkB) {
@@ -822,6 +835,132 @@ __global__ __launch_bounds__(kRegWaves * 64) void lstm_reg_kernel(const float* g
     }
     for (int tile = done + wid; tile < n_tiles; tile += nw)
         lstm_reg_bundle<XKS, 1>(wg, wh, X, V, n_groups, H, ks_x, hcount, tile, lane);
+}
+
+// ---- lstm_rl.ValueNetwork2 (lstm_rl.py:36-66): mlp1 on every human's row in front of the cell ----------------------------
+// lstm_reg_bundle with one more stage per human: x_t -> mlp1 (150 - 100 - 100 - 50, ReLU between) as the value head's layers
+// are run — accumulators of a layer are the next layer's B operands, AGPR / VGPR arrays alternating — and the gate layer reads
+// [mlp1(x_t) | h] (13 + 13 k-steps).  NT tiles per wave: 3 (mlp1's 150-wide layer keeps 40 registers per tile alive beside the
+// 100-wide one's 28 and the cell's 26).
+template <int XKS, int NT>
+__device__ __forceinline__ void lstm2_reg_bundle(RegStream& wm, RegStream& wg, RegStream& wh, const float* X, float* V, int n_groups,
+                                                 int H, int ks_x, const int* hcount, int base, int lane) {
+    constexpr int MK = kRegLstmMlp1 + XKS, GK = kRegLstmGates + kRegLstmKs, HK = kRegLstmHead, KS = kRegLstmKs;
+    constexpr int QM = reg_total_quads(MK), QG = reg_total_quads(GK), QH = reg_total_quads(HK);
+    const gfloat_p Xg = as_global(X) + lane;
+    float h[NT][KS], c[NT][KS], x[NT][XKS], self0[NT], self1[NT];
+    int cnt[NT];
+    const auto load_x = [&](int t, float (&dst)[NT][XKS]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const gfloat_p xt = Xg + ((size_t)(base + nt) * H + t) * ks_x * 64;
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) dst[nt][ks] = xt[ks * 64];
+        }
+    };
+    load_x(0, x);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cnt[nt] = hcount[(size_t)(base + nt) * kSarlGroups + (lane & 15)];
+        self0[nt] = x[nt][0], self1[nt] = x[nt][1];  // self_state = state[:, 0, :6]: the first row's k-steps 0, 1
+#pragma unroll
+        for (int j = 0; j < KS; ++j) h[nt][j] = 0.0f, c[nt][j] = 0.0f;
+    }
+    const auto none = [](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; };
+#pragma unroll 1
+    for (int t = 0; t < H; ++t) {
+        float xn[NT][XKS], hn[NT][KS];
+        load_x(t + 1 < H ? t + 1 : t, xn);  // the next human's rows travel while this one computes
+        f32x4 m4[NT][4];
+        {
+            f32x4 m3[NT][7];
+            {
+                f32x4 m2[NT][7];
+                {
+                    f32x4 m1[NT][10];
+                    reg_dense_arr<MK, 0, NT, true>(wm, [&](int nt, int ks) { return x[nt][ks]; }, none, m1);
+                    reg_dense_arr<MK, 1, NT, false>(wm, [&](int nt, int ks) { return m1[nt][ks >> 2][ks & 3]; }, none, m2);
+                }
+                reg_dense_arr<MK, 2, NT, true>(wm, [&](int nt, int ks) { return m2[nt][ks >> 2][ks & 3]; }, none, m3);
+            }
+            reg_dense<MK, 3, NT, false>(wm, [&](int nt, int ks) { return m3[nt][ks >> 2][ks & 3]; }, none,
+                                        [&](int nt, int mt, f32x4 v) { m4[nt][mt] = v; });  // (cadrl.mlp: no ReLU behind the last layer)
+        }
+#pragma unroll
+        for (int i = reg_qbase(4, MK); i < QM; ++i) (void)reg_take<QM>(wm, i);
+        reg_dense<GK, 0, NT, false>(
+            wg, [&](int nt, int ks) { return ks < KS ? m4[nt][ks >> 2][ks & 3] : h[nt][ks - KS]; }, none,
+            [&](int nt, int mt, f32x4 v) {
+                const float cn_ = reg_sigmoid(v[1]) * c[nt][mt] + reg_sigmoid(v[0]) * reg_tanh(v[2]);
+                const float hn_ = reg_sigmoid(v[3]) * reg_tanh(cn_);
+                const bool present = t < cnt[nt];  // `mixed` rule: this group's episode has fewer humans
+                c[nt][mt] = present ? cn_ : c[nt][mt];
+                hn[nt][mt] = present ? hn_ : h[nt][mt];
+            });
+#pragma unroll
+        for (int i = reg_qbase(1, GK); i < QG; ++i) (void)reg_take<QG>(wg, i);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) h[nt][j] = hn[nt][j];
+#pragma unroll
+            for (int ks = 0; ks < XKS; ++ks) x[nt][ks] = xn[nt][ks];
+        }
+    }
+    float val[NT];
+    {
+        f32x4 j3[NT][7];
+        {
+            f32x4 j2[NT][7];
+            {
+                f32x4 j1[NT][10];
+                reg_dense_arr<HK, 0, NT, true>(
+                    wh, [&](int nt, int ks) { return ks < KS ? h[nt][ks] : ks == KS ? self0[nt] : self1[nt]; }, none, j1);
+                reg_dense_arr<HK, 1, NT, false>(wh, [&](int nt, int ks) { return j1[nt][ks >> 2][ks & 3]; }, none, j2);
+            }
+            reg_dense_arr<HK, 2, NT, true>(wh, [&](int nt, int ks) { return j2[nt][ks >> 2][ks & 3]; }, none, j3);
+        }
+        reg_dense<HK, 3, NT, false>(wh, [&](int nt, int ks) { return j3[nt][ks >> 2][ks & 3]; }, none,
+                                    [&](int nt, int, f32x4 v) { val[nt] = v[0]; });
+    }
+#pragma unroll
+    for (int i = reg_qbase(4, HK); i < QH; ++i) (void)reg_take<QH>(wh, i);
+    if (lane < kSarlGroups) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const size_t G = (size_t)(base + nt) * kSarlGroups + lane;
+            if (G < (size_t)n_groups) V[G] = val[nt];
+        }
+    }
+}
+
+constexpr int kLstm2Tiles = 3;  // (measured at 4096 x 81 x 5: 2 / 3 / 4 tiles per wave 1.797 / 1.765 / 1.768 ms; 4 spill with 61 inputs)
+template <int XKS>
+__global__ __launch_bounds__(kRegWaves * 64) void lstm2_reg_kernel(const float* mlp1, const float* gates, const float* head, const float* X,
+                                                                   float* V, int n_groups, int n_tiles, int H, int ks_x,
+                                                                   const int* hcount) {
+    constexpr int NT = kLstm2Tiles;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * kRegWaves + (threadIdx.x >> 6), nw = gridDim.x * kRegWaves;
+    RegStream wm, wg, wh;
+    wm.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(mlp1), 0, reg_total_quads(kRegLstmMlp1 + XKS) * 1024, 0x00020000);
+    wg.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gates), 0, reg_total_quads(kRegLstmGates + kRegLstmKs) * 1024, 0x00020000);
+    wh.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(head), 0, reg_total_quads(kRegLstmHead) * 1024, 0x00020000);
+    wm.voff = wg.voff = wh.voff = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < kRegDepth; ++i) wm.q[i] = reg_quad(wm, i), wg.q[i] = reg_quad(wg, i), wh.q[i] = reg_quad(wh, i);
+    const int rounds = n_tiles / (NT * nw);
+    int done = 0;
+    for (int k = 0; k < rounds; ++k)
+        lstm2_reg_bundle<XKS, NT>(wm, wg, wh, X, V, n_groups, H, ks_x, hcount, (k * nw + wid) * NT, lane);
+    done = rounds * NT * nw;
+    if (n_tiles - done > 2 * nw) {
+        const int nb = (n_tiles - done) / NT;
+        if (wid < nb) lstm2_reg_bundle<XKS, NT>(wm, wg, wh, X, V, n_groups, H, ks_x, hcount, done + wid * NT, lane);
+        done += nb * NT;
+    }
+    for (int tile = done + wid; tile < n_tiles; tile += nw)
+        lstm2_reg_bundle<XKS, 1>(wm, wg, wh, X, V, n_groups, H, ks_x, hcount, tile, lane);
 }
 
 // ---- sarl.ValueNetwork (sarl.py:28-65) for more than 5 humans, activations in registers ----------------------------------

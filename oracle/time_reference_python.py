@@ -85,13 +85,14 @@ def measure_crowd20(cases, radius=12.0):
             'what': 'unmodified reference loop, ORCA robot, 20 humans, circle_crossing on a %g m circle, one core' % radius}
 
 
-def rl_policy(policy_name, with_om, robot_visible=False, human_num=5):
+def rl_policy(policy_name, with_om, robot_visible=False, human_num=5, interaction=False):
     """(env, robot, policy) with a random-init value network exactly as crowd_nav/train.py:52-80 builds them (CPU device)"""
     import torch
     torch.set_num_threads(1)
     torch.manual_seed(0)
     pcfg = ref_harness.read_config('policy.config', {('sarl', 'with_om'): 'true' if with_om else 'false',
-                                                     ('lstm_rl', 'with_om'): 'true' if with_om else 'false'})
+                                                     ('lstm_rl', 'with_om'): 'true' if with_om else 'false',
+                                                     ('lstm_rl', 'with_interaction_module'): 'true' if interaction else 'false'})
     env, robot, policy = ref_harness.make_env(robot_visible=robot_visible, policy_name=policy_name, policy_config=pcfg,
                                               human_num=human_num)
     policy.set_device(torch.device('cpu'))
@@ -99,10 +100,10 @@ def rl_policy(policy_name, with_om, robot_visible=False, human_num=5):
     return env, robot, policy
 
 
-def measure_decisions(policy_name, with_om, n, human_num=5):
+def measure_decisions(policy_name, with_om, n, human_num=5, interaction=False):
     """n calls of the UNMODIFIED robot.act -> <policy>.predict in the 'test' phase (greedy: every call evaluates all 81
     actions), along the episodes the decisions themselves drive from env.reset('test', 0) on.  Only robot.act is timed."""
-    env, robot, policy = rl_policy(policy_name, with_om, human_num=human_num)
+    env, robot, policy = rl_policy(policy_name, with_om, human_num=human_num, interaction=interaction)
     policy.set_phase('test')
     ob, case, spent, done_n = env.reset('test', 0), 0, 0.0, 0
     action = robot.act(ob)  # first call: action space, lazy imports
@@ -115,7 +116,7 @@ def measure_decisions(policy_name, with_om, n, human_num=5):
         if done:
             case += 1
             ob = env.reset('test', case)
-    return {'policy': policy_name + ('+om' if with_om else ''), 'decisions': n, 'seconds': spent, 'decisions_per_s': n / spent,
+    return {'policy': policy_name + ('+om' if with_om else '') + ('+pairwise' if interaction else ''), 'decisions': n, 'seconds': spent, 'decisions_per_s': n / spent,
             'ms_per_decision': spent / n * 1e3, 'humans': human_num, 'actions': len(policy.action_space)}
 
 
@@ -167,7 +168,8 @@ def main():
                     'weights, torch CPU, 1 thread), 5 humans, greedy phase; only robot.act is timed',
             'unit': 'decisions/s',
             'runs': [measure_decisions('sarl', False, args.decisions), measure_decisions('sarl', True, args.decisions),
-                     measure_decisions('cadrl', False, args.decisions), measure_decisions('lstm_rl', False, args.decisions)]}
+                     measure_decisions('cadrl', False, args.decisions), measure_decisions('lstm_rl', False, args.decisions),
+                     measure_decisions('lstm_rl', False, args.decisions, interaction=True)]}  # lstm_rl.ValueNetwork2
     if 'sampling' in legs:
         out['sampling'] = dict(measure_sampling(args.sampling_seconds), unit='env-steps/s',
                                what="unmodified explorer.run_k_episodes(1, 'train', update_memory=True) calls, epsilon-greedy "

@@ -1,4 +1,4 @@
-"""Times cn_sarl_select for CADRL / LSTM-RL at 4096 envs x 81 actions; usage: policy_bench.py --policy cadrl --humans 5"""
+"""Times cn_sarl_select for CADRL / LSTM-RL at 4096 envs x 81 actions; usage: policy_bench.py --policy cadrl|lstm_rl|lstm_rl2 --humans 5"""
 import argparse, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +20,10 @@ if args.policy == 'cadrl':
     net = cadrl.ValueNetwork(13, [150, 100, 100, 1])
     eng.sarl_configure(actions=acts, model='cadrl', mlp3_dims=(150, 100, 100, 1))
     flop = 2 * 81 * H * (13 * 150 + head) * B
+elif args.policy == 'lstm_rl2':  # with_interaction_module = true (lstm_rl.ValueNetwork2)
+    net = lstm_rl.ValueNetwork2(13, 6, [150, 100, 100, 50], [150, 100, 100, 1], 50)
+    eng.sarl_configure(actions=acts, model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1), interaction_dims=(150, 100, 100, 50))
+    flop = 2 * 81 * (H * (13 * 150 + 150 * 100 + 100 * 100 + 100 * 50 + 200 * (50 + 50)) + 56 * 150 + head) * B
 else:
     net = lstm_rl.ValueNetwork1(13, 6, [150, 100, 100, 1], 50)
     eng.sarl_configure(actions=acts, model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))

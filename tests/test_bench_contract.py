@@ -88,13 +88,13 @@ def test_reference_python_baselines_are_timed_on_this_host_or_labelled_off_host(
     assert os.path.exists(bench.REFERENCE_PYTHON_PROFILE)
     r = json.load(open(bench.REFERENCE_PYTHON_PROFILE))
     assert r['cores'] == 1 and r['value'] > 0 and 'host_cpu' in r
-    assert {d['policy'] for d in r['decision']['runs']} == {'sarl', 'sarl+om', 'cadrl', 'lstm_rl'}
+    assert {d['policy'] for d in r['decision']['runs']} == {'sarl', 'sarl+om', 'cadrl', 'lstm_rl', 'lstm_rl+pairwise'}
     assert r['sampling']['env_steps'] > 0 and r['crowd20']['humans'] == 20
 
     def check(where):
         orca = bench.reference_python_baseline()
         assert orca['kind'] == 'reference' and orca['cores'] == 1 and orca['value'] > 0 and where in orca['host']
-        for pol in ('sarl', 'sarl+om', 'cadrl', 'lstm_rl'):
+        for pol in ('sarl', 'sarl+om', 'cadrl', 'lstm_rl', 'lstm_rl+pairwise'):
             d = bench.reference_decision_baseline(pol)
             assert d['unit'] == 'decisions/s' and d['cores'] == 1 and d['kind'] == 'reference' and where in d['host']
             assert 1.0 < d['value'] < 1000.0 and 'robot.act' in d['sample']  # ~10 decisions/s/core
@@ -135,10 +135,11 @@ def test_secondary_rows_carry_their_cpu_baseline(monkeypatch):
     monkeypatch.setattr(bench, 'reference_sampling_baseline', lambda: {'unit': 'env-steps/s'})
     monkeypatch.setattr(bench, 'config5_schedule_estimate', lambda: {'reference_estimate_s': {}})
     out = bench.secondary(4096, 0)
-    assert seen == ['sarl', 'sarl+om', 'cadrl', 'lstm_rl']
+    assert seen == ['sarl', 'sarl+om', 'cadrl', 'lstm_rl', 'lstm_rl+pairwise']
     assert out['sarl']['cpu_baseline'] == {'policy': 'sarl'} and out['om_sarl']['cpu_baseline'] == {'policy': 'sarl+om'}
     assert out['sarl']['decisions_per_s'] == 4096 / 2e-3
     assert out['cadrl']['cpu_baseline'] == {'policy': 'cadrl'} and out['lstm_rl']['cpu_baseline'] == {'policy': 'lstm_rl'}
+    assert out['lstm_rl_pairwise']['cpu_baseline'] == {'policy': 'lstm_rl+pairwise'}
     assert out['sample_step']['cpu_baseline'] == {'unit': 'env-steps/s'} and out['h20']['cpu_baseline'] == {'kind': 'port'}
     assert out['sample_step']['value'] == 1.0 and out['sample_step']['om_sarl']['value'] == 2.0
     assert out['sample_step']['lstm_rl']['value'] == 11.0 and out['sample_step']['lstm_rl_om']['value'] == 12.0

@@ -384,6 +384,79 @@ def test_register_resident_lstm_rl_value_network(humans, with_om, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('humans,with_om', [(1, False), (5, False), (5, True), (7, False)])
+def test_register_resident_lstm_rl_pairwise_value_network(humans, with_om, monkeypatch):
+    """lstm2_reg_kernel (lstm_rl.ValueNetwork2, lstm_rl.py:36-66: mlp1 on every human's row in front of the cell, all of it in
+    registers, 3 tiles side by side per wave) against the torch module and the LDS kernels: 5 569 tiles = one full round of
+    3-tile bundles on the 1024 waves, a partial round, then single tiles."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import lstm_rl
+    from crowdnav_amd.compat.sarl import build_action_space
+    torch.manual_seed(80 + humans)
+    d = 61 if with_om else 13
+    net = lstm_rl.ValueNetwork2(d, 6, [150, 100, 100, 50], [150, 100, 100, 1], 50)
+    B = 1100
+    space, _, _ = build_action_space(1.0)
+    got = {}
+    for reg in ('1', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        eng = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL,
+                                           robot_visible=1)
+        eng.reset(3000 + np.arange(B))
+        eng.step(np.zeros((B, 2)), update=True)
+        eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='lstm_rl', mlp1_dims=(50, 1),
+                           mlp3_dims=(150, 100, 100, 1), with_om=with_om, interaction_dims=(150, 100, 100, 50))
+        eng.sarl_set_weights(net.state_dict())
+        out = eng.sarl_select()
+        got[reg] = (eng.sarl_export('V').cpu().numpy(), out['best'].cpu().numpy(), eng.sarl_export('X').cpu())
+    with torch.no_grad():
+        want = net(got['1'][2].reshape(B * 81, humans, d)).reshape(B, 81).numpy()
+    assert torch.equal(got['1'][2], got['0'][2])
+    assert np.abs(got['1'][0] - want).max() <= 2e-5 and np.abs(got['0'][0] - want).max() <= 2e-5
+    assert np.abs(got['1'][0] - got['0'][0]).max() <= 2e-6
+    assert (got['1'][1] == got['0'][1]).mean() > 0.99
+
+
+@pytest.mark.gpu
+def test_register_resident_lstm_rl_pairwise_on_the_reference_fixture_and_under_the_mixed_rule(monkeypatch):
+    """Forced onto a small batch (CROWDNAV_AMD_SARL_REG=2), lstm2_reg_kernel reproduces the network outputs of the unmodified
+    reference's LstmRL with the interaction module (lstm_rl2_om.npz), and stops an episode's recurrence at its last present
+    human under the `mixed` rule like the LDS kernel does."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import lstm_rl
+    from crowdnav_amd.compat.sarl import build_action_space
+    monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', '2')
+    g = load_golden('lstm_rl2_om.npz')
+    n = len(g['states'])
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=n, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.set_state(g['states'], g['gtime'])
+    eng.sarl_configure(actions=g['action_space'], gamma=0.9, model='lstm_rl', with_om=True, mlp1_dims=(50, 1),
+                       mlp3_dims=(150, 100, 100, 1), interaction_dims=(150, 100, 100, 50))
+    eng.sarl_set_weights(_lstm2_mirror(g).state_dict())
+    out = eng.sarl_select()
+    assert np.abs(eng.sarl_export('V').cpu().numpy() - g['net_out']).max() <= 2e-6
+    assert np.abs(out['values'].cpu().numpy() - g['values']).max() <= 2e-6
+    torch.manual_seed(12)
+    net = lstm_rl.ValueNetwork2(13, 6, [150, 100, 100, 50], [150, 100, 100, 1], 50)
+    space, _, _ = build_action_space(1.0)
+    B, got = 64, {}
+    for reg in ('2', '0'):
+        monkeypatch.setenv('CROWDNAV_AMD_SARL_REG', reg)
+        e2 = crowdnav_amd.BatchedCrowdSim(num_envs=B, num_humans=5, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1,
+                                          scenario_rule=crowdnav_amd.MIXED)
+        e2.reset(1000 + np.arange(B))
+        e2.step(np.zeros((B, 2)), update=True)
+        e2.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), model='lstm_rl', mlp1_dims=(50, 1),
+                          mlp3_dims=(150, 100, 100, 1), interaction_dims=(150, 100, 100, 50))
+        e2.sarl_set_weights(net.state_dict())
+        e2.sarl_select()
+        got[reg] = e2.sarl_export('V').cpu().numpy()
+        counts = e2.human_count().cpu().numpy()
+    assert len(set(counts.tolist())) >= 3 and counts.min() < 5
+    assert np.abs(got['2'] - got['0']).max() <= 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True])
 def test_value_network_at_the_full_benchmark_size_vs_torch(with_om):
     """BASELINE configs[2] at full size: 4096 envs x 81 actions x 5 humans = 20 736 tiles through the register-resident kernel
