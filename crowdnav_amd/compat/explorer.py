@@ -58,7 +58,16 @@ class Explorer(object):
         35 tiny kernels for a few dozen rows: launch-bound — is replayed from a hipGraph captured on a fixed number of rows (the
         rows beyond the call's hold earlier, finite inputs and are not read back).  CROWDNAV_AMD_TD_GRAPH=0: always eager."""
         model = self.target_model
-        x = nxt.to(next(model.parameters()).device)
+        # (module, name) of every parameter, walked once per model object: model.parameters() visits every submodule — twice per
+        # sampled episode it was ~0.09 ms of host time; the Parameter objects are looked up afresh below, so a replaced or moved one
+        # still changes the key
+        slots = getattr(self, '_td_slots', (None, None))
+        if slots[0] is None or slots[0]() is not model:
+            import weakref
+            slots = self._td_slots = (weakref.ref(model), [(m, k) for m in model.modules() for k, p in m._parameters.items()
+                                                            if p is not None])
+        live = [m._parameters[k] for m, k in slots[1]]
+        x = nxt.to(live[0].device)
         n = int(x.shape[0])
         if (not x.is_cuda or n == 0 or getattr(self, '_td_graph_failed', False)
                 or os.environ.get('CROWDNAV_AMD_TD_GRAPH', '1') == '0'):
@@ -66,7 +75,7 @@ class Explorer(object):
         g = getattr(self, '_td_graph', None)
         # the graph replays reads of the parameters' STORAGE: a model whose parameters moved (.to(), .half(), load_state_dict(
         # assign=True), another module at a recycled id) must be captured again, not replayed on the old weights
-        key = (id(model), tuple(x.shape[1:]), x.dtype, tuple(p.data_ptr() for p in model.parameters()), model.training)
+        key = (id(model), tuple(x.shape[1:]), x.dtype, tuple(p.data_ptr() for p in live), model.training)
         if g is None or g['key'] != key or g['x'].shape[0] < n:
             rows = max(128, 2 * n if g is not None and g['key'] == key else n)
             try:
@@ -378,7 +387,14 @@ class Explorer(object):
             else:
                 lap = lambda name: None  # noqa: E731
             eng = self._rl_engine(B, human_num, rule)
-            eng.sarl_set_weights(policy.model.state_dict())
+            # (the parameters themselves, name -> Parameter, cached per model object: state_dict() builds 22 detached views per
+            # sampled episode, ~0.09 ms of host time; the optimizer updates the same tensors in place, and a model that moves or
+            # reloads keeps its Parameter objects — their addresses are read afresh by every call)
+            wkey = getattr(self, '_rl_params', (None, None))
+            if wkey[0] is None or wkey[0]() is not policy.model:
+                import weakref
+                wkey = self._rl_params = (weakref.ref(policy.model), dict(policy.model.named_parameters()))
+            eng.sarl_set_weights(wkey[1])
             # the seeds go up from a pinned buffer behind the weight re-pack, without a synchronisation (engine.reset waits
             # for the scenarios: ~0.1 ms per sampled episode of device idle time in front of the first step)
             skey = (id(eng), B)
