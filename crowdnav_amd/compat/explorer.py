@@ -328,12 +328,14 @@ class Explorer(object):
         training episode: 10 000 times in the shipped schedule)."""
         policy = self.robot.policy
         cfg = self.env.engine_config(B, human_num, rule, _lib.ROBOT_EXTERNAL)
-        key = (tuple(sorted(cfg.items())), id(policy), policy.action_table().tobytes())
+        # (the action table by the identity of the policy's action_space list — rebuilt tables are new lists; the cache entry holds
+        # the list, so its id cannot be recycled — instead of 81 tuples converted and hashed per sampled episode)
+        key = (tuple(sorted(cfg.items())), id(policy), id(policy.action_space))
         cached = getattr(self, '_rl_engine_cache', None)
         if cached is None or cached[0] != key:
             eng = BatchedCrowdSim(**cfg)
             eng.sarl_configure(**policy.engine_kwargs())
-            self._rl_engine_cache = cached = (key, eng)
+            self._rl_engine_cache = cached = (key, eng, policy.action_space)
         return cached[1]
 
     def _push_all(self, states, values):
@@ -394,7 +396,9 @@ class Explorer(object):
             if wkey[0] is None or wkey[0]() is not policy.model:
                 import weakref
                 wkey = self._rl_params = (weakref.ref(policy.model), dict(policy.model.named_parameters()))
+            lap('  (engine lookup)')
             eng.sarl_set_weights(wkey[1])
+            lap('  (weight re-pack)')
             # the seeds go up from a pinned buffer behind the weight re-pack, without a synchronisation (engine.reset waits
             # for the scenarios: ~0.1 ms per sampled episode of device idle time in front of the first step)
             skey = (id(eng), B)
@@ -405,6 +409,7 @@ class Explorer(object):
             with torch.cuda.stream(eng._stream):
                 seeds_dev.copy_(seeds_host, non_blocking=True)
             eng.reset_async(seeds_dev, None)
+            lap('  (seeds + reset)')
             # the histories live as long as the engine (one allocation + fill per shape, not five per sampled episode); every row
             # that is read below has been written by this call's steps, except traj's row T, which only feeds a value that
             # torch.where discards (stale rows are finite)
@@ -460,6 +465,7 @@ class Explorer(object):
             if prof is not None:
                 prof['n_steps_issued'] = prof.get('n_steps_issued', 0) + T
             host, n = packed.cpu().numpy(), max_steps * B
+            lap('  (histories to the host)')
             R, Dm = host[:8 * n].view(np.float64).reshape(max_steps, B)[:T], host[8 * n:16 * n].view(np.float64).reshape(max_steps, B)[:T]
             Ac, I = host[16 * n:20 * n].view(np.int32).reshape(max_steps, B)[:T], inf_np[:T].copy()
             I[I == kUnwritten] = _lib.NOTHING   # (rows behind an env's last step on the two-launch route)
@@ -494,8 +500,10 @@ class Explorer(object):
                     ends = np.flatnonzero(i_idx == Tb[b_idx] - 1)
                 if single:
                     states, nxt = states[:, 0], nxt[:, 0]
+                lap('  (rows of the episode)')
                 with torch.no_grad():
                     v_next = self._td_values(nxt).to(eng.device)
+                    lap('  (target network)')
                     values = torch.add(r, v_next.double(), alpha=gamma_bar)   # float64, as the reference's Python floats
                     if len(ends) == 1:
                         values[-1:].copy_(r[-1:])

@@ -12,6 +12,12 @@ spec = importlib.util.spec_from_file_location('train_sarl', os.path.join(ROOT, '
 mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
 args = mod.parser().parse_args(['--gpu', '--il-episodes', '100', '--il-epochs', '2', '--train-episodes', os.environ.get('CN_RL_PARTS_EPISODES', '300'), '--train-batches', os.environ.get('CN_RL_PARTS_BATCHES', '1'),
                                 '--evaluation-interval', '100000', '--val-size', '4', '--test-size', '4', '--seed', '0'])
+if os.environ.get('CN_RL_PARTS_GC') == 'off':  # (is the cyclic collector what the parts pay "in situ"?)
+    import gc
+    gc.disable()
+elif os.environ.get('CN_RL_PARTS_GC') == 'freeze':
+    import gc
+    gc.collect(); gc.freeze()
 out = mod.run(args)
 n = int(os.environ.get('CN_RL_PARTS_EPISODES', '300'))
 print({k: round(v / n * 1e3, 3) if isinstance(v, float) else v for k, v in prof.items()}, '(ms per call)', 'env steps', out['timing']['rl_env_steps'])
