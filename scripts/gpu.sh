@@ -128,13 +128,14 @@ gen)
   bench bench_h20_r4_async_train CROWDNAV_AMD_SCENARIO_CACHE=0 -- --no-cpu-baseline --humans 20 --circle-radius 4 --steps 5994 --warmup 402 --chunk 999 --preroll 99 --async-fill
   ( timeout 120 python scripts/reset_probe.py 22 2>&1 | grep "reset ms" | tee $OUT/reset_probe.txt ) ;;
 pmcnet)
-  # MFMA-pipe counters of the four value networks (one --pmc pass each) + their kernel-trace durations: SQ_VALU_MFMA_BUSY_CYCLES
+  # MFMA-pipe counters of the value networks (one --pmc pass each) + their kernel-trace durations: SQ_VALU_MFMA_BUSY_CYCLES
   # over the SIMD-cycles of the kernel = how busy the matrix pipe is in EXECUTED terms (padding included)
   MF="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
   declare -A NET
   NET[sarl]="$REPO/scripts/sarl_bench.py --iters 3"; NET[om_sarl]="$REPO/scripts/sarl_bench.py --iters 3 --om 1"
   NET[cadrl]="$REPO/scripts/policy_bench.py --policy cadrl --iters 3"; NET[lstm_rl]="$REPO/scripts/policy_bench.py --policy lstm_rl --iters 3"
-  for v in sarl om_sarl cadrl lstm_rl; do
+  NET[lstm_rl2]="$REPO/scripts/policy_bench.py --policy lstm_rl2 --iters 3"  # with_interaction_module = true (ValueNetwork2)
+  for v in sarl om_sarl cadrl lstm_rl lstm_rl2; do
     prof pmc_${v}_mfma --pmc $MF --output-format csv -d $OUT/pmc_${v}_mfma -o p -- python ${NET[$v]}
     prof trace_${v} --kernel-trace --stats --output-format csv -d $OUT/trace_${v} -o trace -- python ${NET[$v]}
   done

@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-for v in ('sarl', 'om_sarl', 'cadrl', 'lstm_rl'):
+for v in ('sarl', 'om_sarl', 'cadrl', 'lstm_rl', 'lstm_rl2'):
     pm = glob.glob(os.path.join(root, 'pmc_%s_mfma' % v, '**', '*counter_collection.csv'), recursive=True)
     tr = glob.glob(os.path.join(root, 'trace_%s' % v, '**', '*kernel_stats.csv'), recursive=True)
     if not pm:
@@ -34,7 +34,7 @@ for v in ('sarl', 'om_sarl', 'cadrl', 'lstm_rl'):
             continue
         simd_cycles = c['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0
         busy = c['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles
-        line = '%-8s %-48s MFMA-pipe busy %.3f  (SQ_VALU_MFMA_BUSY_CYCLES %.4g / SIMD-cycles %.4g)  MFMAs %.4g' % (
+        line = '%-9s %-48s MFMA-pipe busy %.3f  (SQ_VALU_MFMA_BUSY_CYCLES %.4g / SIMD-cycles %.4g)  MFMAs %.4g' % (
             v, k[:48], busy, c['SQ_VALU_MFMA_BUSY_CYCLES'], simd_cycles, c['SQ_INSTS_MFMA'])
         if k in dur:
             line += '  avg %.3f ms  executed %.1f TFLOP/s (%.3f of 157.3)' % (dur[k] / 1e6, c['SQ_INSTS_MFMA'] * 2048 / dur[k] / 1e3,

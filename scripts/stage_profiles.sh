@@ -2,7 +2,7 @@
 # the GPU suite's log, the traffic / counter summaries).      bash scripts/stage_profiles.sh r06
 TAG=${1:-r06}; cd "$(dirname "$0")/.."; S=gpurun_out/$TAG; P=profiles
 python scripts/bench_to_profiles.py $TAG
-for t in default driver sarl om_sarl h20 cadrl lstm_rl step; do
+for t in default driver sarl om_sarl h20 cadrl lstm_rl lstm_rl2 step; do
   [ -f $S/trace_$t/trace_kernel_stats.csv ] && cp $S/trace_$t/trace_kernel_stats.csv $P/${TAG}_kernel_stats_$t.csv
 done
 [ -f $S/trace_driver/trace_kernel_trace.csv ] && cp $S/trace_driver/trace_kernel_trace.csv $P/${TAG}_kernel_trace_driver.csv
