@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CROWDNAV_AMD_LIB: another build of the same library (kernel A/B experiments, scripts/gpu_ab.sh); default in-tree
 LIB_PATH = os.environ.get('CROWDNAV_AMD_LIB') or os.path.join(HERE, 'lib', 'libcrowdnav_amd.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 CN_OK, CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_HIP, CN_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 INFO_NAMES = ('Nothing', 'Danger', 'ReachGoal', 'Collision', 'Timeout')
@@ -106,6 +106,7 @@ SYMBOLS = {
     'cn_sarl_explore': (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
     'cn_sarl_transform': (C.c_int, [_P, _P, C.c_int64, C.c_int]),
     'cn_sarl_sample_step': (C.c_int, [_P, C.c_double, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    'cn_sarl_values': (C.c_int, [_P, _P, C.c_int64, _P]),
     'cn_sarl_export': (C.c_int, [_P, C.c_int, _P, C.c_uint64]),
     'cn_rollout_records': (C.c_int, [_P, C.POINTER(CnRolloutIo), C.c_int, _P]),
     'cn_gather_records': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),

@@ -68,6 +68,9 @@ class Explorer(object):
                                                             if p is not None])
         live = [m._parameters[k] for m, k in slots[1]]
         x = nxt.to(live[0].device)
+        v = self._td_values_on_engine(model, live, x)
+        if v is not None:
+            return v
         n = int(x.shape[0])
         if (not x.is_cuda or n == 0 or getattr(self, '_td_graph_failed', False)
                 or os.environ.get('CROWDNAV_AMD_TD_GRAPH', '1') == '0'):
@@ -97,6 +100,55 @@ class Explorer(object):
         g['x'][:n].copy_(x)
         g['graph'].replay()
         return g['y'][:n].reshape(-1)  # (a view of the graph's output: consumed before the next replay — update_memory converts it at once)
+
+    def _td_values_on_engine(self, model, live, x):
+        """The target network's forward by the library's own network kernel (cn_sarl_values: ONE launch on the narrow tiles, the
+        rows read where they lie) on an engine that only holds the target's weights — uploaded again whenever a parameter's
+        version counter or address moved (update_target_model's in-place copy bumps the versions).  None: not this configuration
+        (another policy, occupancy maps, CPU, CROWDNAV_AMD_TD_KERNEL=0) — the caller runs the framework's forward."""
+        policy = self.robot.policy if self.robot is not None else None
+        cfg = getattr(policy, 'net_cfg', None)
+        if (cfg is None or not x.is_cuda or x.dim() != 3 or x.shape[2] != 13 or x.dtype != torch.float32 or x.shape[0] == 0
+                or cfg.get('model', 'sarl') not in ('sarl', 'lstm_rl') or cfg.get('with_om') or cfg.get('interaction_dims')
+                or getattr(self, '_td_kernel_off', False) or os.environ.get('CROWDNAV_AMD_TD_KERNEL', '1') == '0'
+                or type(model) is not type(getattr(policy, 'model', None)) or getattr(self, '_rl_engine_cache', None) is None):
+            return None
+        n, H = int(x.shape[0]), int(x.shape[1])
+        K = len(policy.action_space)
+        envs = 2
+        while envs * K < n:
+            envs *= 2
+        sig = tuple((p.data_ptr(), p._version) for p in live)
+        cached = getattr(self, '_td_engine', None)
+        try:
+            if cached is None or cached['model']() is not model or cached['envs'] < envs or cached['H'] != H:
+                import weakref
+                base = dict(self._rl_engine_cache[0][0])  # the sampling engine's configuration: the same crowd, robot, widths
+                if base['num_humans'] != H:
+                    return None
+                base['num_envs'] = envs
+                eng = BatchedCrowdSim(**base)
+                eng.sarl_configure(**policy.engine_kwargs())
+                cached = self._td_engine = dict(model=weakref.ref(model), envs=envs, H=H, eng=eng, sig=None)
+            if cached['sig'] != sig:
+                cached['eng'].sarl_set_weights({k: m._parameters[k_] for (m, k_), k in
+                                                zip(self._td_slots[1], self._td_names(model))})
+                cached['sig'] = sig
+            return cached['eng'].sarl_values(x.contiguous())
+        except _lib.CrowdNavAmdError as exc:  # e.g. CN_ERR_UNSUPPORTED for widths / sizes off the narrow tiles
+            logging.info('TD targets: cn_sarl_values not available here (%s); using the framework forward', exc)
+            self._td_kernel_off = True
+            return None
+
+    def _td_names(self, model):
+        """state_dict names of the parameter slots of _td_values, in the same order (module walk: prefix + parameter name)."""
+        names = getattr(self, '_td_name_cache', (None, None))
+        if names[0] is None or names[0]() is not model:
+            import weakref
+            names = self._td_name_cache = (weakref.ref(model), [(prefix + '.' if prefix else '') + k
+                                                               for prefix, m in model.named_modules()
+                                                               for k, p in m._parameters.items() if p is not None])
+        return names[1]
 
     # ------------------------------------------------------------------ explorer.py:21-90
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,

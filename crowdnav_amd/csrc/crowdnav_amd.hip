@@ -23,7 +23,7 @@ void cn_launch_orca(cn_engine* e, float* out_vel) { CN_LAUNCH_MAXL(e, orca_kerne
 extern "C" {
 
 const char* cn_last_error(void) { return cn_g_err; }
-int cn_abi_version(void) { return 10; }
+int cn_abi_version(void) { return 11; }
 
 int cn_create(const cn_config* c, cn_engine** out) {
     if (!c || !out) return fail(CN_ERR_INVALID, "cn_create: NULL argument");

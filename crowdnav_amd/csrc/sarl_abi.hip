@@ -760,6 +760,30 @@ int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* b
     return cn_step(e, action, 1, reward, done, info, dmin, nullptr, nullptr, nullptr);
 }
 
+int cn_sarl_values(cn_engine* e, const float* states, int64_t n, float* out) {
+    int rc = bind(e);
+    if (rc) return rc;
+    cn_sarl* s = e->sarl;
+    if (!s || !s->weights_set) return fail(CN_ERR_INVALID, "cn_sarl_values: configure and set weights first");
+    if (!states || !out) return fail(CN_ERR_INVALID, "cn_sarl_values: NULL argument");
+    if (n < 1 || (uint64_t)n > (uint64_t)s->n_groups)
+        return fail(CN_ERR_INVALID, "cn_sarl_values: %lld states, the engine's tiles hold 1 .. %zu (envs x actions)", (long long)n,
+                    s->n_groups);
+    const cn::SarlCfg& C = s->C;
+    if (!s->narrow || s->net.in_dim != 13 || s->cfg.model == CN_MODEL_CADRL)
+        return fail(CN_ERR_UNSUPPORTED, "cn_sarl_values: SARL / LSTM-RL on 13-wide rows at a size that takes the narrow tiles only");
+    cn::SarlDecide D{};
+    D.x_rows = states, D.ext_groups = (int)n, D.in_dim = s->net.in_dim;
+    const int GT = cn::kSarlGroups / C.H;
+    const unsigned tiles = (unsigned)((n + GT - 1) / GT);
+    const auto narrow_kernel = s->cfg.model == CN_MODEL_LSTM_RL ? cn::sarl_narrow_kernel<true> : cn::sarl_narrow_kernel<false>;
+    hipLaunchKernelGGL(narrow_kernel, dim3(tiles), dim3(cn::kNarrowThreads), s->narrow_lds, e->stream, s->ref, C, e->S.pos, e->S.vel,
+                       e->S.goal, e->S.rv, e->S.theta, s->actions, s->orca_vel, s->next_obs, out, D, (const float*)nullptr);
+    e->launch_counts[CN_COUNT_SARL_NARROW] += 1;
+    CN_HIP(hipGetLastError());
+    return CN_OK;
+}
+
 int cn_sarl_export(cn_engine* e, int which, void* dst, uint64_t bytes) {
     int rc = bind(e);
     if (rc) return rc;

@@ -1520,6 +1520,10 @@ struct SarlDecide {
     double* next_obs_out;  // [B][H][5]
     float* om_out;         // [B][H][cells * channels]
     int side_wg;           // sarl_narrow_kernel: the LAST workgroup of the grid is not a tile — it writes the replay-memory states
+    // cn_sarl_values (ABI v11): the rows come from the caller — joint states [ext_groups][H][13] float32 as cn_sarl_transform /
+    // cn_sarl_sample_step wrote them (a replay memory's states) — instead of being built from the envs: V of each, nothing else
+    const float* x_rows;
+    int ext_groups;
 };
 // The same network for a FEW decisions (the single-episode sampling of train.py:156-170: one env, 81 groups = 6 tiles): the
 // one-tile kernels above put a decision on 6 of 256 CUs for ~40 us.  Here a tile is ONE 16-row MFMA tile holding
@@ -1698,7 +1702,7 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
     // where row r = (group r / H, human r % H) of the tile keeps its features: its own row of the one X tile, or (LSTM) row
     // `group` of its human's X tile
     const auto xrow = [&](int r) { return LSTM ? (r % H) * net.ks_x * 64 + r / H : r; };
-    const int n_groups = C.B * C.n_actions;
+    const int n_groups = D.x_rows != nullptr ? D.ext_groups : C.B * C.n_actions;
     const size_t tile = blockIdx.x;
     const unsigned n_tiles = gridDim.x - (unsigned)D.side_wg;
     const SarlNetRef* n = &net;
@@ -1731,18 +1735,22 @@ __global__ __launch_bounds__(kNarrowThreads) void sarl_narrow_kernel(SarlNetRef 
         const int g = tid / H, h = tid - g * H;
         const size_t G = tile * GT + g;
         row_valid = G < (size_t)n_groups;
-        if (row_valid)
+        if (row_valid && D.x_rows != nullptr) {
+            const float* xr = D.x_rows + (G * H + h) * 13;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) f[k] = xr[k];
+        } else if (row_valid)
             sarl_feature_row(C, (int)(G / C.n_actions), (int)(G % C.n_actions), h, pos, goal, rv, theta, actions, next_obs, vel,
                              orca_vel, f);
         if (h == 0) {  // len(state.human_states): under the `mixed` rule the env's absent humans are parked behind the present ones
             int present = H;
-            if (row_valid) {
+            if (row_valid && D.x_rows == nullptr) {
                 const size_t e0 = (G / C.n_actions) * (size_t)(H + 1);
                 present = 0;
                 for (int j = 0; j < H; ++j) present += is_parked(pos[e0 + 1 + j]) ? 0 : 1;
             }
             hc[g] = present;
-            hl[g] = (row_valid && sampling((int)(G / C.n_actions))) ? 1 : 0;
+            hl[g] = (row_valid && (D.x_rows != nullptr || sampling((int)(G / C.n_actions)))) ? 1 : 0;
         }
         // (occupancy maps) where this row's map starts in `om`; vbuf is not part of the zeroed region
         if (om != nullptr) reinterpret_cast<int*>(vbuf)[tid] = row_valid ? (int)(((G / C.n_actions) * H + h) * (size_t)(D.in_dim - 13)) : -1;

@@ -463,6 +463,21 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     return step
 
 
+def _sarl_values(self, states, out=None):
+    """V(state) of joint states the caller holds (cn_sarl_values): float32 [n, H, 13] rows as sarl_transform / the sampler
+    write them -> float32 [n], under the weights of the last sarl_set_weights.  One launch on the narrow tiles; the engine's
+    env state is not touched.  What target_model(next_states) is to Explorer.update_memory's TD targets."""
+    n = int(states.shape[0])
+    if (states.device != self.device or states.dtype != torch.float32 or tuple(states.shape[1:]) != (self.H, 13)
+            or not states.is_contiguous()):
+        raise ValueError('sarl_values: expected a contiguous float32 [n, %d, 13] tensor on %s' % (self.H, self.device))
+    if out is None:
+        out = self._new((n,), torch.float32)
+    check(self._lib.cn_sarl_values(self._h, _ptr(states), n, _ptr(out)))
+    return out
+
+
+BatchedCrowdSim.sarl_values = _sarl_values
 BatchedCrowdSim.sarl_sampler = _sarl_sampler
 BatchedCrowdSim.sarl_configure = _sarl_configure
 BatchedCrowdSim.sarl_set_weights = _sarl_set_weights

@@ -97,7 +97,7 @@ const char* cn_last_error(void);
 /* ABI version of this header (bumped on any change of a signature or of what a call does).  v10 (round 6): no new symbol —
  * cn_sarl_sample_step skips the envs outside `alive` on its two-launch route, takes CN_MODEL_LSTM_RL there and accepts `info` in
  * pinned host memory; cn_rollout / cn_rollout_step / the boundary calls refuse an io whose seed_base / seed_mod differ from
- * cn_rollout_begin's. */
+ * cn_rollout_begin's.  v11 (round 6): + cn_sarl_values. */
 int cn_abi_version(void);
 
 /* replaces gym.make('CrowdSim-v0') + CrowdSim.configure + set_robot (crowd_sim.py:13-82): allocates the
@@ -362,6 +362,15 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
  * sees the episode-end codes arrive without synchronising (compat.Explorer._run_batched_rl). */
 int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
                         int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin);
+/* (ABI v11) V(state) of n joint states the CALLER holds — float32 [n][num_humans][13] rows in the layout cn_sarl_transform /
+ * cn_sarl_sample_step write (a replay memory's states) — under the weights last given to cn_sarl_set_weights: what
+ * `target_model(next_states)` is to the TD targets of Explorer.update_memory (crowd_nav/utils/explorer.py:113-116), on the
+ * narrow tiles (sarl_narrow_kernel: ONE launch, the rows read where they lie) instead of the ~35 library kernels of a
+ * framework forward on a few dozen rows.  out: float32 [n].  The env state of the engine is neither read nor written — an engine
+ * that only serves a target network needs no reset.  CN_MODEL_SARL / CN_MODEL_LSTM_RL (ValueNetwork1) without occupancy maps
+ * at a size that takes the narrow tiles (cn_sarl_sample_step's conditions), 1 <= n <= num_envs x n_actions; CN_ERR_UNSUPPORTED
+ * otherwise.  Same arithmetic as the decision's network kernel (tests/test_sarl.py: <= 2e-6 of the framework's forward). */
+int cn_sarl_values(cn_engine* e, const float* states, int64_t n, float* out);
 /* test/inspection: copy an internal buffer of the last cn_sarl_select to dst (device pointer):
  *   0 reward f64 [B][K] · 1 V f32 [B*K] · 2 next human states f64 [B][H][5] · 3 occupancy maps f32 [B][H][cells*ch]
  *   4 X f32 in MLP tile order (see sarl_kernels.h) */

@@ -349,8 +349,8 @@ def test_sample_step_is_the_five_calls_it_replaces(B, humans, n_act, with_om, mo
 def test_single_episode_sampling_calls_reproduce_the_reference_memory(name, model_on_gpu):
     """train.py:156-170 samples ONE episode per call: the same fixtures with max_envs = 1 — every episode its own one-env batch
     (the narrow-tile route of cn_sarl_sample_step for SARL, one episode's slices of the histories as replay rows).  With the
-    model on the GPU (`examples/train_sarl.py --gpu`) the TD targets come from the graph-replayed forward of the target
-    network, whose parameters a second update_target_model overwrites in place."""
+    model on the GPU (`examples/train_sarl.py --gpu`) the TD targets come from cn_sarl_values (13-wide rows) or the graph-replayed
+    forward of the target network, whose parameters a second update_target_model overwrites in place."""
     from crowdnav_amd.compat.trainer import DeviceReplayMemory
     g = load_golden(name)
     c, env, robot, policy = _setup(g)
@@ -383,7 +383,25 @@ def test_single_episode_sampling_calls_reproduce_the_reference_memory(name, mode
     if states.ndim == 2:
         states = states[:, None, :]
     assert np.abs(states - g['memory_states']).max() <= 5e-6 and np.abs(values - g['memory_values']).max() <= 1e-6
-    if model_on_gpu and not name.startswith('rl_lstm_rl'):
+    if model_on_gpu and name in ('rl_sarl_plain.npz', 'rl_lstm_rl.npz'):
+        # 13-wide rows (round 6, ABI v11): the TD targets are cn_sarl_values on an engine that only holds the target's weights —
+        # uploaded again after the second update_target_model (the scrambled ones would fail the 1e-6 above)
+        assert ex._td_engine is not None and getattr(ex, '_td_graph', None) is None
+        kept = sum(1 for o in lb['outcome'] if o in (2, 3))   # ReachGoal / Collision episodes enter the memory: one launch each
+        assert ex._td_engine['eng'].launch_counts()['sarl_narrow'] == kept >= 1
+        # ... and follows the target's parameters: changed in place (version counters) or given new storage (addresses)
+        x = torch.stack([mem[i][0] for i in range(min(len(mem), 7))]).reshape(-1, states.shape[1], 13)
+        with torch.no_grad():
+            v0 = ex._td_values(x).clone()
+            for p_ in ex.target_model.parameters():
+                p_.mul_(0.5)
+            v1 = ex._td_values(x).clone()
+            assert torch.allclose(v1, ex.target_model(x).reshape(-1), atol=2e-6) and not torch.allclose(v1, v0)
+            for p_ in ex.target_model.parameters():
+                p_.data = p_.data.clone() * 2.0
+            v2 = ex._td_values(x)
+            assert torch.allclose(v2, ex.target_model(x).reshape(-1), atol=2e-6) and torch.allclose(v2, v0, atol=2e-6)
+    elif model_on_gpu and not name.startswith('rl_lstm_rl'):
         assert ex._td_graph is not None   # (an nn.LSTM forward may refuse capture: then the eager path ran, with a warning)
     # which route sampled: SARL and LSTM-RL (with or without occupancy maps: round 6) and CADRL take the narrow tiles + the fused
     # decision / transition kernel — two launches per streamed step

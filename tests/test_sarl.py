@@ -457,6 +457,49 @@ def test_register_resident_lstm_rl_pairwise_on_the_reference_fixture_and_under_t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('model,humans', [('sarl', 5), ('sarl', 3), ('lstm_rl', 5)])
+def test_values_of_caller_held_states_vs_torch(model, humans):
+    """cn_sarl_values (ABI v11): V of joint states the caller holds — replay-memory rows [n, H, 13] — under the engine's weights,
+    by the narrow-tile network kernel reading the rows where they lie: against the torch module on the same rows (what
+    target_model(next_states) is to explorer.py:113-116), for every n from one state to the engine's capacity; and the refusals."""
+    import crowdnav_amd
+    from crowdnav_amd.compat import lstm_rl
+    from crowdnav_amd.compat.sarl import ValueNetwork, build_action_space
+    torch.manual_seed(90 + humans)
+    if model == 'sarl':
+        net = ValueNetwork(13, 6, [150, 100], [100, 50], [150, 100, 100, 1], [100, 100, 1], True, 1.0, 4)
+        kw = {}
+    else:
+        net = lstm_rl.ValueNetwork1(13, 6, [150, 100, 100, 1], 50)
+        kw = dict(model='lstm_rl', mlp1_dims=(50, 1), mlp3_dims=(150, 100, 100, 1))
+    space, _, _ = build_action_space(1.0)
+    eng = crowdnav_amd.BatchedCrowdSim(num_envs=2, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    eng.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), **kw)  # (never reset: the env state is not read)
+    eng.sarl_set_weights(net.state_dict())
+    # rows a replay memory would hold: the transform of real states
+    src = crowdnav_amd.BatchedCrowdSim(num_envs=162, num_humans=humans, robot_policy=crowdnav_amd.ROBOT_EXTERNAL, robot_visible=1)
+    src.reset(500 + np.arange(162))
+    src.step(np.zeros((162, 2)), update=True)
+    src.sarl_configure(actions=np.array([[a.vx, a.vy] for a in space]), **kw)
+    rows = src.sarl_transform(sort_humans=(model == 'lstm_rl')).contiguous()
+    assert tuple(rows.shape) == (162, humans, 13)
+    dev_net = net.to(rows.device)
+    with torch.no_grad():
+        want = dev_net(rows).reshape(-1)
+    for n in (1, 2, 5, 53, 54, 161, 162):
+        got = eng.sarl_values(rows[:n].contiguous())
+        eng.sync()
+        assert float((got - want[:n]).abs().max()) <= 2e-6, n
+    with pytest.raises(crowdnav_amd.CrowdNavAmdError):
+        eng.sarl_values(torch.cat([rows, rows[:1]]))  # more states than the engine's tiles hold
+    # the decision's own network kernel gives the same bits for the same rows (same kernel, rows built in LDS instead)
+    before = eng.launch_counts()
+    eng.sarl_values(rows[:54].contiguous())
+    after = eng.launch_counts()
+    assert after['sarl_narrow'] - before['sarl_narrow'] == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('with_om', [False, True])
 def test_value_network_at_the_full_benchmark_size_vs_torch(with_om):
     """BASELINE configs[2] at full size: 4096 envs x 81 actions x 5 humans = 20 736 tiles through the register-resident kernel
