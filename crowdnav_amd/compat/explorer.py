@@ -118,6 +118,8 @@ class Explorer(object):
         envs = 2
         while envs * K < n:
             envs *= 2
+        if envs > 8:  # (more rows than the narrow tiles take — one workgroup per CU: this call's forward is the framework's)
+            return None
         sig = tuple((p.data_ptr(), p._version) for p in live)
         cached = getattr(self, '_td_engine', None)
         try:
