@@ -734,6 +734,13 @@ __device__ __forceinline__ float reg_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.885390081777927f * x));
 }
 
+// (m all ones: a, zero: b) as ONE v_bfi_b32 on values that are computed either way.  `present ? new : old` let hipcc sink the
+// whole cell update under a divergent branch — s_and_saveexec / s_cbranch_execz / s_or_b64 around each of the 65 (tile, output
+// tile) updates of a step, every one a scheduling barrier between the MFMAs of neighbouring output tiles.
+__device__ __forceinline__ float reg_select(uint32_t m, float a, float b) {
+    return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
+
 template <int XKS, int NT>
 __device__ __forceinline__ void lstm_reg_bundle(RegStream& wg, RegStream& wh, const float* X, float* V, int n_groups, int H, int ks_x,
                                                 const int* hcount, int base, int lane) {
@@ -763,14 +770,16 @@ __device__ __forceinline__ void lstm_reg_bundle(RegStream& wg, RegStream& wh, co
     for (int t = 0; t < H; ++t) {
         float xn[NT][XKS], hn[NT][KS];
         load_x(t + 1 < H ? t + 1 : t, xn);  // the next human's rows travel while this one computes
+        uint32_t present[NT];  // `mixed` rule: a group whose episode has fewer humans keeps its state from here on
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) present[nt] = t < cnt[nt] ? 0xffffffffu : 0u;
         reg_dense<GK, 0, NT, false>(
             wg, [&](int nt, int ks) { return ks < XKS ? x[nt][ks] : h[nt][ks - XKS]; }, none,
             [&](int nt, int mt, f32x4 v) {
                 const float cn_ = reg_sigmoid(v[1]) * c[nt][mt] + reg_sigmoid(v[0]) * reg_tanh(v[2]);
                 const float hn_ = reg_sigmoid(v[3]) * reg_tanh(cn_);
-                const bool present = t < cnt[nt];  // `mixed` rule: this group's episode has fewer humans
-                c[nt][mt] = present ? cn_ : c[nt][mt];
-                hn[nt][mt] = present ? hn_ : h[nt][mt];
+                c[nt][mt] = reg_select(present[nt], cn_, c[nt][mt]);
+                hn[nt][mt] = reg_select(present[nt], hn_, h[nt][mt]);
             });
 #pragma unroll
         for (int i = reg_qbase(1, GK); i < QG; ++i) (void)reg_take<QG>(wg, i);
@@ -871,6 +880,9 @@ __device__ __forceinline__ void lstm2_reg_bundle(RegStream& wm, RegStream& wg, R
     for (int t = 0; t < H; ++t) {
         float xn[NT][XKS], hn[NT][KS];
         load_x(t + 1 < H ? t + 1 : t, xn);  // the next human's rows travel while this one computes
+        uint32_t present[NT];  // `mixed` rule: a group whose episode has fewer humans keeps its state from here on
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) present[nt] = t < cnt[nt] ? 0xffffffffu : 0u;
         f32x4 m4[NT][4];
         {
             f32x4 m3[NT][7];
@@ -893,9 +905,8 @@ __device__ __forceinline__ void lstm2_reg_bundle(RegStream& wm, RegStream& wg, R
             [&](int nt, int mt, f32x4 v) {
                 const float cn_ = reg_sigmoid(v[1]) * c[nt][mt] + reg_sigmoid(v[0]) * reg_tanh(v[2]);
                 const float hn_ = reg_sigmoid(v[3]) * reg_tanh(cn_);
-                const bool present = t < cnt[nt];  // `mixed` rule: this group's episode has fewer humans
-                c[nt][mt] = present ? cn_ : c[nt][mt];
-                hn[nt][mt] = present ? hn_ : h[nt][mt];
+                c[nt][mt] = reg_select(present[nt], cn_, c[nt][mt]);
+                hn[nt][mt] = reg_select(present[nt], hn_, h[nt][mt]);
             });
 #pragma unroll
         for (int i = reg_qbase(1, GK); i < QG; ++i) (void)reg_take<QG>(wg, i);
