@@ -150,6 +150,29 @@ def _setup(g):
 
 
 @pytest.mark.gpu
+def test_rl_engine_cache_follows_everything_the_engine_is_built_from():
+    """Explorer._rl_engine keeps ONE engine between the 10 000 single-episode calls of train.py — found again by a fast key of
+    what engine_config reads (by value, or by identity for the config object, the policy and its action-space list): any of
+    those changing must give another engine, nothing else may."""
+    g = load_golden('rl_sarl_plain.npz')
+    c, env, robot, policy = _setup(g)
+    policy.build_action_space(robot.v_pref)
+    ex = c.Explorer(env, robot, torch.device('cpu'), None, float(g['gamma']), target_policy=policy)
+    e0 = ex._rl_engine(1, 5, 'circle_crossing')
+    assert ex._rl_engine(1, 5, 'circle_crossing') is e0           # the fast path
+    env.discomfort_dist = env.discomfort_dist + 0.05             # a value engine_config reads
+    e1 = ex._rl_engine(1, 5, 'circle_crossing')
+    assert e1 is not e0 and ex._rl_engine(1, 5, 'circle_crossing') is e1
+    policy.action_space = list(policy.action_space)              # a rebuilt table (same values: still a new engine, by identity)
+    e2 = ex._rl_engine(1, 5, 'circle_crossing')
+    assert e2 is not e1
+    assert ex._rl_engine(2, 5, 'circle_crossing') is not e2      # another batch size
+    robot.time_step = 0.25                                       # not part of the engine: no new engine
+    e3 = ex._rl_engine(2, 5, 'circle_crossing')
+    assert ex._rl_engine(2, 5, 'circle_crossing') is e3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('randomize,humans', [(False, 5), (True, 5), (False, 12), (True, 14)])
 def test_explore_continues_each_envs_numpy_stream(randomize, humans):
     """cn_sarl_explore draws from the stream np.random.seed(seed) + the scenario's random() calls left behind — with the
