@@ -479,13 +479,18 @@ class Explorer(object):
             # the histories live as long as the engine (one allocation + fill per shape, not five per sampled episode); every row
             # that is read below has been written by this call's steps, except traj's row T, which only feeds a value that
             # torch.where discards (stale rows are finite)
-            hkey = (id(eng), B, max_steps, human_num, D)
+            # A few envs (the two-launch route of cn_sarl_sample_step: train.py samples ONE episode per call): ALL four histories
+            # live in pinned host memory — the kernels only write them, a step's reward / min distance / action before its info
+            # code — so that the host reads an episode's rows the moment its end code has arrived: no copy back, no wait for the
+            # steps issued past the end, and the TD targets, the push and the host's statistics overlap.
+            pin = B <= 8 and os.environ.get('CROWDNAV_AMD_RL_PINNED', '1') != '0'
+            hkey = (id(eng), B, max_steps, human_num, D, pin)
             if getattr(self, '_rl_hist', (None,))[0] != hkey:
                 z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=eng.device)  # noqa: E731
                 # reward / min-distance / action / info histories are four regions of ONE byte buffer: one blocking copy
                 # brings all of them to the host (four of them were a tenth of a millisecond per sampled episode)
                 n = max_steps * B
-                packed = z((20 * n,), torch.uint8)
+                packed = torch.zeros((20 * n,), dtype=torch.uint8).pin_memory() if pin else z((20 * n,), torch.uint8)
                 rew_, dmn_ = packed[:8 * n].view(torch.float64).view(max_steps, B), packed[8 * n:16 * n].view(torch.float64).view(max_steps, B)
                 act_ = packed[16 * n:20 * n].view(torch.int32).view(max_steps, B)
                 # the info codes go to PINNED host memory: the kernels only write them, and the host watches the episode ends
@@ -508,6 +513,7 @@ class Explorer(object):
             # device is) and stops issuing once every env's episode-end code is there; the steps already issued for an env
             # that has finished are skipped by the kernels (two-launch route) or step a retired env (general route).
             step = eng.sarl_sampler(traj, rew, inf, dmn, act, alive, done, action)
+            fused_before = eng.launch_counts()['sarl_decide_steps']
             eps = float(policy.epsilon)
             ahead, seen, spins = int(os.environ.get('CROWDNAV_AMD_RL_AHEAD', '2')), 0, 0
             finished = np.zeros(B, dtype=bool)
@@ -526,11 +532,16 @@ class Explorer(object):
                         break
                 if finished.all():
                     break
-            eng.sync()
+            # pinned histories are complete up to every env's end code once that code is there — provided the steps ran the
+            # two-launch route (its last kernel writes a step's outputs in that order; launch counters: host-side, no device
+            # work); anything else waits for the device as before
+            fused_steps = eng.launch_counts()['sarl_decide_steps'] - fused_before
+            if not (pin and fused_steps == T and finished.all()):
+                eng.sync()
             lap('steps')
             if prof is not None:
                 prof['n_steps_issued'] = prof.get('n_steps_issued', 0) + T
-            host, n = packed.cpu().numpy(), max_steps * B
+            host, n = (packed if pin else packed.cpu()).numpy(), max_steps * B
             lap('  (histories to the host)')
             R, Dm = host[:8 * n].view(np.float64).reshape(max_steps, B)[:T], host[8 * n:16 * n].view(np.float64).reshape(max_steps, B)[:T]
             Ac, I = host[16 * n:20 * n].view(np.int32).reshape(max_steps, B)[:T], inf_np[:T].copy()
@@ -556,13 +567,15 @@ class Explorer(object):
                     nxt = cat([traj[b, 1:n_ + 1] for b, n_ in zip(keep, ns)])
                     r = cat([rew[:n_, b] for b, n_ in zip(keep, ns)])
                     ends = np.cumsum(ns) - 1                                              # the last step of every episode
+                    if pin:  # (a slice of the pinned history: goes up behind the steps, asynchronously)
+                        r = r.to(eng.device, non_blocking=True)
                 else:  # (an episode as long as the histories: its row n does not exist)
                     b_idx = np.repeat(keep, Tb[keep])
                     i_idx = np.concatenate([np.arange(Tb[b]) for b in keep])
                     bt = torch.as_tensor(b_idx, device=eng.device)
                     it = torch.as_tensor(i_idx, device=eng.device)
                     states, nxt = traj[bt, it], traj[bt, torch.clamp(it + 1, max=max_steps - 1)]
-                    r = rew[it, bt]
+                    r = torch.from_numpy(R[i_idx, b_idx]).to(eng.device) if pin else rew[it, bt]
                     ends = np.flatnonzero(i_idx == Tb[b_idx] - 1)
                 if single:
                     states, nxt = states[:, 0], nxt[:, 0]

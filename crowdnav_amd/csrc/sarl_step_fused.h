@@ -158,10 +158,15 @@ __global__ __launch_bounds__(kMaxBlock) void sarl_decide_step_kernel(Params P, S
                                 robot_action, lane_vel);
     if (L.valid) {
         if (L.a == 0) {
+            // (info LAST: reward / dmin / info — and the action further up — may live in pinned host memory, where a caller that
+            // watches info arrive takes the step's other outputs as written)
             io.reward[L.env] = res.reward;
-            io.done[L.env] = res.done;
-            io.info[L.env] = res.info;
             if (io.dmin) io.dmin[L.env] = res.dmin;
+            io.done[L.env] = res.done;
+            // (an episode's LAST step: its outputs have been acknowledged before the end code goes out — a system-scope release,
+            // once per episode; earlier steps are ordered by the kernel boundaries between them)
+            if (res.done) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            io.info[L.env] = res.info;
             if (io.update) {
                 S.gtime[L.env] = gtime;
                 S.theta[L.env] = theta;

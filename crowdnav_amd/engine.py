@@ -438,7 +438,10 @@ def _sarl_sampler(self, traj, rew, info, dmin, act, alive, done, action):
     for t_, dt, shape in specs:  # raw addresses go to the C ABI below: every tensor on the engine's device, dense, as declared
         # (info may live in PINNED host memory instead: the kernels only write it — posted stores over the host link — and a
         # caller that streams steps can watch the episode-end codes arrive without a device synchronisation)
-        on_device = t_.device == self.device or (t_ is info and t_.device.type == 'cpu' and t_.is_pinned())
+        # (round 6, later: so may the reward / min-distance / action histories — written before the step's info code on the
+        # two-launch route; on the other routes a kernel READS the action row back: correct over the host link, only slower)
+        on_device = t_.device == self.device or (any(t_ is w for w in (info, rew, dmin, act)) and t_.device.type == 'cpu'
+                                                 and t_.is_pinned())
         if not on_device or t_.dtype != dt or tuple(t_.shape) != shape or not t_.is_contiguous():
             raise ValueError('sarl_sampler: expected a contiguous %s %s tensor on %s, got %s %s on %s (contiguous: %s)'
                              % (dt, shape, self.device, t_.dtype, tuple(t_.shape), t_.device, t_.is_contiguous()))

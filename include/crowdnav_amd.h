@@ -358,7 +358,8 @@ int cn_sarl_transform(cn_engine* e, float* out, int64_t env_stride, int sort_hum
  * state, its done flag and its entries of reward / info / dmin / best / state_out stay as its last sampled step left them
  * (the other routes keep stepping such an env, as cn_step does; either way those outputs mean nothing).  A caller that
  * cannot know an episode's end without a round trip may therefore stream a few calls past it at the price of two
- * near-empty launches each; info (written, never read, by the kernels) may point into pinned host memory so that the host
+ * near-empty launches each; info — and reward / dmin / best, which that route only writes, a step's before its info code and
+ * an episode's last step's acknowledged before it — (written, never read, by the kernels) may point into pinned host memory so that the host
  * sees the episode-end codes arrive without synchronising (compat.Explorer._run_batched_rl). */
 int cn_sarl_sample_step(cn_engine* e, double epsilon, uint8_t* alive, int32_t* best, double* action, float* state_out,
                         int64_t env_stride, int sort_humans, double* reward, uint8_t* done, uint8_t* info, double* dmin);

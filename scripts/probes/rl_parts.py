@@ -6,7 +6,9 @@ import crowdnav_amd.compat.explorer as ex
 orig = ex.Explorer.__init__
 prof = {}
 def init(self, *a, **k):
-    orig(self, *a, **k); self.rl_profile = prof
+    orig(self, *a, **k)
+    if os.environ.get('CN_RL_PARTS_NOPROF') != '1':  # (1: no laps, no extra synchronisation — only the call's own time below)
+        self.rl_profile = prof
 ex.Explorer.__init__ = init
 spec = importlib.util.spec_from_file_location('train_sarl', os.path.join(ROOT, 'examples', 'train_sarl.py'))
 mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
@@ -20,4 +22,4 @@ elif os.environ.get('CN_RL_PARTS_GC') == 'freeze':
     gc.collect(); gc.freeze()
 out = mod.run(args)
 n = int(os.environ.get('CN_RL_PARTS_EPISODES', '300'))
-print({k: round(v / n * 1e3, 3) if isinstance(v, float) else v for k, v in prof.items()}, '(ms per call)', 'env steps', out['timing']['rl_env_steps'])
+print({k: round(v / n * 1e3, 3) if isinstance(v, float) else v for k, v in prof.items()}, '(ms per call)', 'env steps', out['timing']['rl_env_steps'], 'rl_sample_s per episode: %.3f ms' % (out['timing']['rl_sample_s'] / n * 1e3))
