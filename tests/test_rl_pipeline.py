@@ -150,6 +150,42 @@ def _setup(g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('route', ['CROWDNAV_AMD_SARL_NARROW', 'CROWDNAV_AMD_SARL_FUSED_STEP', 'CROWDNAV_AMD_RL_PINNED'])
+def test_single_episode_sampling_with_pinned_histories_off_the_two_launch_route(route, monkeypatch):
+    """The reward / min-distance / action histories of a single-episode call live in pinned host memory (round 6).  Only the
+    two-launch route orders a step's outputs before its info code; on the one-tile kernels (NARROW=0: cn_sarl_explore READS the
+    action row back over the host link) and on the three-launch route (FUSED_STEP=0) the host waits for the device before it
+    reads them; PINNED=0 keeps them on the device.  Same episodes, same replay memory as the reference every time."""
+    from crowdnav_amd.compat.trainer import DeviceReplayMemory
+    monkeypatch.setenv(route, '0')
+    g = load_golden('rl_sarl_plain.npz')
+    c, env, robot, policy = _setup(g)
+    k = int(g['k'])
+    mem = DeviceReplayMemory(100000, 'cuda:0')
+    dev = torch.device('cuda:0')
+    policy.get_model().to(dev)
+    policy.set_device(dev)
+    ex = c.Explorer(env, robot, dev, mem, float(g['gamma']), target_policy=policy)
+    ex.max_envs = 1
+    ex.update_target_model(policy.get_model())
+    env.case_counter['train'] = int(g['first_case'])
+    ex.run_k_episodes(k, 'train', update_memory=True, episode=0)
+    lb = ex.last_batch
+    assert lb['outcome'] == g['ep_outcome'].tolist() and lb['steps'] == g['ep_steps'].tolist()
+    for e in range(k):
+        assert lb['actions'][e] == g['ep_actions'][e][:int(g['ep_steps'][e])].tolist(), e
+    assert len(mem) == len(g['memory_values'])
+    states = torch.stack([mem[i][0].cpu() for i in range(len(mem))]).numpy()
+    values = torch.cat([mem[i][1].cpu() for i in range(len(mem))]).numpy()
+    assert np.abs(states - g['memory_states']).max() <= 5e-6 and np.abs(values - g['memory_values']).max() <= 1e-6
+    counts = ex._rl_engine_cache[1].launch_counts()
+    if route == 'CROWDNAV_AMD_RL_PINNED':
+        assert counts['sarl_decide_steps'] == counts['sarl_narrow'] > 0 and not ex._rl_hist[3].is_cuda and ex._rl_hist[2].is_cuda
+    else:
+        assert counts['sarl_decide_steps'] == 0 and not ex._rl_hist[2].is_cuda   # pinned histories, the host waited
+
+
+@pytest.mark.gpu
 def test_rl_engine_cache_follows_everything_the_engine_is_built_from():
     """Explorer._rl_engine keeps ONE engine between the 10 000 single-episode calls of train.py — found again by a fast key of
     what engine_config reads (by value, or by identity for the config object, the policy and its action-space list): any of
