@@ -316,6 +316,44 @@ __device__ __forceinline__ void reg_dense(WS& ws, In in, Init init, Emit emit) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// A layer with ONE output (a value head, an attention score) on the vector ALUs: as a 16-wide MFMA tile it executes 16 x the
+// multiply-adds it needs — 25 k-steps x NT matrix instructions of 32 cycles each for 100 inputs — and the FP32 MFMA runs at the
+// vector rate, so nothing is gained by keeping it on the matrix side.  The stream's quads are the same (`replicate` packing: lane
+// l's A fragment of k-step ks IS the weight of the input its own B fragment holds — feature 4 ks + (l >> 4) of row l & 15): every
+// lane multiplies its 25 inputs by its 25 weights (v_fma_f32), the four lane groups of a row are summed through two cross-lane
+// exchanges, the bias goes on last.  Every lane of a row ends with the row's value, as with the replicated tile.  Not the MFMA's
+// summation order: ~1e-7 of it (tests: 1e-6 of the reference).
+template <int XKS, int L, int NT, class WS, class In, class Emit>
+__device__ __forceinline__ void reg_dense_valu1(WS& ws, In in, Emit emit) {
+    constexpr RegShape S = reg_shape(L, XKS);
+    constexpr int QT = reg_total_quads(XKS), QB = reg_qbase(L, XKS), KQ = reg_cdiv(S.ks, 4);
+    static_assert(S.mt == 1 && S.bias && !S.paired, "one replicated output tile with a bias quad");
+    const f32x4 c0 = reg_take<QT>(ws, QB + reg_qpos(L, XKS, 0, 0));
+    float acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const f32x4 a = reg_take<QT>(ws, QB + reg_qpos(L, XKS, 0, 1 + q));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ks = 4 * q + kk;
+            if (ks < S.ks) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_fmaf(a[kk], in(nt, ks), acc[nt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float v = acc[nt];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        v += c0[0];
+        emit(nt, 0, f32x4{v, v, v, v});
+    }
+}
+
 // ReLU of one value; AG: the result goes to an AGPR (the asm's "=a" operand is what keeps the array in the accumulator half
 // of the register file, where the next layer's MFMAs read it as their B operand directly — arrays the compiler moves there
 // on its own are copied back with v_accvgpr_read before every use).
@@ -569,6 +607,8 @@ __global__ __launch_bounds__(kRegWaves * 64) void sarl_reg_kernel(const float* s
         f32x4 wf[4];
         {
             float sc[NT];  // attention.4: the score of (human, group) in every register of the group's lanes
+            // (stays on the matrix side although it is one output: the reference masks a score that is EXACTLY zero, sarl.py:52, and
+            // a sum in another order lands on that discontinuity for other rows — one of 1.66 M at the benchmark size, measured)
             reg_dense<KEY, kR_att_4, NT, false>(ws, [&](int nt, int ks) { return att[nt][ks >> 2][ks & 3]; }, none,
                                                 [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
             CN_SARL_TICK(8);
@@ -705,8 +745,8 @@ __global__ __launch_bounds__(kRegWaves * 64) void cadrl_reg_kernel(const float* 
                 reg_dense_arr<NK, 2, NT, true>(ws, [&](int nt, int ks) { return h2[nt][ks >> 2][ks & 3]; }, none, h3);
             }
             float sc[NT];
-            reg_dense<NK, 3, NT, false>(ws, [&](int nt, int ks) { return h3[nt][ks >> 2][ks & 3]; }, none,
-                                        [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
+            reg_dense_valu1<NK, 3, NT>(ws, [&](int nt, int ks) { return h3[nt][ks >> 2][ks & 3]; },
+                                       [&](int nt, int, f32x4 v) { sc[nt] = v[0]; });
 #pragma unroll
             for (int i = reg_qbase(reg_layers(NK), NK); i < QT; ++i) (void)reg_take<QT>(ws, i);
             if (c == 0) m = sc[0];  // torch.min over dim 0: the first minimum's value
